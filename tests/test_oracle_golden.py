@@ -1,0 +1,211 @@
+"""Pin the CPU oracle against golden vectors produced by the reference itself (tests/golden/make_golden.py).
+CPU only (`-m "not gpu"`)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from oracle import ddim as oddim
+from oracle import flow as oflow
+from oracle import hooks as ohooks
+from oracle import unet as ounet
+from vface_amd.utils import synth
+
+TINY = ounet.UNetSpec(model_channels=32)
+
+
+def tiny_sd():
+    return synth.synth_state_dict(ounet.param_shapes(TINY), seed=0)
+
+
+# ------------------------------------------------------------------ FSAI
+@pytest.mark.parametrize("d", [320, 640, 1280])
+@pytest.mark.parametrize("ratio", [0.8, 0.5])
+def test_fsai_matches_reference(d, ratio):
+    g = load_golden("fsai")
+    q1 = synth.synth_normal(f"fsai.q1.{d}", (2, 5, d), seed=1)
+    q2 = synth.synth_normal(f"fsai.q2.{d}", (2, 5, d), seed=2)
+    out = ohooks.combine_fft_high_low(q1, q2, ratio)
+    assert torch.allclose(out, g[f"d{d}_r{ratio}"], atol=2e-6, rtol=0)
+    outh = ohooks.combine_fft_high_low(q1.half(), q2.half(), ratio)
+    assert torch.allclose(outh, g[f"d{d}_r{ratio}_h"], atol=2e-6, rtol=0)
+    # the same map as two real matrices
+    a_lo, a_hi = ohooks.fsai_matrices(d, ratio)
+    lin = (q2.double() @ a_lo + q1.double() @ a_hi).float()
+    assert (lin - g[f"d{d}_r{ratio}"]).abs().max() < 5e-6
+    assert torch.allclose(a_lo + a_hi, torch.eye(d, dtype=torch.float64), atol=1e-12)
+
+
+# ------------------------------------------------------------------ flow warp
+FLOW_CASES = ["zero", "subpixel", "pm3", "integer", "oob", "smooth"]
+
+
+def _flows():
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from cases import make_flows
+    return {k: torch.from_numpy(v) for k, v in make_flows(64, 64).items()}
+
+
+@pytest.mark.parametrize("case", FLOW_CASES)
+def test_warp_indices_bit_exact_and_values(case):
+    g = load_golden("warp")
+    fl = _flows()[case]
+    x0, y0 = oflow.gather_indices(fl)
+    assert torch.equal(x0, g[f"x0_{case}"]) and torch.equal(y0, g[f"y0_{case}"])
+    ix, iy = oflow.sample_coords(fl)
+    assert torch.equal(ix, g[f"ix_{case}"]) and torch.equal(iy, g[f"iy_{case}"])
+    img = synth.synth_normal("warp.img", (3, 8, 64, 64), seed=3)
+    out = oflow.warp_image(img[0], fl)
+    assert torch.allclose(out, g[f"warp_{case}"], atol=3e-6, rtol=0)
+
+
+def test_align_by_flow_not_recurrent():
+    g = load_golden("warp")
+    fl = _flows()
+    img = synth.synth_normal("warp.img", (3, 8, 64, 64), seed=3)
+    flows = [fl["pm3"][None], fl["smooth"][None]]
+    for a, key in ((0.8, "align_a0.8"), (0.5, "align_a0.5")):
+        out = oflow.align_by_flow(img, flows, a)
+        assert torch.allclose(out, g[key], atol=3e-6, rtol=0)
+        assert torch.equal(out[0], img[0])  # frame 0 untouched
+
+
+# ------------------------------------------------------------------ hooked attention module at the real shape
+@pytest.mark.parametrize("mode", ["plain", "replace", "fft", "flow_fix"])
+def test_attn_module_level0(mode):
+    g = load_golden("attn_module")
+    F_, n, d = 2, 4096, 320
+    sd = synth.synth_state_dict({"attn1.to_q.weight": (d, d), "attn1.to_k.weight": (d, d),
+                                 "attn1.to_v.weight": (d, d), "attn1.to_out.0.weight": (d, d),
+                                 "attn1.to_out.0.bias": (d,)})
+    x = synth.synth_normal("attnmod.x", (3 * F_, n, d))
+    flow = [synth.synth_flow(F_ - 1, 64, 64)[i][None] for i in range(F_ - 1)]
+    cfg = None if mode == "plain" else ohooks.HookCfg(True, 3, mode, flow, 0.8, 0.8)
+    out = ohooks.attention(x, sd["attn1.to_q.weight"], sd["attn1.to_k.weight"], sd["attn1.to_v.weight"],
+                           sd["attn1.to_out.0.weight"], sd["attn1.to_out.0.bias"], 8, None, cfg, (64, 64))
+    assert rel_l2(out[:, ::128], g[mode]) < 2e-6
+
+
+# ------------------------------------------------------------------ tiny UNet, every hook mode
+def test_attn1_ordinal_table():
+    g = load_golden("tiny_unet")
+    names = ounet.attn1_names(TINY)
+    for grp in ("input_blocks", "middle_block", "output_blocks"):
+        ref = [str(s) for s in g[f"names_{grp}"]]
+        # the reference enumerates inside the group (names relative to input_blocks / middle_block / ...)
+        mine = [n.split(".", 1)[1] for n in names[grp]]
+        assert mine == ref
+    assert [len(names[k]) for k in ("input_blocks", "middle_block", "output_blocks")] == [6, 1, 9]
+
+
+def test_param_shapes_match_reference_count():
+    # 859.5 M parameters for the shipped configuration
+    total = sum(int(np.prod(s)) for s in ounet.param_shapes(ounet.UNetSpec()).values())
+    assert abs(total / 1e6 - 859.5) < 0.1
+
+
+def _tiny_run(registry, n=6):
+    F_ = 2
+    x = synth.synth_normal("tiny.x", (3 * F_, 9, 64, 64))[:n]
+    ctx = synth.synth_normal("tiny.ctx", (3 * F_, 1, 768))[:n]
+    t = torch.full((n,), 481, dtype=torch.long)
+    return ounet.unet_forward(tiny_sd(), TINY, x, t, ctx, registry)
+
+
+TINY_MODES = ["plain", "off", "in_replace", "in_fft", "in_flow_fix", "in_temporal", "in_adaIn", "in_mix",
+              "in_fft_vfixed", "out_fft", "sel_replace_025", "chunks2"]
+
+
+@pytest.mark.parametrize("mode", TINY_MODES)
+def test_tiny_unet_modes(mode):
+    g = load_golden("tiny_unet")
+    names = ounet.attn1_names(TINY)
+    flow = [synth.synth_flow(1, 64, 64)[0][None]]
+    reg = {}
+    allidx = list(range(9))
+    n = 6
+    if mode == "plain":
+        reg = None
+    else:
+        ohooks.register_spa_attn_injection(reg, names, 1, switch_on=False, input_blocks=True, middle_block=True,
+                                           output_blocks=True, chunks=3)
+        if mode.startswith("in_"):
+            ohooks.register_spa_attn_injection(reg, names, 1, switch_on=True, input_blocks=True,
+                                               middle_block=False, output_blocks=False, flow=flow, chunks=3,
+                                               block_indices=allidx, fusion=mode[3:], split_ratio_fft=0.8,
+                                               alpha=0.8)
+        elif mode == "out_fft":
+            ohooks.register_spa_attn_injection(reg, names, 1, switch_on=True, input_blocks=False,
+                                               middle_block=False, output_blocks=True, chunks=3,
+                                               block_indices=allidx, fusion="fft")
+        elif mode == "sel_replace_025":
+            ohooks.register_spa_attn_injection(reg, names, 1, switch_on=True, input_blocks=True,
+                                               middle_block=True, output_blocks=True, chunks=3,
+                                               block_indices=[0, 2, 5], fusion="replace")
+        elif mode == "chunks2":
+            ohooks.register_spa_attn_injection(reg, names, 1, switch_on=True, input_blocks=True,
+                                               middle_block=False, output_blocks=True, chunks=2,
+                                               block_indices=[0, 1, 2])
+            n = 4
+    out = _tiny_run(reg, n)
+    assert rel_l2(out, g[mode]) < 1e-5, mode
+    if mode == "off":
+        assert torch.equal(g["off"], g["plain"])  # switch_on=False == unpatched forward (reference fact)
+
+
+# ------------------------------------------------------------------ DDIM schedule, sampling loop, inversion
+@pytest.mark.parametrize("S", [50, 20, 25])
+def test_schedule(S):
+    g = load_golden("ddim")
+    sch = oddim.Schedule(S, 0.0)
+    assert np.array_equal(sch.timesteps, g[f"S{S}_timesteps"].numpy())
+    assert np.array_equal(np.asarray(sch.alphas, np.float64), g[f"S{S}_alphas"].numpy())
+    assert np.array_equal(np.asarray(sch.alphas_prev, np.float64), g[f"S{S}_alphas_prev"].numpy())
+    assert np.array_equal(np.asarray(sch.sqrt_one_minus_alphas, np.float64), g[f"S{S}_sqrt_1m"].numpy())
+    assert np.array_equal(sch.alphas_cumprod.numpy(), g["alphas_cumprod"].numpy())
+    if S == 50:
+        assert sch.timesteps[0] == 1 and sch.timesteps[-1] == 981
+
+
+def _ddim_inputs():
+    F_, h, w = 2, 64, 64
+    d = dict(
+        x_T=synth.synth_normal("ddim.xT", (F_, 4, h, w)), c=synth.synth_normal("ddim.c", (F_, 1, 768)),
+        uc=synth.synth_normal("ddim.uc", (F_, 1, 768)), tc=synth.synth_normal("ddim.tc", (F_, 1, 768)),
+        inp=synth.synth_normal("ddim.inpaint", (F_, 4, h, w)) * 0.18215, mask=synth.synth_mask(F_, h, w),
+        flow=[synth.synth_flow(F_ - 1, h, w)[i][None] for i in range(F_ - 1)])
+    return d
+
+
+def test_sample_three_steps_shipped_hook_schedule():
+    g = load_golden("ddim")
+    d = _ddim_inputs()
+    sd = tiny_sd()
+    names = ounet.attn1_names(TINY)
+    inv = {int(s): synth.synth_normal(f"ddim.inv.{int(s)}", (2, 4, 64, 64)) for s in oddim.ddim_timesteps(50)}
+
+    def apply_model(x, t, c, reg):
+        return ounet.unet_forward(sd, TINY, x, t, c, reg)
+
+    img, trace = oddim.sample(apply_model, names, 50, d["x_T"], d["c"], d["uc"], d["tc"], inv, d["inp"], d["mask"],
+                              scale=3.0, eta=0.0, flow=d["flow"], steps_limit=3)
+    assert rel_l2(img, g["sample3_final"]) < 2e-5
+    assert rel_l2(torch.stack(trace), g["sample3_x_inter"]) < 2e-5
+
+
+def test_invert_two_steps():
+    g = load_golden("ddim")
+    d = _ddim_inputs()
+    sd = tiny_sd()
+    x0 = synth.synth_normal("ddim.z2", (4, 4, 64, 64))
+    cond2 = torch.cat([d["tc"], d["c"]], 0)
+
+    def apply_model(x, t, c, reg):
+        return ounet.unet_forward(sd, TINY, x, t, c, None)
+
+    xn, saved = oddim.invert(apply_model, 50, x0, cond2, torch.cat([d["inp"]] * 2), torch.cat([d["mask"]] * 2),
+                             batch_size=2, steps_limit=2)
+    assert rel_l2(xn, g["invert2_final"]) < 2e-5
+    assert rel_l2(saved[1], g["invert2_saved_1"]) < 2e-5
+    assert rel_l2(saved[21], g["invert2_saved_21"]) < 2e-5
