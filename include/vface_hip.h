@@ -1,0 +1,151 @@
+/* vface_hip.h -- C ABI of libvface_hip.so: the MI355X (gfx950) kernels behind VFace's per-frame DDIM
+ * denoising hot path.
+ *
+ * The reference (Sanoojan/VFace, REFace/) has no FFI: its extension point is Python -- nn.Module
+ * forwards and the closure `register_spa_attn_injection` installs on every `attn1`
+ * (REFace/ldm/models/pnp_utils.py:57,289-339).  Each entry point below names the reference
+ * call site(s) whose device work it replaces; the Python side that binds them (ctypes, raw device
+ * pointers + the current HIP stream) is vface_amd/hip.py, and INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless said otherwise; no allocation, no synchronisation, no
+ *    global state inside: calls only enqueue kernels on `stream` (a hipStream_t passed as void*), so
+ *    they can be captured into a hipGraph; re-entrant per stream.
+ *  - `dtype`: 0 = fp16 (the reference's autocast type), 1 = bf16.  Accumulation, softmax and
+ *    normalisation statistics are always fp32.
+ *  - activations are token-major / NHWC: element (sample b, pixel p, channel c) at
+ *    base[(b*HW + p)*ld + c]; `ld` lets a tensor be a channel slice of a wider (concatenated) buffer.
+ *  - 16-bit rows must be 16-byte aligned and channel counts multiples of 8.
+ *  - return value: 0 = ok; negative = VFACE_ERR_* (nothing was launched).  No exceptions cross the ABI.
+ */
+#ifndef VFACE_HIP_H
+#define VFACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VFACE_ABI_VERSION 1
+
+#define VFACE_OK 0
+#define VFACE_ERR_ARG (-1)
+#define VFACE_ERR_ALIGN (-2)
+#define VFACE_ERR_SHAPE (-3)
+#define VFACE_ERR_DTYPE (-4)
+#define VFACE_ERR_LAUNCH (-5)
+#define VFACE_ERR_WORKSPACE (-6)
+
+#define VFACE_F16 0
+#define VFACE_BF16 1
+
+/* epilogue flags of vface_gemm / vface_conv3x3 */
+#define VFACE_EPI_GEGLU 1   /* out[m][c] = (acc_val + b) * gelu(acc_gate + b); Wt rows packed by vface layout */
+#define VFACE_EPI_OUT_F32 2 /* store fp32 instead of the 16-bit type */
+
+/* fusion modes of the attn1 hook (pnp_utils.py:133-262) understood by vface_attn1_forward */
+#define VFACE_FUSION_NONE 0       /* switch_on == False, or unpatched CrossAttention.forward */
+#define VFACE_FUSION_REPLACE 1    /* :133-143 and chunks == 2 (:259-262): q,k of every chunk <- chunk 0 */
+#define VFACE_FUSION_LINEAR 2     /* "fft"/"flow_fix"/"fft_vfixed"/"mix": q,k <- own*W_a + chunk0*W_b (folded weights) */
+
+int vface_abi_version(void);
+const char* vface_error_string(int code);
+
+/* C[M][N] (+)= A[M][K] * Wt[N][K]^T with fused epilogue.
+ * Replaces every nn.Linear / 1x1 conv on the path: to_q/to_k/to_v/to_out (attention.py:161-177),
+ * GEGLU + FeedForward (attention.py:37-64), proj_in/proj_out (attention.py:261-276), ResBlock
+ * emb_layers / skip_connection (openaimodel.py:218-241), time_embed (openaimodel.py:631-636).
+ * A2 (optional): columns [K1, K) of the A operand come from A2[m % a2_row_mod][k - K1] (K1 % 64 == 0).
+ * rowbias: fp32 [M/rows_per_sample][ld_rowbias] added per sample (time-embedding / cross-attention vector). */
+int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1, int a2_row_mod, const void* Wt,
+               int64_t ldw, int M, int N, int K, const float* bias, const float* rowbias, int rows_per_sample,
+               int ld_rowbias, const void* residual, int64_t ldr, void* C, int64_t ldc, const void* zeros, int flags,
+               int dtype, void* stream);
+
+/* Y = conv3x3(X) over NHWC, padding 1, stride 1|2, optional nearest x2 upsampling of X first, as an
+ * implicit GEMM (nothing materialised).  Wt packed [Cout][3][3][Cin].
+ * Replaces nn.Conv2d in ResBlock.in_layers/out_layers (openaimodel.py:201-232), Downsample.op (:151-153),
+ * Upsample.conv after F.interpolate (:108-118), input_blocks.0 (:668-674) and `out` (:821-825). */
+int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw, int Cout,
+                  int stride, int upsample, const float* bias, const float* rowbias, int ld_rowbias,
+                  const void* residual, int64_t ldr, void* Y, int64_t ldy, const void* zeros, int flags, int dtype,
+                  void* stream);
+
+/* O = softmax(Q K^T * scale) V per (sample, head), streaming softmax, no [n x n] matrix.
+ * Replaces attention.py:206-220 / pnp_utils.py:270-285.  Output sample b uses q,k of sample qk_map[b] and
+ * v of sample v_map[b] (NULL = identity): the zero-copy form of the hook's q/k/v row assignments. */
+int vface_attention(const void* Q, const void* K, const void* V, int64_t ldq, int64_t ldk, int64_t ldv, int64_t bsq,
+                    int64_t bsk, int64_t bsv, const int32_t* qk_map, const int32_t* v_map, void* O, int64_t ldo,
+                    int64_t bso, int B, int heads, int n, int nk, int dh, float scale, int dtype, void* stream);
+
+/* y = LayerNorm(x) * gamma + beta, fp32 statistics (attention.py:231-233). */
+int vface_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy, int M,
+                    int C, float eps, int dtype, void* stream);
+
+/* GroupNorm statistics (mean, rstd) per (image, group) -> stats[nimg][groups][2] fp32;
+ * `partial` is scratch of vface_groupnorm_partial_floats() floats.  util.py:214-216, attention.py:76-77. */
+int vface_groupnorm_partial_floats(int nimg, int hw, int C, int groups);
+int vface_groupnorm_stats(const void* x, int64_t ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
+                          float* stats, int dtype, void* stream);
+/* y = (x - mean) * rstd * gamma + beta, then SiLU if `silu` (openaimodel.py:201-205,225-232). */
+int vface_groupnorm_apply(const void* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
+                          void* y, int64_t ldy, int nimg, int hw, int C, int groups, int silu, int dtype, void* stream);
+
+/* Flow-guided temporal smoothing of a token-major map [F][h*w][C] (temporal_flow.py:40-53,222-237):
+ *   dst[f] = alpha * src[f] + one_minus_alpha * bilinear(src[f-1], (x + dx, y + dy)); dst[0] = src[0]
+ * (or warped from `prev` with `flow_prev` when given: the previous rank's boundary frame).
+ * flow: fp32 [F-1][2][h][w] in pixels of the map; channel 0 = dx, 1 = dy.  Sampling coordinates follow
+ * the reference's fp32 operation order exactly (bit-exact gather indices); flags bit 0 = use CUDA-ATen's
+ * multiply-by-reciprocal for the scalar division.  dbg_x0/dbg_y0 (optional, int32 [F-1][h][w]) receive
+ * the integer north-west corner of every bilinear footprint. */
+int vface_flow_warp(const void* src, int64_t ld_src, int64_t fs_src, const void* prev, int64_t ld_prev,
+                    const float* flow, const float* flow_prev, void* dst, int64_t ld_dst, int64_t fs_dst, int F,
+                    int h, int w, int C, float alpha, float one_minus_alpha, int flags, int32_t* dbg_x0,
+                    int32_t* dbg_y0, int dtype, void* stream);
+
+/* The hooked self-attention as one call (pnp_utils.py:94-287, the closure installed on attn1):
+ *   x [B][n][d] (already LayerNorm'd), B = chunks * F laid out [uncond ; cond ; recon]
+ *   Wqkv [3d][d]  = rows of to_q | to_k | to_v
+ *   Wlin [2d][2d] = folded weights of a LINEAR fusion (rows q|k, columns [own x | chunk-0 x]) or NULL
+ *   out = to_out(attention) + bo + rowbias[sample] + residual
+ * flow != NULL (and h*w == n): chunk 1's fused q,k are smoothed by vface_flow_warp before attention
+ * (pnp_utils.py:201-218).  v_fixed: v of chunks 1,2 <- their first frame (fft_vfixed :255-256).
+ * halo_qk / halo_flow: previous rank's last-frame fused q|k [n][2d] and the flow into this rank's frame 0.
+ * tail_qk (optional out): this rank's last-frame fused q|k, to hand to the next rank.
+ * workspace: vface_attn1_workspace_bytes() bytes. */
+size_t vface_attn1_workspace_bytes(int B, int n, int d, int chunks);
+int vface_attn1_forward(const void* x, int64_t ldx, const void* Wqkv, const void* Wlin, const void* Wo,
+                        const float* bo, const float* rowbias, int ld_rowbias, const void* residual, int64_t ldr,
+                        void* out, int64_t ldo, int B, int n, int d, int heads, int chunks, int fusion,
+                        int v_fixed, const float* flow, int h, int w, float alpha, float one_minus_alpha,
+                        int warp_flags, const void* halo_qk, const float* halo_flow, void* tail_qk,
+                        const int32_t* qk_map, const int32_t* v_map, void* workspace, size_t workspace_bytes,
+                        const void* zeros, int dtype, void* stream);
+
+/* Small ops */
+/* util.py:151-171 timestep_embedding: out[N][dim] = [cos(t f_i) | sin(t f_i)] */
+int vface_timestep_embedding(const int64_t* t, void* out, int N, int dim, int dtype, void* stream);
+/* nn.SiLU on a flat buffer (time_embed / emb_layers, openaimodel.py:218-224,631-636); in_f32: x is fp32 */
+int vface_silu(const void* x, void* y, int64_t count, int in_f32, int dtype, void* stream);
+int vface_cast_f32(const float* src, void* dst, int64_t count, int dtype, void* stream);
+/* ddim_w_inv.py:633,654-655: x_in = cat[cat[x,inp,mask], cat[x,inp,mask], cat[inv_t,inp,mask]] -> NHWC [3F][hw][cpad] */
+int vface_pack_unet_input(const float* x, const float* inv, const float* inpaint, const float* mask, void* out, int F,
+                          int h, int w, int cpad, int dtype, void* stream);
+int vface_nchw_to_nhwc(const float* x, void* out, int N, int C, int hw, int cpad, int dtype, void* stream);
+int vface_nhwc_to_nchw_f32(const float* x, int64_t ldx, float* out, int N, int C, int hw, void* stream);
+/* ddim_w_inv.py:666-667,686-700: guidance + x0 prediction + x_{t-1}; eps = NHWC fp32 UNet output of
+ * [uncond ; cond ; recon]; x, inv, outputs NCHW fp32 [F][C][hw].  pred_x0 / x_prev_recon / noise optional. */
+int vface_ddim_step(const float* eps, int64_t lde, const float* x, const float* inv, float* x_prev, float* pred_x0,
+                    float* x_prev_recon, int F, int C, int hw, float scale, float a_t, float a_prev, float sigma_t,
+                    float sqrt_one_minus_at, const float* noise, void* stream);
+/* strided 2-D copy of 16-bit rows (th.cat([h, hs.pop()], 1), openaimodel.py:898, when not written in place) */
+int vface_copy2d(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols, int dtype,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFACE_HIP_H */

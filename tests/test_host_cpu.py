@@ -1,0 +1,88 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol the header declares,
+the ctypes table matches the header's argument counts, and the weight packing is an exact refactoring."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT
+from oracle import hooks as ohooks
+from vface_amd import packing
+
+HEADER = os.path.join(ROOT, "include", "vface_hip.h")
+LIB = os.path.join(ROOT, "vface_amd", "lib", "libvface_hip.so")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(vface_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        decls[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return decls
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(LIB):
+        import __graft_entry__ as ge
+        ge.build()
+    lib = ctypes.CDLL(LIB)
+    decls = _declared()
+    assert len(decls) >= 20
+    for name in decls:
+        assert hasattr(lib, name), f"{name} declared in include/vface_hip.h but not exported"
+    lib.vface_abi_version.restype = ctypes.c_int
+    assert lib.vface_abi_version() == 1
+
+
+def test_ctypes_table_matches_header():
+    from vface_amd import hip
+    decls = _declared()
+    assert set(decls) == set(hip.SIGNATURES)
+    for name, n in decls.items():
+        assert len(hip.SIGNATURES[name][1]) == n, name
+
+
+def test_no_gpu_means_loud_failure():
+    from vface_amd import hip
+    hip.load()
+    a = torch.zeros(8, 8, dtype=torch.float16)
+    with pytest.raises(hip.VFaceHipError):
+        hip.gemm(a, a, a, M=8, N=8, K=8, lda=8, ldc=8)
+
+
+@pytest.mark.parametrize("d,ratio", [(64, 0.8), (320, 0.8), (320, 0.5)])
+def test_fold_fsai_is_exact(d, ratio):
+    g = torch.Generator().manual_seed(0)
+    wq, wk = torch.randn(d, d, generator=g) / d ** 0.5, torch.randn(d, d, generator=g) / d ** 0.5
+    x_own, x_st = torch.randn(5, d, generator=g), torch.randn(5, d, generator=g)
+    wl = packing.fold_fsai(wq, wk, ratio).double()
+    got = torch.cat([x_own, x_st], 1).double() @ wl.t()
+    for i, w in enumerate((wq, wk)):
+        ref = ohooks.combine_fft_high_low(x_st @ w.t(), x_own @ w.t(), ratio)
+        assert (got[:, i * d:(i + 1) * d].float() - ref).abs().max() < 5e-6
+
+
+def test_pack_geglu_and_conv():
+    g = torch.Generator().manual_seed(1)
+    d = 32
+    w, b = torch.randn(8 * d, d, generator=g), torch.randn(8 * d, generator=g)
+    wp, bp = packing.pack_geglu(w, b)
+    x = torch.randn(3, d, generator=g)
+    y = x @ wp.t() + bp
+    y = y.reshape(3, -1, 2, 16)
+    val, gate = y[:, :, 0].reshape(3, -1), y[:, :, 1].reshape(3, -1)
+    ref_v, ref_g = (x @ w.t() + b).chunk(2, -1)
+    assert torch.allclose(val, ref_v, atol=1e-5) and torch.allclose(gate, ref_g, atol=1e-5)
+    cw = torch.randn(6, 9, 3, 3, generator=g)
+    pw = packing.pack_conv3x3(cw)
+    assert pw.shape == (6, 9 * 16)
+    xi = torch.randn(1, 9, 5, 5, generator=g)
+    ref = F.conv2d(xi, cw, padding=1)
+    cols = F.unfold(F.pad(xi, (0, 0, 0, 0, 0, 7)), 3, padding=1)  # [1, 16*9, 25], (c, ky, kx) order
+    cols = cols.reshape(1, 16, 9, 25).permute(0, 2, 1, 3).reshape(1, 144, 25)  # -> (ky, kx, c)
+    assert torch.allclose((pw @ cols[0]).reshape(1, 6, 5, 5), ref, atol=1e-5)

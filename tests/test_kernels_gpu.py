@@ -1,0 +1,294 @@
+"""Per-kernel parity on the MI355X: each C-ABI entry point against a torch-CPU fp32 computation of the
+same op on the same (16-bit-rounded) inputs, and against the reference-generated golden vectors.
+Tolerances: rel-L2 <= 1e-3 for fp16 outputs (the north-star bound), looser and stated for bf16."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+TOL = {torch.float16: 1e-3, torch.bfloat16: 8e-3}
+
+
+def hip():
+    from vface_amd import hip as h
+    h.load()
+    return h
+
+
+def rnd(shape, seed, dt, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dt)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (200, 72, 136), (1000, 320, 320), (24, 1280, 320), (4096, 960, 320)])
+def test_gemm_plain_bias_residual(dt, M, N, K):
+    h = hip()
+    a, w = rnd((M, K), 1, dt), rnd((N, K), 2, dt, 1 / math.sqrt(K))
+    bias = rnd((N,), 3, torch.float32)
+    res = rnd((M, N), 4, dt)
+    out = torch.empty(M, N, dtype=dt, device=DEV)
+    h.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias.to(DEV), residual=res.to(DEV), ldr=N)
+    ref = a.float() @ w.float().t() + bias + res.float()
+    assert rel_l2(out.cpu().float(), ref) < TOL[dt]
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    h.gemm(a.to(DEV), w.to(DEV), out32, M=M, N=N, K=K, lda=K, ldc=N, flags=h.EPI_OUT_F32)
+    assert rel_l2(out32.cpu(), a.float() @ w.float().t()) < 1e-5
+
+
+def test_gemm_strided_views_rowbias_dual_source():
+    h = hip()
+    dt = torch.float16
+    M, N, K = 512, 192, 128
+    big = rnd((M, 3 * K), 1, dt)  # a is the middle column block of a wider buffer
+    a2 = rnd((M // 2, K), 5, dt)
+    w = rnd((N, 2 * K), 2, dt, 1 / math.sqrt(2 * K))
+    rb = rnd((4, N), 3, torch.float32)
+    outbig = torch.zeros(M, N + 64, dtype=dt, device=DEV)
+    bigd = big.to(DEV)
+    h.gemm(bigd[:, K:], w.to(DEV), outbig[:, 32:], M=M, N=N, K=2 * K, lda=3 * K, ldc=N + 64, rowbias=rb.to(DEV),
+           rows_per_sample=M // 4, a2=a2.to(DEV), lda2=K, k1=K, a2_row_mod=M // 2)
+    acat = torch.cat([big[:, K:2 * K].float(), a2.float().repeat(2, 1)], 1)
+    ref = acat @ w.float().t() + rb.repeat_interleave(M // 4, 0)
+    got = outbig.cpu().float()
+    assert rel_l2(got[:, 32:32 + N], ref) < 1e-3
+    assert got[:, :32].abs().max() == 0 and got[:, 32 + N:].abs().max() == 0  # nothing outside the view
+
+
+def test_gemm_geglu():
+    h = hip()
+    dt = torch.float16
+    M, d = 300, 64
+    x = rnd((M, d), 1, dt)
+    w = rnd((8 * d, d), 2, dt, 1 / math.sqrt(d))
+    b = rnd((8 * d,), 3, torch.float32, 0.1)
+    from vface_amd.packing import pack_geglu
+    wp, bp = pack_geglu(w, b)
+    out = torch.empty(M, 4 * d, dtype=dt, device=DEV)
+    h.gemm(x.to(DEV), wp.to(DEV), out, M=M, N=8 * d, K=d, lda=d, ldc=4 * d, bias=bp.to(DEV), flags=h.EPI_GEGLU)
+    y = x.float() @ w.float().t() + b
+    val, gate = y.chunk(2, -1)
+    assert rel_l2(out.cpu().float(), val * F.gelu(gate)) < 1e-3
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,H,W,stride,up", [(16, 64, 12, 10, 1, False), (64, 72, 16, 16, 2, False),
+                                                    (64, 64, 8, 8, 1, True), (320, 320, 16, 16, 1, False)])
+def test_conv3x3(dt, cin, cout, H, W, stride, up):
+    h = hip()
+    from vface_amd.packing import pack_conv3x3
+    nimg = 3
+    x = rnd((nimg, cin, H, W), 1, dt)
+    w = rnd((cout, cin, 3, 3), 2, dt, 1 / math.sqrt(9 * cin))
+    b = rnd((cout,), 3, torch.float32, 0.1)
+    xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if up else x.float()
+    ref = F.conv2d(xin, w.float(), b, stride=stride, padding=1)
+    OH, OW = ref.shape[2:]
+    rb = rnd((nimg, cout), 4, torch.float32)
+    res = rnd((nimg, OH, OW, cout), 5, dt)
+    ref = ref + rb[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = torch.empty(nimg, OH, OW, cout, dtype=dt, device=DEV)
+    h.conv3x3(xn, pack_conv3x3(w).to(DEV), out, nimg=nimg, H=H, W=W, cin=cin, cout=cout, ldx=cin, ldy=cout,
+              stride=stride, upsample=up, bias=b.to(DEV), rowbias=rb.to(DEV), residual=res.to(DEV), ldr=cout)
+    assert rel_l2(out.cpu().float().permute(0, 3, 1, 2), ref) < TOL[dt]
+
+
+def _attn_ref(q, k, v, heads, scale, qk_map=None, v_map=None):
+    B, n, d = q.shape
+    dh = d // heads
+    if qk_map is not None:
+        q, k = q[qk_map], k[qk_map]
+    if v_map is not None:
+        v = v[v_map]
+    sp = lambda t: t.reshape(B, t.shape[1], heads, dh).permute(0, 2, 1, 3).float()
+    s = (sp(q) @ sp(k).transpose(-1, -2)) * scale
+    return (s.softmax(-1) @ sp(v)).permute(0, 2, 1, 3).reshape(B, n, d)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("dh,n", [(8, 64), (16, 144), (32, 256), (40, 1024), (40, 576), (80, 256), (160, 64),
+                                  (160, 144), (40, 16)])
+def test_attention(dt, dh, n):
+    h = hip()
+    B, heads = 3, 8
+    d = heads * dh
+    qkv = rnd((B, n, 3 * d), 1, dt)
+    out = torch.empty(B, n, d, dtype=dt, device=DEV)
+    qd = qkv.to(DEV)
+    scale = dh ** -0.5
+    h.attention(qd, qd[:, :, d:], qd[:, :, 2 * d:], out, B=B, heads=heads, n=n, nk=n, dh=dh, ldq=3 * d, ldk=3 * d,
+                ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d, ldo=d, bso=n * d, scale=scale)
+    ref = _attn_ref(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], heads, scale)
+    assert rel_l2(out.cpu().float(), ref) < TOL[dt]
+
+
+def test_attention_sample_maps_and_spike():
+    """qk_map / v_map remapping, and a spiked key row that forces the running-max rescale late in the walk."""
+    h = hip()
+    dt = torch.float16
+    B, heads, dh, n = 6, 8, 40, 512
+    d = heads * dh
+    qkv = rnd((B, n, 3 * d), 7, dt)
+    qkv[:, 400, d:2 * d] *= 6.0  # key 400 dominates: max jumps in the 7th key block
+    qk_map = torch.tensor([0, 1, 0, 1, 0, 1], dtype=torch.int32)
+    v_map = torch.tensor([0, 1, 2, 2, 4, 4], dtype=torch.int32)
+    out = torch.empty(B, n, d, dtype=dt, device=DEV)
+    qd = qkv.to(DEV)
+    scale = dh ** -0.5
+    h.attention(qd, qd[:, :, d:], qd[:, :, 2 * d:], out, B=B, heads=heads, n=n, nk=n, dh=dh, ldq=3 * d, ldk=3 * d,
+                ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d, ldo=d, bso=n * d, scale=scale,
+                qk_map=qk_map.to(DEV), v_map=v_map.to(DEV))
+    ref = _attn_ref(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], heads, scale, qk_map.long(), v_map.long())
+    assert rel_l2(out.cpu().float(), ref) < 1e-3
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C", [64, 320, 640, 1280])
+def test_layernorm(dt, C):
+    h = hip()
+    M = 77
+    x = rnd((M, C), 1, dt, 2.0) + 0.5
+    g, b = rnd((C,), 2, torch.float32) * 0.1 + 1, rnd((C,), 3, torch.float32) * 0.1
+    out = torch.empty(M, C, dtype=dt, device=DEV)
+    h.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), out, M=M, C_=C, ldx=C, ldy=C)
+    ref = F.layer_norm(x.float(), (C,), g, b, 1e-5)
+    assert rel_l2(out.cpu().float(), ref) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C,hw,silu,eps", [(64, 100, True, 1e-5), (320, 4096, True, 1e-5), (960, 256, True, 1e-5),
+                                           (1280, 64, False, 1e-6), (2560, 64, True, 1e-5)])
+def test_groupnorm(dt, C, hw, silu, eps):
+    h = hip()
+    nimg = 3
+    x = rnd((nimg, hw, C), 1, dt, 1.5) + 0.3
+    g, b = rnd((C,), 2, torch.float32) * 0.1 + 1, rnd((C,), 3, torch.float32) * 0.1
+    xd = x.to(DEV)
+    st = h.groupnorm_stats(xd, nimg=nimg, hw=hw, C_=C, ldx=C, eps=eps)
+    out = torch.empty_like(xd)
+    h.groupnorm_apply(xd, st, g.to(DEV), b.to(DEV), out, nimg=nimg, hw=hw, C_=C, ldx=C, ldy=C, silu=silu)
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    assert rel_l2(out.cpu().float().permute(0, 2, 1), ref) < TOL[dt]
+
+
+def _flow_cases():
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from cases import make_flows
+    return {k: torch.from_numpy(v) for k, v in make_flows(64, 64).items()}
+
+
+def test_flow_warp_indices_bit_exact_vs_reference_golden():
+    """The integer gather indices must equal the reference's bit for bit (north-star); values to fp16 rounding."""
+    h = hip()
+    from vface_amd.utils import synth
+    g = load_golden("warp")
+    cases = _flow_cases()
+    names = list(cases)
+    img = synth.synth_normal("warp.img", (3, 8, 64, 64), seed=3)[0]  # [8,64,64]
+    F_ = len(names) + 1
+    src = img.permute(1, 2, 0).reshape(1, 4096, 8).repeat(F_, 1, 1).half().to(DEV)
+    flow = torch.stack([cases[n] for n in names]).to(DEV)
+    dst = torch.empty_like(src)
+    x0 = torch.empty(F_ - 1, 64, 64, dtype=torch.int32, device=DEV)
+    y0 = torch.empty_like(x0)
+    h.flow_warp(src, dst, flow, F=F_, h=64, w=64, C_=8, ld_src=8, fs_src=4096 * 8, ld_dst=8, fs_dst=4096 * 8,
+                alpha=0.0, dbg_x0=x0, dbg_y0=y0)
+    for i, n in enumerate(names):
+        assert torch.equal(x0[i].cpu(), g[f"x0_{n}"]), n
+        assert torch.equal(y0[i].cpu(), g[f"y0_{n}"]), n
+        got = dst[i + 1].cpu().float().reshape(64, 64, 8).permute(2, 0, 1)
+        assert (got - g[f"warp_{n}"]).abs().max() < 4e-3, n  # fp16 in/out of O(1) values
+    assert torch.equal(dst[0], src[0])
+
+
+def test_flow_warp_align_matches_oracle_with_halo():
+    h = hip()
+    from oracle import flow as oflow
+    from vface_amd.utils import synth
+    F_, C, hh, ww = 4, 64, 64, 64
+    x = synth.synth_normal("warp.align", (F_ + 1, C, hh, ww), seed=5).half()
+    fl = synth.synth_flow(F_, hh, ww, seed=9)
+    ref = oflow.align_by_flow(x, [fl[i] for i in range(F_)], 0.8)  # frames 1.. are the shard, frame 0 the halo
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(t.shape[0], hh * ww, C).contiguous()
+    src = tok(x[1:]).to(DEV)
+    dst = torch.empty_like(src)
+    h.flow_warp(src, dst, fl[1:].contiguous().to(DEV), F=F_, h=hh, w=ww, C_=C, ld_src=C, fs_src=hh * ww * C, ld_dst=C,
+                fs_dst=hh * ww * C, alpha=0.8, prev=tok(x[:1])[0].to(DEV), ld_prev=C, flow_prev=fl[0].contiguous().to(DEV))
+    got = dst.cpu().float()
+    assert rel_l2(got, tok(ref[1:]).float()) < 6e-4
+    # bit-identical to the oracle run at the same (fp16) storage type
+    assert (got - tok(ref[1:]).float()).abs().max() <= 2e-3
+
+
+def test_timestep_embedding_pack_and_ddim():
+    h = hip()
+    from oracle import ddim as oddim
+    from oracle import unet as ounet
+    t = torch.tensor([1, 481, 981, 21], dtype=torch.int64)
+    out = torch.empty(4, 320, dtype=torch.float16, device=DEV)
+    h.timestep_embedding(t.to(DEV), out, 320)
+    assert (out.cpu().float() - ounet.timestep_embedding(t, 320)).abs().max() < 2e-3
+    F_, hh, ww = 2, 8, 8
+    x, inv, inp = rnd((F_, 4, hh, ww), 1, torch.float32), rnd((F_, 4, hh, ww), 2, torch.float32), rnd((F_, 4, hh, ww), 3, torch.float32)
+    mask = (rnd((F_, 1, hh, ww), 4, torch.float32) > 0).float()
+    packed = torch.empty(3 * F_, hh * ww, 16, dtype=torch.float16, device=DEV)
+    h.pack_unet_input(x.to(DEV), inv.to(DEV), inp.to(DEV), mask.to(DEV), packed, F=F_, h=hh, w=ww, cpad=16)
+    x9, r9 = torch.cat([x, inp, mask], 1), torch.cat([inv, inp, mask], 1)
+    ref = torch.cat([x9, x9, r9], 0).permute(0, 2, 3, 1).reshape(3 * F_, hh * ww, 9)
+    got = packed.cpu().float()
+    assert (got[..., :9] - ref.half().float()).abs().max() == 0 and got[..., 9:].abs().max() == 0
+    eps = rnd((3 * F_, 4, hh, ww), 5, torch.float32)
+    eps_nhwc = eps.permute(0, 2, 3, 1).reshape(3 * F_ * hh * ww, 4).contiguous().to(DEV)
+    sch = oddim.Schedule(50)
+    idx = 30
+    xp, p0 = torch.empty_like(x, device=DEV), torch.empty_like(x, device=DEV)
+    h.ddim_step(eps_nhwc, x.to(DEV), inv.to(DEV), xp, F=F_, C_=4, hw=hh * ww, lde=4, scale=3.0,
+                a_t=float(sch.alphas[idx]), a_prev=float(sch.alphas_prev[idx]), sigma_t=0.0,
+                sqrt_one_minus_at=float(sch.sqrt_one_minus_alphas[idx]), pred_x0=p0)
+    e_u, e_c, e_r = eps.chunk(3)
+    e_t, _ = oddim.cfg_combine(e_u, e_c, e_r, 3.0)
+    rx, rp = oddim.ddim_update(x, e_t, float(sch.alphas[idx]), float(sch.alphas_prev[idx]), 0.0,
+                               float(sch.sqrt_one_minus_alphas[idx]))
+    assert (xp.cpu() - rx).abs().max() < 2e-6 and (p0.cpu() - rp).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("mode", ["plain", "replace", "fft", "flow_fix"])
+def test_attn1_forward_level0_vs_reference_golden(mode):
+    """The hooked attn1 as one C call at the real level-0 shape (d=320, 8 heads, n=4096, F=2) against the
+    reference-generated fixture (strided token slice)."""
+    h = hip()
+    from vface_amd.packing import fold_fsai, pack_qkv
+    from vface_amd.utils import synth
+    g = load_golden("attn_module")
+    F_, n, d = 2, 4096, 320
+    B = 3 * F_
+    sd = synth.synth_state_dict({"attn1.to_q.weight": (d, d), "attn1.to_k.weight": (d, d),
+                                 "attn1.to_v.weight": (d, d), "attn1.to_out.0.weight": (d, d),
+                                 "attn1.to_out.0.bias": (d,)})
+    x = synth.synth_normal("attnmod.x", (B, n, d)).half().to(DEV)
+    wqkv = pack_qkv(sd["attn1.to_q.weight"], sd["attn1.to_k.weight"], sd["attn1.to_v.weight"]).half().to(DEV)
+    wlin = fold_fsai(sd["attn1.to_q.weight"], sd["attn1.to_k.weight"], 0.8).half().to(DEV)
+    wo = sd["attn1.to_out.0.weight"].half().to(DEV)
+    bo = sd["attn1.to_out.0.bias"].to(DEV)
+    ws = torch.empty(h.attn1_workspace_bytes(B, n, d, 3), dtype=torch.uint8, device=DEV)
+    out = torch.empty(B, n, d, dtype=torch.float16, device=DEV)
+    kw = dict(B=B, n=n, d=d, heads=8, chunks=3, ldx=d, ldo=d, workspace=ws)
+    if mode == "plain":
+        h.attn1_forward(x, wqkv, None, wo, bo, out, fusion=h.FUSION_NONE, **kw)
+    elif mode == "replace":
+        qk_map = torch.arange(B, dtype=torch.int32) % F_
+        h.attn1_forward(x, wqkv, None, wo, bo, out, fusion=h.FUSION_REPLACE, qk_map=qk_map.to(DEV), **kw)
+    else:
+        flow = synth.synth_flow(F_ - 1, 64, 64).to(DEV) if mode == "flow_fix" else None
+        h.attn1_forward(x, wqkv, wlin, wo, bo, out, fusion=h.FUSION_LINEAR, flow=flow, h=64, w=64, alpha=0.8, **kw)
+    assert rel_l2(out[:, ::128].cpu().float(), g[mode]) < 1e-3

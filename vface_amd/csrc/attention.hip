@@ -1,0 +1,276 @@
+// Streaming-softmax multi-head attention for the VFace UNet (gfx950): O = softmax(Q K^T * scale) V
+// without materialising the [n x n] score matrix the reference builds (attention.py:206-220,
+// pnp_utils.py:270-287).  8 heads, head dim 40 / 80 / 160 (8 / 16 / 32 for the test-size UNet).
+//
+// * One workgroup = 4 waves = 64*QT queries of one (sample, head); each wave owns 16*QT queries.
+// * Keys are walked in blocks of 64.  K and V blocks are staged global -> registers -> LDS (two LDS
+//   buffers, next block's loads issued before the current block's math, written after it).
+// * Scores are computed TRANSPOSED, S^T = K Q^T, with mfma_f32_16x16x32: a lane then holds 16 keys of
+//   ONE query, so the row max / row sum are in-lane plus two cross-lane steps, and the fp32 accumulator
+//   registers, converted to 16 bit, are directly the B operand of O^T += V^T P^T (no LDS round trip).
+//   V^T fragments come from the row-major V block with ds_read_b64_tr_b16.
+// * Softmax is fp32 (as autocast keeps it, SURVEY precision map): p = exp2((s - m) * scale*log2e).
+// * Sample remapping: output sample b reads q,k of sample qk_map[b] and v of sample v_map[b].  This is
+//   how the hook's "replace" / chunks==2 injection (pnp_utils.py:136-142,259-262) and fft_vfixed's
+//   V broadcast (:255-256) run without copying anything.
+#include "common.hpp"
+#include "vface_kernels.hpp"
+
+namespace {
+
+constexpr int KVB = 64;
+
+constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
+// V row pitch in bytes: an odd multiple of 32 B so the 8 rows a 32-lane half touches in one
+// ds_read_b64_tr_b16 fall in 8 distinct 32-B bank ranges of the 256-B bank row.
+constexpr int v_pitch_bytes(int dvp) {
+    int b = round_up(dvp * 2, 32);
+    return ((b / 32) & 1) ? b : b + 32;
+}
+
+template <class TT, int DH, int QT>
+__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+    using E = typename TT::elem;
+    using V8 = typename TT::v8;
+    using V4 = typename TT::v4;
+    constexpr int DKP = round_up(DH, 32), NKS = DKP / 32;
+    constexpr int DVP = round_up(DH, 16), NC = DVP / 16;
+    constexpr int KROW = DKP + 8;                    // elements
+    constexpr int VROW = v_pitch_bytes(DVP) / 2;     // elements
+    constexpr int CPR = DH / 8;                      // 16-B chunks per row
+    constexpr int NCH = KVB * CPR;                   // chunks per K (or V) block
+    constexpr int SR = (NCH + 255) / 256;            // staging rounds
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    E* sK = reinterpret_cast<E*>(smem_raw);          // [2][KVB][KROW]
+    E* sV = sK + 2 * KVB * KROW;                     // [2][KVB][VROW]
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const int bqk = p.qk_map ? p.qk_map[b] : b;
+    const int bv = p.v_map ? p.v_map[b] : b;
+    const E* Qg = reinterpret_cast<const E*>(p.Q) + (long)bqk * p.bsq + h * DH;
+    const E* Kg = reinterpret_cast<const E*>(p.K) + (long)bqk * p.bsk + h * DH;
+    const E* Vg = reinterpret_cast<const E*>(p.V) + (long)bv * p.bsv + h * DH;
+    const int nk = p.nk;
+
+    // zero LDS once: pad columns (DH..DKP of K, DH..DVP of V) are never written again
+    {
+        uint4* z = reinterpret_cast<uint4*>(smem_raw);
+        constexpr int total16 = (2 * KVB * KROW + 2 * KVB * VROW) * 2 / 16;
+        for (int i = t; i < total16; i += 256) z[i] = make_uint4(0, 0, 0, 0);
+    }
+
+    // Q fragments (B operand of S^T = K Q^T): lane (query fr, group fg) holds dh 32*ks + 8*fg .. +7
+    V8 qf[QT][NKS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q = q0 + qt * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d = ks * 32 + fg * 8;
+            V8 v;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (E)0.0f;
+            if (q < p.n && d < DH) v = *reinterpret_cast<const V8*>(Qg + (long)q * p.ldq + d);
+            qf[qt][ks] = v;
+        }
+    }
+
+    uint4 kreg[SR], vreg[SR];
+    auto load_block = [&](int kb) {
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            const int id = r * 256 + t;
+            const int row = id / CPR, c = id - row * CPR;
+            const int key = kb * KVB + row;
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (id < NCH && key < nk) {
+                kv = *reinterpret_cast<const uint4*>(Kg + (long)key * p.ldk + c * 8);
+                vv = *reinterpret_cast<const uint4*>(Vg + (long)key * p.ldv + c * 8);
+            }
+            kreg[r] = kv;
+            vreg[r] = vv;
+        }
+    };
+    auto store_block = [&](int buf) {
+        E* dK = sK + buf * KVB * KROW;
+        E* dV = sV + buf * KVB * VROW;
+#pragma unroll
+        for (int r = 0; r < SR; ++r) {
+            const int id = r * 256 + t;
+            const int row = id / CPR, c = id - row * CPR;
+            if (id < NCH) {
+                *reinterpret_cast<uint4*>(dK + row * KROW + c * 8) = kreg[r];
+                *reinterpret_cast<uint4*>(dV + row * VROW + c * 8) = vreg[r];
+            }
+        }
+    };
+
+    f4_t o[NC][QT];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[c][qt] = f4_t{0.f, 0.f, 0.f, 0.f};
+    float m_run[QT], l_run[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -1e30f; l_run[qt] = 0.f; }
+
+    const float cexp = p.scale * 1.44269504088896340736f;
+    const int nblocks = (nk + KVB - 1) / KVB;
+
+    load_block(0);
+    __syncthreads();  // zero fill done
+    store_block(0);
+    __syncthreads();
+
+    for (int kb = 0; kb < nblocks; ++kb) {
+        const int cur = kb & 1;
+        if (kb + 1 < nblocks) load_block(kb + 1);
+        const E* cK = sK + cur * KVB * KROW;
+        const E* cV = sV + cur * KVB * VROW;
+
+        // ---- S^T = K Q^T : s[tile][qt], lane holds keys 16*tile + 4*fg + r of query fr
+        f4_t s[4][QT];
+#pragma unroll
+        for (int tl = 0; tl < 4; ++tl) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) s[tl][qt] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const V8 kf = *reinterpret_cast<const V8*>(cK + (tl * 16 + fr) * KROW + ks * 32 + fg * 8);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) s[tl][qt] = TT::mfma32(kf, qf[qt][ks], s[tl][qt]);
+            }
+        }
+        // ---- online softmax (fp32)
+        const bool tail = (kb + 1) * KVB > nk;
+        V8 pf[QT][2];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = -1e30f;
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (tail && kb * KVB + tl * 16 + fg * 4 + r >= nk) s[tl][qt][r] = -1e30f;
+                    mx = fmaxf(mx, s[tl][qt][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run[qt], mx);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * cexp);
+            m_run[qt] = m_new;
+            const float mc = m_new * cexp;
+            float ls = 0.f;
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(s[tl][qt][r] * cexp - mc);
+                    s[tl][qt][r] = pv;
+                    ls += pv;
+                }
+            l_run[qt] = l_run[qt] * alpha + ls;
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[c][qt][r] *= alpha;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                V8 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = from_f32<E>(s[2 * st][qt][r]);
+                    v[4 + r] = from_f32<E>(s[2 * st + 1][qt][r]);
+                }
+                pf[qt][st] = v;
+            }
+        }
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const E* base = cV + (st * 32 + fg * 4 + (fr >> 2)) * VROW + c * 16 + (fr & 3) * 4;
+                const V4 lo = TT::tr_read(base);
+                const V4 hi = TT::tr_read(base + 16 * VROW);
+                V8 vf;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { vf[r] = lo[r]; vf[4 + r] = hi[r]; }
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) o[c][qt] = TT::mfma32(vf, pf[qt][st], o[c][qt]);
+            }
+        }
+        if (kb + 1 < nblocks) store_block(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds dh 16c + 4fg + r of query fr
+    E* Og = reinterpret_cast<E*>(p.O) + (long)b * p.bso + h * DH;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = l_run[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int q = q0 + qt * 16 + fr;
+        if (q >= p.n) continue;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int d = c * 16 + fg * 4;
+            if (d >= DH) continue;
+            V4 ov;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = from_f32<E>(o[c][qt][r] * inv);
+            *reinterpret_cast<V4*>(Og + (long)q * p.ldo + d) = ov;
+        }
+    }
+}
+
+template <class TT, int DH, int QT>
+int launch(const AttnParams& p, hipStream_t stream) {
+    constexpr int DKP = round_up(DH, 32), DVP = round_up(DH, 16);
+    constexpr int KROW = DKP + 8, VROW = v_pitch_bytes(DVP) / 2;
+    constexpr size_t lds = (size_t)(2 * KVB * KROW + 2 * KVB * VROW) * 2;
+    auto kern = attn_kernel<TT, DH, QT>;
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return VF_ERR_LAUNCH;
+        attr_set = true;
+    }
+    dim3 grid((p.n + 64 * QT - 1) / (64 * QT), p.heads, p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
+}
+
+template <class TT>
+int dispatch(const AttnParams& p, hipStream_t stream) {
+    switch (p.dh) {
+        case 8: return launch<TT, 8, 2>(p, stream);
+        case 16: return launch<TT, 16, 2>(p, stream);
+        case 32: return launch<TT, 32, 2>(p, stream);
+        case 40: return launch<TT, 40, 2>(p, stream);
+        case 80: return launch<TT, 80, 2>(p, stream);
+        case 160: return launch<TT, 160, 1>(p, stream);
+        default: return VF_ERR_SHAPE;
+    }
+}
+
+}  // namespace
+
+int vf_launch_attention(const AttnParams& p, int dtype, hipStream_t stream) {
+    if (!p.Q || !p.K || !p.V || !p.O) return VF_ERR_ARG;
+    if (p.B <= 0 || p.heads <= 0 || p.n <= 0 || p.nk <= 0) return VF_ERR_ARG;
+    if (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) return VF_ERR_ALIGN;
+    if ((uintptr_t)p.O & 7) return VF_ERR_ALIGN;
+    if ((p.ldq | p.ldk | p.ldv | p.bsq | p.bsk | p.bsv) & 7) return VF_ERR_ALIGN;
+    if ((p.ldo | p.bso) & 3) return VF_ERR_ALIGN;
+    if (dtype == VF_DTYPE_F16) return dispatch<F16>(p, stream);
+    if (dtype == VF_DTYPE_BF16) return dispatch<BF16>(p, stream);
+    return VF_ERR_DTYPE;
+}

@@ -1,0 +1,220 @@
+// C ABI of libvface_hip.so (see include/vface_hip.h): argument checking + kernel sequencing only.
+#include "../../include/vface_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "vface_kernels.hpp"
+
+namespace {
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline size_t align256(size_t b) { return (b + 255) & ~size_t(255); }
+
+GemmParams plain_gemm(const void* A, long lda, const void* Wt, long ldw, int M, int N, int K, const float* bias,
+                      void* C, long ldc, const void* zeros) {
+    GemmParams p{};
+    p.mode = 0; p.A = A; p.lda = lda; p.Wt = Wt; p.ldw = ldw; p.Kw = K; p.M = M; p.N = N; p.K = K;
+    p.bias = bias; p.C = C; p.ldc = ldc; p.zeros = zeros;
+    return p;
+}
+}  // namespace
+
+extern "C" {
+
+int vface_abi_version(void) { return VFACE_ABI_VERSION; }
+
+const char* vface_error_string(int code) {
+    switch (code) {
+        case VFACE_OK: return "ok";
+        case VFACE_ERR_ARG: return "invalid argument (null pointer or non-positive size)";
+        case VFACE_ERR_ALIGN: return "pointer or leading dimension not aligned (16-bit rows need 16 B, channels % 8)";
+        case VFACE_ERR_SHAPE: return "unsupported shape";
+        case VFACE_ERR_DTYPE: return "unsupported dtype (0 = fp16, 1 = bf16)";
+        case VFACE_ERR_LAUNCH: return "kernel launch failed";
+        case VFACE_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown error";
+    }
+}
+
+int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1, int a2_row_mod, const void* Wt,
+               int64_t ldw, int M, int N, int K, const float* bias, const float* rowbias, int rows_per_sample,
+               int ld_rowbias, const void* residual, int64_t ldr, void* C, int64_t ldc, const void* zeros, int flags,
+               int dtype, void* stream) {
+    GemmParams p = plain_gemm(A, lda, Wt, ldw, M, N, K, bias, C, ldc, zeros);
+    p.A2 = A2; p.lda2 = lda2; p.K1 = K1; p.a2_row_mod = a2_row_mod;
+    p.rowbias = rowbias; p.rows_per_sample = rows_per_sample; p.ld_rowbias = ld_rowbias;
+    p.residual = residual; p.ldr = ldr; p.flags = flags;
+    return vf_launch_gemm(p, dtype, S(stream));
+}
+
+int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw, int Cout,
+                  int stride, int upsample, const float* bias, const float* rowbias, int ld_rowbias,
+                  const void* residual, int64_t ldr, void* Y, int64_t ldy, const void* zeros, int flags, int dtype,
+                  void* stream) {
+    if (nimg <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return VFACE_ERR_ARG;
+    if (stride != 1 && stride != 2) return VFACE_ERR_SHAPE;
+    if (flags & VFACE_EPI_GEGLU) return VFACE_ERR_SHAPE;
+    GemmParams p{};
+    p.mode = 1; p.A = X; p.lda = ldx; p.Wt = Wt; p.ldw = ldw; p.Kw = 9 * Cin;
+    p.H = H; p.W = W; p.Cin = Cin; p.stride = stride; p.upsample = upsample ? 1 : 0;
+    const int VH = upsample ? 2 * H : H, VW = upsample ? 2 * W : W;
+    p.OH = (VH + 2 - 3) / stride + 1; p.OW = (VW + 2 - 3) / stride + 1;
+    p.M = nimg * p.OH * p.OW; p.N = Cout; p.K = 9 * Cin;
+    p.bias = bias; p.rowbias = rowbias; p.rows_per_sample = p.OH * p.OW; p.ld_rowbias = ld_rowbias;
+    p.residual = residual; p.ldr = ldr; p.C = Y; p.ldc = ldy; p.zeros = zeros; p.flags = flags;
+    return vf_launch_gemm(p, dtype, S(stream));
+}
+
+int vface_attention(const void* Q, const void* K, const void* V, int64_t ldq, int64_t ldk, int64_t ldv, int64_t bsq,
+                    int64_t bsk, int64_t bsv, const int32_t* qk_map, const int32_t* v_map, void* O, int64_t ldo,
+                    int64_t bso, int B, int heads, int n, int nk, int dh, float scale, int dtype, void* stream) {
+    AttnParams p{};
+    p.Q = Q; p.K = K; p.V = V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.bsq = bsq; p.bsk = bsk; p.bsv = bsv;
+    p.qk_map = qk_map; p.v_map = v_map; p.O = O; p.ldo = ldo; p.bso = bso;
+    p.B = B; p.heads = heads; p.n = n; p.nk = nk; p.dh = dh; p.scale = scale;
+    return vf_launch_attention(p, dtype, S(stream));
+}
+
+int vface_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy, int M,
+                    int C, float eps, int dtype, void* stream) {
+    return vf_launch_layernorm(x, ldx, gamma, beta, y, ldy, M, C, eps, dtype, S(stream));
+}
+
+int vface_groupnorm_partial_floats(int nimg, int hw, int C, int groups) {
+    if (nimg <= 0 || hw <= 0 || groups <= 0) return VFACE_ERR_ARG;
+    return vf_gn_partial_floats(nimg, hw, C, groups);
+}
+
+int vface_groupnorm_stats(const void* x, int64_t ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
+                          float* stats, int dtype, void* stream) {
+    return vf_launch_gn_stats(x, ldx, nimg, hw, C, groups, eps, partial, stats, dtype, S(stream));
+}
+
+int vface_groupnorm_apply(const void* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
+                          void* y, int64_t ldy, int nimg, int hw, int C, int groups, int silu, int dtype,
+                          void* stream) {
+    return vf_launch_gn_apply(x, ldx, stats, gamma, beta, y, ldy, nimg, hw, C, groups, silu, dtype, S(stream));
+}
+
+int vface_flow_warp(const void* src, int64_t ld_src, int64_t fs_src, const void* prev, int64_t ld_prev,
+                    const float* flow, const float* flow_prev, void* dst, int64_t ld_dst, int64_t fs_dst, int F,
+                    int h, int w, int C, float alpha, float one_minus_alpha, int flags, int32_t* dbg_x0,
+                    int32_t* dbg_y0, int dtype, void* stream) {
+    return vf_launch_flow_warp(src, ld_src, fs_src, prev, ld_prev, flow, flow_prev, dst, ld_dst, fs_dst, F, h, w, C,
+                               alpha, one_minus_alpha, flags, dbg_x0, dbg_y0, dtype, S(stream));
+}
+
+size_t vface_attn1_workspace_bytes(int B, int n, int d, int chunks) {
+    if (B <= 0 || n <= 0 || d <= 0 || chunks <= 0) return 0;
+    const size_t F = (size_t)B / chunks;
+    return align256((size_t)B * n * 3 * d * 2) + align256(F * n * 2 * d * 2) + align256((size_t)B * n * d * 2);
+}
+
+int vface_attn1_forward(const void* x, int64_t ldx, const void* Wqkv, const void* Wlin, const void* Wo,
+                        const float* bo, const float* rowbias, int ld_rowbias, const void* residual, int64_t ldr,
+                        void* out, int64_t ldo, int B, int n, int d, int heads, int chunks, int fusion,
+                        int v_fixed, const float* flow, int h, int w, float alpha, float one_minus_alpha,
+                        int warp_flags, const void* halo_qk, const float* halo_flow, void* tail_qk,
+                        const int32_t* qk_map, const int32_t* v_map, void* workspace, size_t workspace_bytes,
+                        const void* zeros, int dtype, void* stream) {
+    if (!x || !Wqkv || !Wo || !out || !workspace || !zeros) return VFACE_ERR_ARG;
+    if (B <= 0 || n <= 0 || d <= 0 || heads <= 0 || chunks <= 0 || d % heads) return VFACE_ERR_ARG;
+    if (dtype != VFACE_F16 && dtype != VFACE_BF16) return VFACE_ERR_DTYPE;
+    if (fusion != VFACE_FUSION_NONE && B % chunks) return VFACE_ERR_SHAPE;
+    if (workspace_bytes < vface_attn1_workspace_bytes(B, n, d, chunks)) return VFACE_ERR_WORKSPACE;
+    if (fusion == VFACE_FUSION_REPLACE && !qk_map) return VFACE_ERR_ARG;
+    if (fusion == VFACE_FUSION_LINEAR && (!Wlin || (d % 64))) return VFACE_ERR_SHAPE;
+    if (v_fixed && !v_map) return VFACE_ERR_ARG;
+    const bool warp = fusion == VFACE_FUSION_LINEAR && flow != nullptr;
+    if (warp && (h * w != n || chunks != 3)) return VFACE_ERR_SHAPE;
+    hipStream_t st = S(stream);
+    const size_t esz = 2;
+    const long F = B / chunks, Fn = F * n;
+    char* ws = static_cast<char*>(workspace);
+    char* qkv = ws;
+    char* T = qkv + align256((size_t)B * n * 3 * d * esz);
+    char* att = T + align256((size_t)Fn * 2 * d * esz);
+    const char* xb = static_cast<const char*>(x);
+    const char* wq = static_cast<const char*>(Wqkv);
+    int rc;
+    auto at = [&](char* base, long row, long col, long ld) { return base + ((size_t)row * ld + col) * esz; };
+
+    if (fusion == VFACE_FUSION_NONE) {
+        GemmParams p = plain_gemm(x, ldx, Wqkv, d, B * n, 3 * d, d, nullptr, qkv, 3 * d, zeros);
+        if ((rc = vf_launch_gemm(p, dtype, st))) return rc;
+    } else {
+        // chunk 0: q, k, v as projected (pnp_utils.py:106,127-128)
+        GemmParams p0 = plain_gemm(x, ldx, Wqkv, d, (int)Fn, 3 * d, d, nullptr, qkv, 3 * d, zeros);
+        if ((rc = vf_launch_gemm(p0, dtype, st))) return rc;
+        // other chunks: v only -- their q, k are overwritten by the fusion
+        GemmParams pv = plain_gemm(xb + (size_t)Fn * ldx * esz, ldx, wq + (size_t)2 * d * d * esz, d, (int)(B * n - Fn),
+                                   d, d, nullptr, at(qkv, Fn, 2 * d, 3 * d), 3 * d, zeros);
+        if ((rc = vf_launch_gemm(pv, dtype, st))) return rc;
+        if (fusion == VFACE_FUSION_LINEAR) {
+            // fused q|k of chunk c >= 1: [x_c | x_0] (K = 2d) times the folded weights
+            for (int c = 1; c < chunks; ++c) {
+                const bool to_tmp = warp && c == 1;
+                GemmParams pf = plain_gemm(xb + (size_t)c * Fn * ldx * esz, ldx, Wlin, 2 * d, (int)Fn, 2 * d, 2 * d,
+                                           nullptr, to_tmp ? T : at(qkv, c * Fn, 0, 3 * d), to_tmp ? 2 * d : 3 * d,
+                                           zeros);
+                pf.A2 = x; pf.lda2 = ldx; pf.K1 = d; pf.a2_row_mod = 0;
+                if ((rc = vf_launch_gemm(pf, dtype, st))) return rc;
+            }
+            if (warp) {
+                if (tail_qk) {
+                    rc = vf_launch_copy2d(T + (size_t)(F - 1) * n * 2 * d * esz, 2 * d, tail_qk, 2 * d, n, 2 * d, dtype, st);
+                    if (rc) return rc;
+                }
+                rc = vf_launch_flow_warp(T, 2 * d, (long)n * 2 * d, halo_qk, 2 * d, flow, halo_flow,
+                                         at(qkv, Fn, 0, 3 * d), 3 * d, (long)n * 3 * d, (int)F, h, w, 2 * d, alpha,
+                                         one_minus_alpha, warp_flags, nullptr, nullptr, dtype, st);
+                if (rc) return rc;
+            }
+        }
+    }
+    AttnParams a{};
+    a.Q = qkv; a.K = qkv + (size_t)d * esz; a.V = qkv + (size_t)2 * d * esz;
+    a.ldq = a.ldk = a.ldv = 3 * d; a.bsq = a.bsk = a.bsv = (long)n * 3 * d;
+    a.qk_map = (fusion == VFACE_FUSION_REPLACE) ? qk_map : nullptr;
+    a.v_map = v_fixed ? v_map : nullptr;
+    a.O = att; a.ldo = d; a.bso = (long)n * d;
+    a.B = B; a.heads = heads; a.n = n; a.nk = n; a.dh = d / heads;
+    a.scale = 1.0f / sqrtf((float)(d / heads));
+    if ((rc = vf_launch_attention(a, dtype, st))) return rc;
+    GemmParams po = plain_gemm(att, d, Wo, d, B * n, d, d, bo, out, ldo, zeros);
+    po.rowbias = rowbias; po.rows_per_sample = n; po.ld_rowbias = ld_rowbias;
+    po.residual = residual; po.ldr = ldr;
+    return vf_launch_gemm(po, dtype, st);
+}
+
+int vface_timestep_embedding(const int64_t* t, void* out, int N, int dim, int dtype, void* stream) {
+    return vf_launch_timestep_embedding(reinterpret_cast<const long long*>(t), out, N, dim, dtype, S(stream));
+}
+int vface_silu(const void* x, void* y, int64_t count, int in_f32, int dtype, void* stream) {
+    return vf_launch_silu(x, y, count, in_f32, dtype, S(stream));
+}
+int vface_cast_f32(const float* src, void* dst, int64_t count, int dtype, void* stream) {
+    return vf_launch_cast(src, dst, count, dtype, S(stream));
+}
+int vface_pack_unet_input(const float* x, const float* inv, const float* inpaint, const float* mask, void* out, int F,
+                          int h, int w, int cpad, int dtype, void* stream) {
+    return vf_launch_pack_input(x, inv, inpaint, mask, out, F, h, w, cpad, dtype, S(stream));
+}
+int vface_nchw_to_nhwc(const float* x, void* out, int N, int C, int hw, int cpad, int dtype, void* stream) {
+    return vf_launch_nchw_to_nhwc(x, out, N, C, hw, cpad, dtype, S(stream));
+}
+int vface_nhwc_to_nchw_f32(const float* x, int64_t ldx, float* out, int N, int C, int hw, void* stream) {
+    return vf_launch_nhwc_to_nchw_f32(x, ldx, out, N, C, hw, S(stream));
+}
+int vface_ddim_step(const float* eps, int64_t lde, const float* x, const float* inv, float* x_prev, float* pred_x0,
+                    float* x_prev_recon, int F, int C, int hw, float scale, float a_t, float a_prev, float sigma_t,
+                    float sqrt_one_minus_at, const float* noise, void* stream) {
+    return vf_launch_ddim_step(eps, lde, x, inv, x_prev, pred_x0, x_prev_recon, F, C, hw, scale, a_t, a_prev, sigma_t,
+                               sqrt_one_minus_at, noise, S(stream));
+}
+int vface_copy2d(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols, int dtype,
+                 void* stream) {
+    return vf_launch_copy2d(src, ld_src, dst, ld_dst, rows, cols, dtype, S(stream));
+}
+
+}  // extern "C"

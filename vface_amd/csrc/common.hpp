@@ -1,0 +1,66 @@
+// Shared device helpers for the VFace gfx950 kernels (CDNA4, wave64).  Written for MI355X only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 b4_t __attribute__((ext_vector_type(4)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef short s4_t __attribute__((ext_vector_type(4)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// 16-bit storage types the path computes in.  fp16 is the reference's autocast type; bf16 is the
+// north-star's MFMA type.  Same MFMA rate and fragment layout on gfx950 (guide §3).
+struct F16 {
+    using elem = _Float16;
+    using v8 = h8_t;
+    using v4 = h4_t;
+    static __device__ __forceinline__ f4_t mfma32(v8 a, v8 b, f4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ v4 tr_read(const elem* lds) {
+        return __builtin_bit_cast(v4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                          (__attribute__((address_space(3))) s4_t*)(lds)));
+    }
+};
+struct BF16 {
+    using elem = __bf16;
+    using v8 = b8_t;
+    using v4 = b4_t;
+    static __device__ __forceinline__ f4_t mfma32(v8 a, v8 b, f4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ v4 tr_read(const elem* lds) {
+        return __builtin_bit_cast(v4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                          (__attribute__((address_space(3))) s4_t*)(lds)));
+    }
+};
+
+template <class E> __device__ __forceinline__ float to_f32(E x) { return (float)x; }
+template <class E> __device__ __forceinline__ E from_f32(float x) { return (E)x; }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// error codes of the C ABI
+enum {
+    VF_OK = 0,
+    VF_ERR_ARG = -1,      // null pointer / non-positive size
+    VF_ERR_ALIGN = -2,    // pointer or leading dimension not aligned as the kernel requires
+    VF_ERR_SHAPE = -3,    // unsupported shape (head dim, channel multiple, ...)
+    VF_ERR_DTYPE = -4,
+    VF_ERR_LAUNCH = -5,   // hipGetLastError() after launch
+};
+
+#define VF_DTYPE_F16 0
+#define VF_DTYPE_BF16 1

@@ -1,0 +1,528 @@
+// Bandwidth-bound kernels of the VFace UNet path (gfx950): normalisations, the flow-guided warp of Q/K
+// maps, layout packing and the DDIM update.  All loads/stores of 16-bit data are 16 B per lane.
+#include "common.hpp"
+#include "vface_kernels.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// attention.py:231-233 (nn.LayerNorm, eps 1e-5).  fp32 statistics (autocast keeps layer_norm in fp32);
+// the result is written in the 16-bit type because its only consumer is a 16-bit GEMM.
+// One wave per row: the row (<= 2048 channels) lives in registers between the two passes.
+template <class TT, int CH8>  // CH8: 16-B chunks per lane (row length <= 512*CH8)
+__global__ __launch_bounds__(256) void layernorm_kernel(const typename TT::elem* __restrict__ x, long ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        typename TT::elem* __restrict__ y, long ldy, int M, int C,
+                                                        float eps) {
+    using E = typename TT::elem;
+    using V8 = typename TT::v8;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const E* xr = x + (long)row * ldx;
+    float v[CH8][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH8; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            const V8 t = *reinterpret_cast<const V8*>(xr + c);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = to_f32(t[j]); s += v[i][j]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH8; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    E* yr = y + (long)row * ldy;
+#pragma unroll
+    for (int i = 0; i < CH8; ++i) {
+        const int c = (i * 64 + lane) * 8;
+        if (c < C) {
+            V8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = from_f32<E>((v[i][j] - mean) * rstd * gamma[c + j] + beta[c + j]);
+            *reinterpret_cast<V8*>(yr + c) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GroupNorm
+// util.py:214-216 (GroupNorm32, fp32 math) and attention.py:76-77 (eps 1e-6).  NHWC activations: a
+// group is a slab of C/groups adjacent channels of every pixel.  Pass 1: each workgroup reduces a
+// range of pixels over ALL channels (coalesced rows) into per-group (sum, sumsq) partials; pass 2
+// folds the partials in double precision into (mean, rstd).
+constexpr int GN_PIX = 64;  // pixels per workgroup in pass 1
+
+template <class TT>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const typename TT::elem* __restrict__ x, long ldx, int hw,
+                                                         int C, int groups, float* __restrict__ partial) {
+    using E = typename TT::elem;
+    using V8 = typename TT::v8;
+    __shared__ float acc[2 * 64];  // groups <= 64
+    const int img = blockIdx.y, chunk = blockIdx.x;
+    const int cpg = C / groups;
+    for (int i = threadIdx.x; i < 2 * groups; i += 256) acc[i] = 0.f;
+    __syncthreads();
+    const int c8 = C / 8;
+    const int p0 = chunk * GN_PIX, p1 = min(hw, p0 + GN_PIX);
+    const long total = (long)(p1 - p0) * c8;
+    const E* base = x + ((long)img * hw + p0) * ldx;
+    // a thread keeps one channel chunk when 256 % c8 == 0 is false as well: accumulate per element group
+    for (long i = threadIdx.x; i < total; i += 256) {
+        const int pix = (int)(i / c8), cc = (int)(i - (long)pix * c8) * 8;
+        const V8 t = *reinterpret_cast<const V8*>(base + (long)pix * ldx + cc);
+        int g = cc / cpg;
+        int left = (g + 1) * cpg - cc;  // channels left in group g from cc
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (left == 0) {
+                atomicAdd(&acc[2 * g], s); atomicAdd(&acc[2 * g + 1], q);
+                s = q = 0.f; ++g; left = cpg;
+            }
+            const float f = to_f32(t[j]);
+            s += f; q += f * f; --left;
+        }
+        atomicAdd(&acc[2 * g], s); atomicAdd(&acc[2 * g + 1], q);
+    }
+    __syncthreads();
+    float* out = partial + ((long)img * gridDim.x + chunk) * 2 * groups;
+    for (int i = threadIdx.x; i < 2 * groups; i += 256) out[i] = acc[i];
+}
+
+__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int groups, double count,
+                                   float eps, float* __restrict__ stats) {
+    const int img = blockIdx.x;
+    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+        double s = 0.0, q = 0.0;
+        for (int c = 0; c < nchunks; ++c) {
+            const float* pp = partial + ((long)img * nchunks + c) * 2 * groups;
+            s += pp[2 * g]; q += pp[2 * g + 1];
+        }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[((long)img * groups + g) * 2] = (float)mean;
+        stats[((long)img * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+template <class TT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const typename TT::elem* __restrict__ x, long ldx,
+                                                       const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       typename TT::elem* __restrict__ y, long ldy, int hw, int C,
+                                                       int groups, int silu, long total) {
+    using E = typename TT::elem;
+    using V8 = typename TT::v8;
+    const int c8 = C / 8, cpg = C / groups;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long pix = i / c8;
+        const int cc = (int)(i - pix * c8) * 8;
+        const int img = (int)(pix / hw);
+        const V8 t = *reinterpret_cast<const V8*>(x + pix * ldx + cc);
+        const float* st = stats + (long)img * groups * 2;
+        V8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = cc + j, g = c / cpg;
+            float f = (to_f32(t[j]) - st[2 * g]) * st[2 * g + 1] * gamma[c] + beta[c];
+            if (silu) f = silu_f(f);
+            o[j] = from_f32<E>(f);
+        }
+        *reinterpret_cast<V8*>(y + pix * ldy + cc) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ flow warp
+// temporal_flow.py:40-53 (warp_image) + :222-237 (align_by_flow) on token-major maps [F][h*w][C]:
+//   out[f] = alpha * src[f] + (1 - alpha) * bilinear(src[f-1], (x + dx, y + dy)),  out[0] = src[0]
+// reading the UNMODIFIED source (not recurrent).  The sampling coordinate follows the reference's fp32
+// operation order exactly -- x + dx; 2.0 * v / max(W-1, 1) - 1.0; ATen's ((g + 1) / 2) * (W - 1);
+// clamp to the border; floor -- with no FMA contraction, because the normalise / un-normalise round
+// trip moves integer coordinates by an ulp and decides floor().  flags bit 0 selects CUDA-ATen's
+// "multiply by the reciprocal" form of the scalar division (what the reference computes on its
+// native CUDA device); the default true division is what it computes on CPU, where the oracle and
+// the golden vectors were produced.
+// `prev` (optional) is the frame preceding src[0] -- the last frame of the previous rank's shard when
+// frames are sharded across GPUs -- with its own flow field `flow_prev`.
+__device__ __forceinline__ float unnorm_coord(float pos, float d, int size, bool recip) {
+    const float v = __fadd_rn(pos, d);
+    const float den = (float)max(size - 1, 1);
+    const float two_v = __fmul_rn(2.0f, v);
+    const float qn = recip ? __fmul_rn(two_v, __fdiv_rn(1.0f, den)) : __fdiv_rn(two_v, den);
+    const float g = __fsub_rn(qn, 1.0f);
+    float c = __fmul_rn(__fmul_rn(__fadd_rn(g, 1.0f), 0.5f), (float)(size - 1));
+    c = fminf((float)(size - 1), fmaxf(c, 0.0f));
+    return c;
+}
+
+template <class TT>
+__global__ __launch_bounds__(256) void flow_warp_kernel(const typename TT::elem* __restrict__ src, long ld_src,
+                                                        long fs_src, const typename TT::elem* __restrict__ prev,
+                                                        long ld_prev, const float* __restrict__ flow,
+                                                        const float* __restrict__ flow_prev,
+                                                        typename TT::elem* __restrict__ dst, long ld_dst,
+                                                        long fs_dst, int F, int h, int w, int C, float alpha,
+                                                        float oma, int flags, int* __restrict__ dbg_x0,
+                                                        int* __restrict__ dbg_y0) {
+    using E = typename TT::elem;
+    using V8 = typename TT::v8;
+    const int c8 = C / 8;
+    const int f = blockIdx.y;
+    const long total = (long)h * w * c8;
+    const bool recip = flags & 1;
+    const E* cur = src + (long)f * fs_src;
+    E* out = dst + (long)f * fs_dst;
+    const E* from = nullptr;
+    long ld_from = ld_src;
+    const float* fl = nullptr;
+    if (f > 0) { from = src + (long)(f - 1) * fs_src; fl = flow + (long)(f - 1) * 2 * h * w; }
+    else if (prev) { from = prev; ld_from = ld_prev; fl = flow_prev; }
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int pix = (int)(i / c8), cc = (int)(i - (long)pix * c8) * 8;
+        const V8 xv = *reinterpret_cast<const V8*>(cur + (long)pix * ld_src + cc);
+        if (!from) { *reinterpret_cast<V8*>(out + (long)pix * ld_dst + cc) = xv; continue; }
+        const int py = pix / w, px = pix - py * w;
+        const float ix = unnorm_coord((float)px, fl[pix], w, recip);
+        const float iy = unnorm_coord((float)py, fl[h * w + pix], h, recip);
+        const float fx0 = floorf(ix), fy0 = floorf(iy);
+        const int x0 = (int)fx0, y0 = (int)fy0;
+        if (cc == 0 && f > 0 && dbg_x0) {
+            dbg_x0[(long)(f - 1) * h * w + pix] = x0;
+            dbg_y0[(long)(f - 1) * h * w + pix] = y0;
+        }
+        const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+        const bool vx = x0 + 1 <= w - 1, vy = y0 + 1 <= h - 1;
+        const int x1 = vx ? x0 + 1 : x0, y1 = vy ? y0 + 1 : y0;
+        const float w00 = wx0 * wy0, w01 = vx ? wx1 * wy0 : 0.f, w10 = vy ? wx0 * wy1 : 0.f,
+                    w11 = (vx && vy) ? wx1 * wy1 : 0.f;
+        const V8 a = *reinterpret_cast<const V8*>(from + (long)(y0 * w + x0) * ld_from + cc);
+        const V8 b = *reinterpret_cast<const V8*>(from + (long)(y0 * w + x1) * ld_from + cc);
+        const V8 c = *reinterpret_cast<const V8*>(from + (long)(y1 * w + x0) * ld_from + cc);
+        const V8 d = *reinterpret_cast<const V8*>(from + (long)(y1 * w + x1) * ld_from + cc);
+        V8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float wv = to_f32(a[j]) * w00;
+            wv += to_f32(b[j]) * w01;
+            wv += to_f32(c[j]) * w10;
+            wv += to_f32(d[j]) * w11;
+            // alpha * x keeps the 16-bit type in the reference (python scalar * half tensor), then the
+            // fp32 sum is rounded on store (temporal_flow.py:234-235)
+            const float ax = to_f32(from_f32<E>(alpha * to_f32(xv[j])));
+            o[j] = from_f32<E>(ax + oma * wv);
+        }
+        *reinterpret_cast<V8*>(out + (long)pix * ld_dst + cc) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ small ops
+// util.py:151-171: [cos(t * f_i) | sin(t * f_i)], f_i = exp(-ln(10000) * i / half)
+template <class TT>
+__global__ void timestep_embedding_kernel(const long long* __restrict__ t, typename TT::elem* __restrict__ out,
+                                          int N, int dim) {
+    using E = typename TT::elem;
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * half) return;
+    const int n = i / half, k = i - n * half;
+    const float freq = expf(-9.210340371976184f * (float)k / (float)half);
+    const float arg = (float)t[n] * freq;
+    out[(long)n * dim + k] = from_f32<E>(cosf(arg));
+    out[(long)n * dim + half + k] = from_f32<E>(sinf(arg));
+    if ((dim & 1) && k == 0) out[(long)n * dim + dim - 1] = from_f32<E>(0.f);
+}
+
+template <class TT, bool IN_F32>
+__global__ void silu_kernel(const void* __restrict__ x, typename TT::elem* __restrict__ y, long count) {
+    using E = typename TT::elem;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x) {
+        const float f = IN_F32 ? reinterpret_cast<const float*>(x)[i] : to_f32(reinterpret_cast<const E*>(x)[i]);
+        y[i] = from_f32<E>(silu_f(f));
+    }
+}
+
+template <class TT>
+__global__ void cast_kernel(const float* __restrict__ x, typename TT::elem* __restrict__ y, long count) {
+    using E = typename TT::elem;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        y[i] = from_f32<E>(x[i]);
+}
+
+// ddim_w_inv.py:633,654-655: x9 = cat[x, inpaint, mask]; x_in = cat[x9, x9, cat[inv_t, inpaint, mask]]
+// written straight into the NHWC 16-bit layout the first convolution reads, channels padded to cpad.
+template <class TT>
+__global__ void pack_input_kernel(const float* __restrict__ x, const float* __restrict__ inv,
+                                  const float* __restrict__ inpaint, const float* __restrict__ mask,
+                                  typename TT::elem* __restrict__ out, int F, int hw, int cpad) {
+    using E = typename TT::elem;
+    const long total = (long)3 * F * hw * cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpad);
+        const long pi = i / cpad;
+        const int pix = (int)(pi % hw);
+        const int s = (int)(pi / hw);
+        const int chunk = s / F, f = s - chunk * F;
+        float v = 0.f;
+        if (c < 4) v = (chunk == 2 ? inv : x)[((long)f * 4 + c) * hw + pix];
+        else if (c < 8) v = inpaint[((long)f * 4 + (c - 4)) * hw + pix];
+        else if (c == 8) v = mask[(long)f * hw + pix];
+        out[i] = from_f32<E>(v);
+    }
+}
+
+template <class TT>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, typename TT::elem* __restrict__ out, int N, int C,
+                                    int hw, int cpad) {
+    using E = typename TT::elem;
+    const long total = (long)N * hw * cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpad);
+        const long pi = i / cpad;
+        const int pix = (int)(pi % hw);
+        const int n = (int)(pi / hw);
+        out[i] = from_f32<E>(c < C ? x[((long)n * C + c) * hw + pix] : 0.f);
+    }
+}
+
+__global__ void nhwc_to_nchw_f32_kernel(const float* __restrict__ x, long ldx, float* __restrict__ out, int N, int C,
+                                        int hw) {
+    const long total = (long)N * C * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % hw);
+        const long nc = i / hw;
+        const int c = (int)(nc % C);
+        const int n = (int)(nc / C);
+        out[i] = x[((long)n * hw + pix) * ldx + c];
+    }
+}
+
+// ddim_w_inv.py:666-667 (guidance; the recon branch formula as written) and :686-700 (x0 prediction,
+// direction, x_{t-1}); eps is the UNet output for [uncond ; cond ; recon], NHWC fp32 with row stride lde.
+__global__ void ddim_step_kernel(const float* __restrict__ eps, long lde, const float* __restrict__ x,
+                                 const float* __restrict__ inv, float* __restrict__ x_prev,
+                                 float* __restrict__ pred_x0, float* __restrict__ x_prev_recon, int F, int C, int hw,
+                                 float scale, float a_t, float a_prev, float sigma_t, float sqrt_1m_at,
+                                 const float* __restrict__ noise) {
+    const long total = (long)F * C * hw;
+    const float sqrt_at = sqrtf(a_t), sqrt_ap = sqrtf(a_prev);
+    const float dir = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % hw);
+        const long fc = i / hw;
+        const int c = (int)(fc % C);
+        const int f = (int)(fc / C);
+        const float eu = eps[((long)f * hw + pix) * lde + c];
+        const float ec = eps[((long)(F + f) * hw + pix) * lde + c];
+        const float er = eps[((long)(2 * F + f) * hw + pix) * lde + c];
+        const float e_t = eu + scale * (ec - eu);
+        const float p0 = (x[i] - sqrt_1m_at * e_t) / sqrt_at;
+        const float nz = noise ? sigma_t * noise[i] : 0.f;
+        x_prev[i] = sqrt_ap * p0 + dir * e_t + nz;
+        if (pred_x0) pred_x0[i] = p0;
+        if (x_prev_recon && inv) {
+            const float e_r = er + scale * (er - eu);
+            const float p0r = (inv[i] - sqrt_1m_at * e_r) / sqrt_at;
+            x_prev_recon[i] = sqrt_ap * p0r + dir * e_r;
+        }
+    }
+}
+
+template <class TT>
+__global__ void copy2d_kernel(const typename TT::elem* __restrict__ src, long lds_, typename TT::elem* __restrict__ dst,
+                              long ldd, long rows, int cols) {
+    using V8 = typename TT::v8;
+    const int c8 = cols / 8;
+    const long total = rows * c8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c8;
+        const int c = (int)(i - r * c8) * 8;
+        *reinterpret_cast<V8*>(dst + r * ldd + c) = *reinterpret_cast<const V8*>(src + r * lds_ + c);
+    }
+}
+
+inline int grid_for(long total, int block = 256, int cap = 8192) {
+    long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+inline int ok() { return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH; }
+
+}  // namespace
+
+#define DISPATCH_DTYPE(dtype, CALL)            \
+    if ((dtype) == VF_DTYPE_F16) { using TT = F16; CALL; } \
+    else if ((dtype) == VF_DTYPE_BF16) { using TT = BF16; CALL; } \
+    else return VF_ERR_DTYPE;
+
+int vf_launch_layernorm(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, int M,
+                        int C, float eps, int dtype, hipStream_t stream) {
+    if (!x || !gamma || !beta || !y || M <= 0 || C <= 0) return VF_ERR_ARG;
+    if ((C & 7) || (ldx & 7) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VF_ERR_ALIGN;
+    if (C > 2048) return VF_ERR_SHAPE;
+    const int ch8 = (C + 511) / 512;
+    dim3 grid((M + 3) / 4);
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        const E* xi = (const E*)x; E* yo = (E*)y;
+        switch (ch8) {
+            case 1: hipLaunchKernelGGL((layernorm_kernel<TT, 1>), grid, dim3(256), 0, stream, xi, ldx, gamma, beta, yo, ldy, M, C, eps); break;
+            case 2: hipLaunchKernelGGL((layernorm_kernel<TT, 2>), grid, dim3(256), 0, stream, xi, ldx, gamma, beta, yo, ldy, M, C, eps); break;
+            case 3: hipLaunchKernelGGL((layernorm_kernel<TT, 3>), grid, dim3(256), 0, stream, xi, ldx, gamma, beta, yo, ldy, M, C, eps); break;
+            default: hipLaunchKernelGGL((layernorm_kernel<TT, 4>), grid, dim3(256), 0, stream, xi, ldx, gamma, beta, yo, ldy, M, C, eps); break;
+        }
+    });
+    return ok();
+}
+
+int vf_gn_partial_floats(int nimg, int hw, int C, int groups) {
+    (void)C;
+    return nimg * ((hw + GN_PIX - 1) / GN_PIX) * 2 * groups;
+}
+
+int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
+                       float* stats, int dtype, hipStream_t stream) {
+    if (!x || !partial || !stats || nimg <= 0 || hw <= 0 || C <= 0 || groups <= 0) return VF_ERR_ARG;
+    if ((C & 7) || (ldx & 7) || ((uintptr_t)x & 15)) return VF_ERR_ALIGN;
+    if (groups > 64 || C % groups) return VF_ERR_SHAPE;
+    const int nchunks = (hw + GN_PIX - 1) / GN_PIX;
+    dim3 grid(nchunks, nimg);
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        hipLaunchKernelGGL((gn_partial_kernel<TT>), grid, dim3(256), 0, stream, (const E*)x, ldx, hw, C, groups, partial);
+    });
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg), dim3(64), 0, stream, (const float*)partial, nchunks, groups,
+                       (double)hw * (C / groups), eps, stats);
+    return ok();
+}
+
+int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y,
+                       long ldy, int nimg, int hw, int C, int groups, int silu, int dtype, hipStream_t stream) {
+    if (!x || !stats || !gamma || !beta || !y || nimg <= 0 || hw <= 0) return VF_ERR_ARG;
+    if ((C & 7) || (ldx & 7) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VF_ERR_ALIGN;
+    if (groups > 64 || C % groups) return VF_ERR_SHAPE;
+    const long total = (long)nimg * hw * (C / 8);
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        hipLaunchKernelGGL((gn_apply_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, stream, (const E*)x, ldx, stats,
+                           gamma, beta, (E*)y, ldy, hw, C, groups, silu, total);
+    });
+    return ok();
+}
+
+int vf_launch_flow_warp(const void* src, long ld_src, long fs_src, const void* prev, long ld_prev,
+                        const float* flow, const float* flow_prev, void* dst, long ld_dst, long fs_dst, int F, int h,
+                        int w, int C, float alpha, float one_minus_alpha, int flags, int* dbg_x0, int* dbg_y0,
+                        int dtype, hipStream_t stream) {
+    if (!src || !dst || F <= 0 || h <= 0 || w <= 0 || C <= 0) return VF_ERR_ARG;
+    if (F > 1 && !flow) return VF_ERR_ARG;
+    if (prev && !flow_prev) return VF_ERR_ARG;
+    if ((C & 7) || (ld_src & 7) || (ld_dst & 7) || (fs_src & 7) || (fs_dst & 7) || (prev && (ld_prev & 7))) return VF_ERR_ALIGN;
+    if (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)prev) & 15) return VF_ERR_ALIGN;
+    if ((dbg_x0 == nullptr) != (dbg_y0 == nullptr)) return VF_ERR_ARG;
+    const long total = (long)h * w * (C / 8);
+    dim3 grid(grid_for(total, 256, 2048), F);
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        hipLaunchKernelGGL((flow_warp_kernel<TT>), grid, dim3(256), 0, stream, (const E*)src, ld_src, fs_src,
+                           (const E*)prev, ld_prev, flow, flow_prev, (E*)dst, ld_dst, fs_dst, F, h, w, C, alpha, one_minus_alpha, flags,
+                           dbg_x0, dbg_y0);
+    });
+    return ok();
+}
+
+int vf_launch_timestep_embedding(const long long* t, void* out, int N, int dim, int dtype, hipStream_t stream) {
+    if (!t || !out || N <= 0 || dim <= 1) return VF_ERR_ARG;
+    const int total = N * (dim / 2);
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        hipLaunchKernelGGL((timestep_embedding_kernel<TT>), dim3((total + 255) / 256), dim3(256), 0, stream, t, (E*)out, N, dim);
+    });
+    return ok();
+}
+
+int vf_launch_silu(const void* x, void* y, long count, int in_f32, int dtype, hipStream_t stream) {
+    if (!x || !y || count <= 0) return VF_ERR_ARG;
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        if (in_f32) hipLaunchKernelGGL((silu_kernel<TT, true>), dim3(grid_for(count)), dim3(256), 0, stream, x, (E*)y, count);
+        else hipLaunchKernelGGL((silu_kernel<TT, false>), dim3(grid_for(count)), dim3(256), 0, stream, x, (E*)y, count);
+    });
+    return ok();
+}
+
+int vf_launch_cast(const float* src, void* dst, long count, int dtype, hipStream_t stream) {
+    if (!src || !dst || count <= 0) return VF_ERR_ARG;
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        hipLaunchKernelGGL((cast_kernel<TT>), dim3(grid_for(count)), dim3(256), 0, stream, src, (E*)dst, count);
+    });
+    return ok();
+}
+
+int vf_launch_pack_input(const float* x, const float* inv, const float* inpaint, const float* mask, void* out,
+                         int F, int h, int w, int cpad, int dtype, hipStream_t stream) {
+    if (!x || !inv || !inpaint || !mask || !out || F <= 0 || h <= 0 || w <= 0) return VF_ERR_ARG;
+    if (cpad < 9 || (cpad & 7)) return VF_ERR_SHAPE;
+    const long total = (long)3 * F * h * w * cpad;
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        hipLaunchKernelGGL((pack_input_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, stream, x, inv, inpaint, mask, (E*)out, F, h * w, cpad);
+    });
+    return ok();
+}
+
+int vf_launch_nchw_to_nhwc(const float* x, void* out, int N, int C, int hw, int cpad, int dtype, hipStream_t stream) {
+    if (!x || !out || N <= 0 || C <= 0 || hw <= 0 || cpad < C) return VF_ERR_ARG;
+    const long total = (long)N * hw * cpad;
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        hipLaunchKernelGGL((nchw_to_nhwc_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, stream, x, (E*)out, N, C, hw, cpad);
+    });
+    return ok();
+}
+
+int vf_launch_nhwc_to_nchw_f32(const float* x, long ldx, float* out, int N, int C, int hw, hipStream_t stream) {
+    if (!x || !out || N <= 0 || C <= 0 || hw <= 0 || ldx < C) return VF_ERR_ARG;
+    const long total = (long)N * C * hw;
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(grid_for(total)), dim3(256), 0, stream, x, ldx, out, N, C, hw);
+    return ok();
+}
+
+int vf_launch_ddim_step(const float* eps, long lde, const float* x, const float* inv, float* x_prev, float* pred_x0,
+                        float* x_prev_recon, int F, int C, int hw, float scale, float a_t, float a_prev, float sigma_t,
+                        float sqrt_1m_at, const float* noise, hipStream_t stream) {
+    if (!eps || !x || !x_prev || F <= 0 || C <= 0 || hw <= 0 || lde < C) return VF_ERR_ARG;
+    const long total = (long)F * C * hw;
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(total)), dim3(256), 0, stream, eps, lde, x, inv, x_prev, pred_x0,
+                       x_prev_recon, F, C, hw, scale, a_t, a_prev, sigma_t, sqrt_1m_at, noise);
+    return ok();
+}
+
+int vf_launch_copy2d(const void* src, long lds_, void* dst, long ldd, long rows, int cols, int dtype,
+                     hipStream_t stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0) return VF_ERR_ARG;
+    if ((cols & 7) || (lds_ & 7) || (ldd & 7) || (((uintptr_t)src | (uintptr_t)dst) & 15)) return VF_ERR_ALIGN;
+    const long total = rows * (cols / 8);
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        hipLaunchKernelGGL((copy2d_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, stream, (const E*)src, lds_, (E*)dst, ldd, rows, cols);
+    });
+    return ok();
+}

@@ -1,0 +1,68 @@
+// Internal launch interface between the C ABI (capi.cpp / include/vface_hip.h) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { GEMM_GEGLU = 1, GEMM_OUT_F32 = 2 };
+
+struct GemmParams {
+    int mode;  // 0: plain A[M][K]; 1: implicit 3x3 conv over NHWC
+    const void* A;
+    long lda;  // plain: row stride; conv: pixel stride (>= Cin) in elements
+    const void* A2;  // optional second source for k >= K1 (plain mode), row = m % a2_row_mod
+    long lda2;
+    int K1, a2_row_mod;
+    const void* Wt;  // [N][ldw]
+    long ldw;
+    int Kw;  // valid k columns of Wt (multiple of 8)
+    int M, N, K;
+    // conv geometry (stored input H x W, output OH x OW)
+    int H, W, Cin, OH, OW, stride, upsample;
+    const float* bias;     // [N] or null
+    const float* rowbias;  // [M / rows_per_sample][ld_rowbias] or null
+    int rows_per_sample;
+    int ld_rowbias;
+    const void* residual;  // [M][ldr] or null
+    long ldr;
+    void* C;  // [M][ldc]
+    long ldc;
+    const void* zeros;  // >= 16 zero bytes, 16-B aligned
+    int flags;
+};
+int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
+
+struct AttnParams {
+    const void* Q; const void* K; const void* V;  // [B][n][ld*], head h at column h*dh
+    long ldq, ldk, ldv;           // row (token) strides in elements
+    long bsq, bsk, bsv;           // batch (sample) strides in elements
+    const int* qk_map;            // [B] source sample of q,k for output sample b, or null (identity)
+    const int* v_map;             // [B] source sample of v, or null
+    void* O; long ldo, bso;       // [B][n][ldo]
+    int B, heads, n, nk, dh;      // nk = number of keys (== n for self-attention)
+    float scale;
+};
+int vf_launch_attention(const AttnParams& p, int dtype, hipStream_t stream);
+
+int vf_launch_layernorm(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, int M,
+                        int C, float eps, int dtype, hipStream_t stream);
+int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
+                       float* stats, int dtype, hipStream_t stream);
+int vf_gn_partial_floats(int nimg, int hw, int C, int groups);
+int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y,
+                       long ldy, int nimg, int hw, int C, int groups, int silu, int dtype, hipStream_t stream);
+int vf_launch_flow_warp(const void* src, long ld_src, long fs_src, const void* prev, long ld_prev,
+                        const float* flow, const float* flow_prev, void* dst, long ld_dst, long fs_dst, int F, int h,
+                        int w, int C, float alpha, float one_minus_alpha, int flags, int* dbg_x0, int* dbg_y0, int dtype,
+                        hipStream_t stream);
+int vf_launch_timestep_embedding(const long long* t, void* out, int N, int dim, int dtype, hipStream_t stream);
+int vf_launch_silu(const void* x, void* y, long count, int in_f32, int dtype, hipStream_t stream);
+int vf_launch_pack_input(const float* x, const float* inv, const float* inpaint, const float* mask, void* out,
+                         int F, int h, int w, int cpad, int dtype, hipStream_t stream);
+int vf_launch_nchw_to_nhwc(const float* x, void* out, int N, int C, int hw, int cpad, int dtype, hipStream_t stream);
+int vf_launch_nhwc_to_nchw_f32(const float* x, long ldx, float* out, int N, int C, int hw, hipStream_t stream);
+int vf_launch_ddim_step(const float* eps, long lde, const float* x, const float* inv, float* x_prev, float* pred_x0,
+                        float* x_prev_recon, int F, int C, int hw, float scale, float a_t, float a_prev, float sigma_t,
+                        float sqrt_1m_at, const float* noise, hipStream_t stream);
+int vf_launch_copy2d(const void* src, long lds, void* dst, long ldd, long rows, int cols, int dtype,
+                     hipStream_t stream);
+int vf_launch_cast(const float* src, void* dst, long count, int dtype, hipStream_t stream);

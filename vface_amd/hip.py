@@ -1,0 +1,244 @@
+"""ctypes binding of ``libvface_hip.so`` (C ABI: ``include/vface_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every call below hands raw device
+pointers and ``torch.cuda.current_stream().cuda_stream`` to a hand-written gfx950 kernel.  There is no
+fallback: if the library is missing, or a tensor is not on the GPU, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvface_hip.so")
+
+F16, BF16 = 0, 1
+EPI_GEGLU, EPI_OUT_F32 = 1, 2
+FUSION_NONE, FUSION_REPLACE, FUSION_LINEAR = 0, 1, 2
+
+_i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/vface_hip.h one to one
+SIGNATURES = {
+    "vface_abi_version": (C.c_int, []),
+    "vface_error_string": (C.c_char_p, [_i32]),
+    "vface_gemm": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp,
+                             _i64, _vp, _i64, _vp, _i32, _i32, _vp]),
+    "vface_conv3x3": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp,
+                                _i64, _vp, _i64, _vp, _i32, _i32, _vp]),
+    "vface_attention": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32,
+                                  _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+    "vface_layernorm": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _vp]),
+    "vface_groupnorm_partial_floats": (C.c_int, [_i32, _i32, _i32, _i32]),
+    "vface_groupnorm_stats": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _vp]),
+    "vface_groupnorm_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vface_flow_warp": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
+                                  _f32, _i32, _vp, _vp, _i32, _vp]),
+    "vface_attn1_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "vface_attn1_forward": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32,
+                                      _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _sz, _vp, _i32, _vp]),
+    "vface_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "vface_silu": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "vface_cast_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "vface_pack_unet_input": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vface_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vface_nhwc_to_nchw_f32": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp]),
+    "vface_ddim_step": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32,
+                                  _vp, _vp]),
+    "vface_copy2d": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+class VFaceHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the library and bind every symbol of the header; raises if it is absent (no CPU fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VFaceHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The VFace path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.vface_abi_version() != 1:
+        raise VFaceHipError("libvface_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        msg = load().vface_error_string(rc).decode()
+        raise VFaceHipError(f"{what}: {msg} (code {rc})")
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float16:
+        return F16
+    if dt == torch.bfloat16:
+        return BF16
+    raise VFaceHipError(f"unsupported dtype {dt}: the HIP path computes in fp16 or bf16")
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VFaceHipError("tensor is not on the GPU: the VFace hot path has no CPU fallback")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+_zeros = {}
+
+
+def zeros_page(device) -> torch.Tensor:
+    """A 256-byte zero page the implicit-GEMM kernels read for padding taps / tile tails."""
+    key = str(device)
+    if key not in _zeros:
+        _zeros[key] = torch.zeros(256, dtype=torch.uint8, device=device)
+    return _zeros[key]
+
+
+# ---------------------------------------------------------------------------------------------- wrappers
+def gemm(a: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldc: int,
+         ldw: Optional[int] = None, bias=None, rowbias=None, rows_per_sample: int = 1, residual=None, ldr: int = 0,
+         a2=None, lda2: int = 0, k1: int = 0, a2_row_mod: int = 0, flags: int = 0):
+    """out[M, :N] = a[M, :K] @ wt[:N, :K]^T (+ epilogue).  Tensors are device buffers; M/N/K/ld* describe the view."""
+    lib = load()
+    rc = lib.vface_gemm(_p(a), lda, _p(a2), lda2, k1, a2_row_mod, _p(wt), ldw if ldw is not None else K, M, N, K,
+                        _p(bias), _p(rowbias), rows_per_sample, rowbias.shape[-1] if rowbias is not None else 0,
+                        _p(residual), ldr, _p(out), ldc, _p(zeros_page(a.device)), flags, dtype_code(a.dtype),
+                        _stream())
+    _check(rc, "vface_gemm")
+
+
+def conv3x3(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, H: int, W: int, cin: int, cout: int,
+            ldx: int, ldy: int, stride: int = 1, upsample: bool = False, bias=None, rowbias=None, residual=None,
+            ldr: int = 0, flags: int = 0):
+    lib = load()
+    rc = lib.vface_conv3x3(_p(x), ldx, nimg, H, W, cin, _p(wt), 9 * cin, cout, stride, int(upsample), _p(bias),
+                           _p(rowbias), rowbias.shape[-1] if rowbias is not None else 0, _p(residual), ldr, _p(out),
+                           ldy, _p(zeros_page(x.device)), flags, dtype_code(x.dtype), _stream())
+    _check(rc, "vface_conv3x3")
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, B: int, heads: int, n: int,
+              nk: int, dh: int, ldq: int, ldk: int, ldv: int, bsq: int, bsk: int, bsv: int, ldo: int, bso: int,
+              scale: float, qk_map=None, v_map=None):
+    lib = load()
+    rc = lib.vface_attention(_p(q), _p(k), _p(v), ldq, ldk, ldv, bsq, bsk, bsv, _p(qk_map), _p(v_map), _p(out), ldo,
+                             bso, B, heads, n, nk, dh, scale, dtype_code(out.dtype), _stream())
+    _check(rc, "vface_attention")
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, *, M: int, C_: int,
+              ldx: int, ldy: int, eps: float = 1e-5):
+    rc = load().vface_layernorm(_p(x), ldx, _p(gamma), _p(beta), _p(out), ldy, M, C_, eps, dtype_code(x.dtype),
+                                _stream())
+    _check(rc, "vface_layernorm")
+
+
+def groupnorm_stats(x: torch.Tensor, *, nimg: int, hw: int, C_: int, ldx: int, groups: int = 32, eps: float = 1e-5):
+    lib = load()
+    nf = lib.vface_groupnorm_partial_floats(nimg, hw, C_, groups)
+    partial = torch.empty(nf, dtype=torch.float32, device=x.device)
+    stats = torch.empty(nimg, groups, 2, dtype=torch.float32, device=x.device)
+    rc = lib.vface_groupnorm_stats(_p(x), ldx, nimg, hw, C_, groups, eps, _p(partial), _p(stats),
+                                   dtype_code(x.dtype), _stream())
+    _check(rc, "vface_groupnorm_stats")
+    return stats
+
+
+def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor,
+                    *, nimg: int, hw: int, C_: int, ldx: int, ldy: int, groups: int = 32, silu: bool = False):
+    rc = load().vface_groupnorm_apply(_p(x), ldx, _p(stats), _p(gamma), _p(beta), _p(out), ldy, nimg, hw, C_, groups,
+                                      int(silu), dtype_code(x.dtype), _stream())
+    _check(rc, "vface_groupnorm_apply")
+
+
+def flow_warp(src: torch.Tensor, dst: torch.Tensor, flow: Optional[torch.Tensor], *, F: int, h: int, w: int, C_: int,
+              ld_src: int, fs_src: int, ld_dst: int, fs_dst: int, alpha: float, prev=None, ld_prev: int = 0,
+              flow_prev=None, cuda_recip_div: bool = False, dbg_x0=None, dbg_y0=None):
+    # python-double (1 - alpha) rounded to fp32, as the reference's scalar * fp32-tensor product sees it
+    rc = load().vface_flow_warp(_p(src), ld_src, fs_src, _p(prev), ld_prev, _p(flow), _p(flow_prev), _p(dst), ld_dst,
+                                fs_dst, F, h, w, C_, float(alpha), float(1.0 - alpha), int(cuda_recip_div),
+                                _p(dbg_x0), _p(dbg_y0), dtype_code(src.dtype), _stream())
+    _check(rc, "vface_flow_warp")
+
+
+def attn1_workspace_bytes(B: int, n: int, d: int, chunks: int) -> int:
+    return int(load().vface_attn1_workspace_bytes(B, n, d, chunks))
+
+
+def attn1_forward(x, wqkv, wlin, wo, bo, out, *, B, n, d, heads, chunks, fusion, ldx, ldo, workspace, rowbias=None,
+                  residual=None, ldr=0, v_fixed=False, flow=None, h=0, w=0, alpha=0.8, cuda_recip_div=False,
+                  halo_qk=None, halo_flow=None, tail_qk=None, qk_map=None, v_map=None):
+    rc = load().vface_attn1_forward(_p(x), ldx, _p(wqkv), _p(wlin), _p(wo), _p(bo), _p(rowbias),
+                                    rowbias.shape[-1] if rowbias is not None else 0, _p(residual), ldr, _p(out), ldo,
+                                    B, n, d, heads, chunks, fusion, int(v_fixed), _p(flow), h, w, float(alpha),
+                                    float(1.0 - alpha), int(cuda_recip_div), _p(halo_qk), _p(halo_flow), _p(tail_qk),
+                                    _p(qk_map), _p(v_map), _p(workspace), workspace.numel() * workspace.element_size(),
+                                    _p(zeros_page(x.device)), dtype_code(x.dtype), _stream())
+    _check(rc, "vface_attn1_forward")
+
+
+def timestep_embedding(t: torch.Tensor, out: torch.Tensor, dim: int):
+    assert t.dtype == torch.int64
+    rc = load().vface_timestep_embedding(_p(t), _p(out), t.numel(), dim, dtype_code(out.dtype), _stream())
+    _check(rc, "vface_timestep_embedding")
+
+
+def silu(x: torch.Tensor, out: torch.Tensor):
+    rc = load().vface_silu(_p(x), _p(out), x.numel(), int(x.dtype == torch.float32), dtype_code(out.dtype), _stream())
+    _check(rc, "vface_silu")
+
+
+def cast_f32(x: torch.Tensor, out: torch.Tensor):
+    assert x.dtype == torch.float32
+    rc = load().vface_cast_f32(_p(x), _p(out), x.numel(), dtype_code(out.dtype), _stream())
+    _check(rc, "vface_cast_f32")
+
+
+def pack_unet_input(x, inv, inpaint, mask, out, *, F, h, w, cpad):
+    rc = load().vface_pack_unet_input(_p(x), _p(inv), _p(inpaint), _p(mask), _p(out), F, h, w, cpad,
+                                      dtype_code(out.dtype), _stream())
+    _check(rc, "vface_pack_unet_input")
+
+
+def nchw_to_nhwc(x: torch.Tensor, out: torch.Tensor, *, N: int, C_: int, hw: int, cpad: int):
+    rc = load().vface_nchw_to_nhwc(_p(x), _p(out), N, C_, hw, cpad, dtype_code(out.dtype), _stream())
+    _check(rc, "vface_nchw_to_nhwc")
+
+
+def nhwc_to_nchw_f32(x: torch.Tensor, out: torch.Tensor, *, N: int, C_: int, hw: int, ldx: int):
+    rc = load().vface_nhwc_to_nchw_f32(_p(x), ldx, _p(out), N, C_, hw, _stream())
+    _check(rc, "vface_nhwc_to_nchw_f32")
+
+
+def ddim_step(eps, x, inv, x_prev, *, F, C_, hw, lde, scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, pred_x0=None,
+              x_prev_recon=None, noise=None):
+    rc = load().vface_ddim_step(_p(eps), lde, _p(x), _p(inv), _p(x_prev), _p(pred_x0), _p(x_prev_recon), F, C_, hw,
+                                scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, _p(noise), _stream())
+    _check(rc, "vface_ddim_step")
+
+
+def copy2d(src, dst, *, rows, cols, ld_src, ld_dst):
+    rc = load().vface_copy2d(_p(src), ld_src, _p(dst), ld_dst, rows, cols, dtype_code(src.dtype), _stream())
+    _check(rc, "vface_copy2d")

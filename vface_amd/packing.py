@@ -1,0 +1,73 @@
+"""Weight packing for the HIP kernels (host side, done once per module / hook configuration).
+
+Everything here is a re-layout or an exact linear refactoring of the reference's fp32 parameters,
+computed in fp64 and handed to the device in the 16-bit compute type:
+
+* ``pack_conv3x3``   nn.Conv2d weight [Cout, Cin, 3, 3] -> [Cout, (ky, kx, Cin_pad)] for the implicit GEMM.
+* ``pack_geglu``     GEGLU.proj rows (attention.py:40-44: first half value, second half gate) interleaved in
+                     16-row blocks so the GEMM epilogue finds value and gate of a channel in the same lane.
+* ``pack_qkv``       to_q | to_k | to_v stacked into one [3d, d] matrix (one GEMM, attention.py:161,171-172).
+* ``fold_fsai``      frequency-spectrum attention interpolation folded into the projection:
+                     ``combine_fft_high_low`` (face_swap_utils.py:425-464) is linear, so for chunk c >= 1
+                     q_new = q_c A_lo + q_0 A_hi = x_c (Wq^T A_lo) + x_0 (Wq^T A_hi).
+* ``fold_mix``       the same mechanism for ``mix_source_and_target`` (face_swap_utils.py:189-199).
+"""
+from __future__ import annotations
+
+import torch
+
+
+def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None) -> torch.Tensor:
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    cp = cin_pad if cin_pad is not None else (cin + 7) // 8 * 8
+    out = torch.zeros(cout, 3, 3, cp, dtype=w.dtype)
+    out[..., :cin] = w.permute(0, 2, 3, 1)
+    return out.reshape(cout, 9 * cp).contiguous()
+
+
+def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
+    return w.reshape(w.shape[0], w.shape[1]).contiguous()
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor):
+    two_inner, d = w.shape
+    inner = two_inner // 2
+    assert inner % 16 == 0, "GEGLU inner width must be a multiple of 16"
+    val, gate = w[:inner].reshape(inner // 16, 16, d), w[inner:].reshape(inner // 16, 16, d)
+    wp = torch.stack([val, gate], 1).reshape(two_inner, d).contiguous()
+    bv, bg = b[:inner].reshape(inner // 16, 16), b[inner:].reshape(inner // 16, 16)
+    bp = torch.stack([bv, bg], 1).reshape(two_inner).contiguous()
+    return wp, bp
+
+
+def pack_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor) -> torch.Tensor:
+    return torch.cat([wq, wk, wv], 0).contiguous()
+
+
+def _band_filter_rows(m: torch.Tensor, lo: int, hi: int) -> torch.Tensor:
+    """Re(ifft(mask[lo:hi] * fft(row))) for every row of ``m`` (fp64)."""
+    f = torch.fft.fft(m.double(), dim=-1)
+    keep = torch.zeros_like(f)
+    keep[..., lo:hi] = f[..., lo:hi]
+    return torch.fft.ifft(keep, dim=-1).real
+
+
+def fold_fsai(wq: torch.Tensor, wk: torch.Tensor, split_ratio: float) -> torch.Tensor:
+    """[2d, 2d] fp32: rows = fused q outputs then fused k outputs; columns = [own x | chunk-0 x].
+    Bins [0, int(d*ratio)) come from the own branch, the rest from chunk 0 (face_swap_utils.py:447-457)."""
+    d = wq.shape[0]
+    s = int(d * split_ratio)
+    blocks = []
+    for w in (wq, wk):
+        wt = w.double().t()  # [d_in, d_out]: row k is the response of every output channel to input k
+        own = _band_filter_rows(wt, 0, s).t()      # (Wq^T A_lo)^T  -> [d_out, d_in]
+        struct = _band_filter_rows(wt, s, d).t()   # (Wq^T A_hi)^T
+        blocks.append(torch.cat([own, struct], 1))
+    return torch.cat(blocks, 0).float().contiguous()
+
+
+def fold_mix(wq: torch.Tensor, wk: torch.Tensor, alpha: float) -> torch.Tensor:
+    """mix_source_and_target(target=chunk 0, source=own, alpha): (1-alpha)*own + alpha*chunk0."""
+    blocks = [torch.cat([(1.0 - alpha) * w.double(), alpha * w.double()], 1) for w in (wq, wk)]
+    return torch.cat(blocks, 0).float().contiguous()
