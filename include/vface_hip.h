@@ -137,10 +137,12 @@ int vface_pack_unet_input(const float* x, const float* inv, const float* inpaint
 int vface_nchw_to_nhwc(const float* x, void* out, int N, int C, int hw, int cpad, int dtype, void* stream);
 int vface_nhwc_to_nchw_f32(const float* x, int64_t ldx, float* out, int N, int C, int hw, void* stream);
 /* ddim_w_inv.py:666-667,686-700: guidance + x0 prediction + x_{t-1}; eps = NHWC fp32 UNet output of
- * [uncond ; cond ; recon]; x, inv, outputs NCHW fp32 [F][C][hw].  pred_x0 / x_prev_recon / noise optional. */
+ * [uncond ; cond ; recon]; x, inv, outputs NCHW fp32 [F][C][hw].  pred_x0 / x_prev_recon / noise optional.
+ * single_branch != 0: eps holds ONE branch [F] and is used unguided -- with a_t = a(t - T/S), a_prev = a(t),
+ * sigma 0 this is the inversion update of ddim_invert (ddim_w_inv.py:436-449). */
 int vface_ddim_step(const float* eps, int64_t lde, const float* x, const float* inv, float* x_prev, float* pred_x0,
                     float* x_prev_recon, int F, int C, int hw, float scale, float a_t, float a_prev, float sigma_t,
-                    float sqrt_one_minus_at, const float* noise, void* stream);
+                    float sqrt_one_minus_at, const float* noise, int single_branch, void* stream);
 /* strided 2-D copy of 16-bit rows (th.cat([h, hs.pop()], 1), openaimodel.py:898, when not written in place) */
 int vface_copy2d(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols, int dtype,
                  void* stream);

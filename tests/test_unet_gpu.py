@@ -1,0 +1,197 @@
+"""Whole-path parity on the MI355X: the hooked UNet and the DDIM loop through the product modules (HIP kernels)
+against the CPU oracle on the same seeded inputs, and against the reference-generated full-size fixture.
+Tolerance: rel-L2 <= 1e-3 in fp16 is the north-star bound for the UNet output; see TOL below for what is
+asserted per case."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2
+from oracle import ddim as oddim
+from oracle import hooks as ohooks
+from oracle import unet as ounet
+from vface_amd.utils import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+SMALL = ounet.UNetSpec(model_channels=64)
+
+
+def small_cfg(mc=64):
+    return dict(image_size=32, in_channels=9, out_channels=4, model_channels=mc, attention_resolutions=[4, 2, 1],
+                num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                transformer_depth=1, context_dim=768, legacy=False)
+
+
+@pytest.fixture(scope="module")
+def small():
+    from vface_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler
+    ldm = LatentDiffusion(small_cfg())
+    synth.fill_module_(ldm.unet, seed=0)
+    sd = {k: v.clone() for k, v in ldm.unet.state_dict().items()}
+    ldm = ldm.to(DEV)
+    return ldm, DDIMSampler(ldm), sd
+
+
+def _register(sampler, mode, flow):
+    from vface_amd.ldm.models.pnp_utils import register_spa_attn_injection as reg
+    reg(sampler, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True, chunks=3)
+    if mode == "off":
+        return
+    kw = dict(switch_on=True, attn_component="attn1", flow=flow, split_ratio_fft=0.8, alpha=0.8)
+    if mode.startswith("in_"):
+        reg(sampler, 1, input_blocks=True, middle_block=False, output_blocks=False, chunks=3,
+            block_indices=list(range(9)), fusion=mode[3:], **kw)
+    elif mode == "out_fft":
+        reg(sampler, 1, input_blocks=False, middle_block=False, output_blocks=True, chunks=3,
+            block_indices=list(range(9)), fusion="fft", **kw)
+    elif mode == "sel_replace_025":
+        reg(sampler, 1, input_blocks=True, middle_block=True, output_blocks=True, chunks=3, block_indices=[0, 2, 5],
+            fusion="replace", **kw)
+    elif mode == "chunks2":
+        reg(sampler, 1, input_blocks=True, middle_block=False, output_blocks=True, chunks=2, block_indices=[0, 1, 2], **kw)
+
+
+def _oracle_registry(mode, flow):
+    names = ounet.attn1_names(SMALL)
+    r = {}
+    ohooks.register_spa_attn_injection(r, names, 1, switch_on=False, input_blocks=True, middle_block=True,
+                                       output_blocks=True, chunks=3)
+    kw = dict(switch_on=True, flow=flow, split_ratio_fft=0.8, alpha=0.8)
+    if mode.startswith("in_"):
+        ohooks.register_spa_attn_injection(r, names, 1, input_blocks=True, middle_block=False, output_blocks=False,
+                                           chunks=3, block_indices=list(range(9)), fusion=mode[3:], **kw)
+    elif mode == "out_fft":
+        ohooks.register_spa_attn_injection(r, names, 1, input_blocks=False, middle_block=False, output_blocks=True,
+                                           chunks=3, block_indices=list(range(9)), fusion="fft", **kw)
+    elif mode == "sel_replace_025":
+        ohooks.register_spa_attn_injection(r, names, 1, input_blocks=True, middle_block=True, output_blocks=True,
+                                           chunks=3, block_indices=[0, 2, 5], fusion="replace", **kw)
+    elif mode == "chunks2":
+        ohooks.register_spa_attn_injection(r, names, 1, input_blocks=True, middle_block=False, output_blocks=True,
+                                           chunks=2, block_indices=[0, 1, 2], **kw)
+    return r
+
+
+MODES = ["off", "in_replace", "in_fft", "in_flow_fix", "in_fft_vfixed", "in_mix", "out_fft", "sel_replace_025", "chunks2"]
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_small_unet_hook_modes_vs_oracle(small, mode):
+    """model_channels=64 (head dims 8/16/32) at a 32x32 latent; the flow gate fires at level 0 (n = 1024)."""
+    ldm, sampler, sd = small
+    F_, h, w = 2, 32, 32
+    n = 4 if mode == "chunks2" else 6
+    x = synth.synth_normal("small.x", (6, 9, h, w))[:n]
+    ctx = synth.synth_normal("small.ctx", (6, 1, 768))[:n]
+    t = torch.full((n,), 481, dtype=torch.long)
+    flow = [synth.synth_flow(F_ - 1, h, w)[i][None] for i in range(F_ - 1)]
+    _register(sampler, mode, flow)
+    got = ldm.apply_model(x.to(DEV), t.to(DEV), ctx.to(DEV)).float().cpu()
+    ref = ounet.unet_forward(sd, SMALL, x, t, ctx, _oracle_registry(mode, flow))
+    err = rel_l2(got, ref)
+    print(f"{mode}: rel-L2 {err:.3e}")
+    assert err < 2e-3, (mode, err)
+
+
+def test_unsupported_modes_fail_loudly(small):
+    ldm, sampler, _ = small
+    x = synth.synth_normal("small.x", (6, 9, 32, 32)).to(DEV)
+    ctx = synth.synth_normal("small.ctx", (6, 1, 768)).to(DEV)
+    t = torch.full((6,), 481, dtype=torch.long, device=DEV)
+    _register(sampler, "in_temporal", None)
+    with pytest.raises(NotImplementedError):
+        ldm.apply_model(x, t, ctx)
+    _register(sampler, "off", None)
+    from vface_amd import hip
+    with pytest.raises(hip.VFaceHipError):
+        ldm.apply_model(x.cpu(), t.cpu(), ctx.cpu())
+
+
+@pytest.mark.parametrize("mode", ["plain", "flow_fix", "replace"])
+def test_full_unet_vs_reference_golden(mode):
+    """The real 859.5 M-parameter UNet, F=2 at 64x64, against the fixture the reference itself produced."""
+    from vface_amd.ldm.models.diffusion.ddpm import FFHQ_UNET_CONFIG, LatentDiffusion
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler
+    from vface_amd.ldm.models.pnp_utils import register_spa_attn_injection as reg
+    g = load_golden("full_unet")
+    ldm = _full_model()
+    sampler = DDIMSampler(ldm)
+    F_, h, w = 2, 64, 64
+    x = synth.synth_normal("full.x", (3 * F_, 9, h, w)).to(DEV)
+    ctx = synth.synth_normal("full.ctx", (3 * F_, 1, 768)).to(DEV)
+    t = torch.full((3 * F_,), 481, dtype=torch.long, device=DEV)
+    flow = [synth.synth_flow(F_ - 1, h, w)[i][None] for i in range(F_ - 1)]
+    reg(sampler, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True, chunks=3)
+    if mode != "plain":
+        reg(sampler, 1, switch_on=True, input_blocks=True, middle_block=False, output_blocks=False, chunks=3,
+            flow=flow if mode == "flow_fix" else None, block_indices=list(range(9)), fusion=mode,
+            split_ratio_fft=0.8, alpha=0.8)
+    got = ldm.apply_model(x, t, ctx).float().cpu()
+    err = rel_l2(got, g[mode])
+    print(f"full UNet {mode}: rel-L2 vs reference {err:.3e}")
+    assert err < 2e-3, err
+
+
+_FULL = {}
+
+
+def _full_model():
+    if "m" not in _FULL:
+        from vface_amd.ldm.models.diffusion.ddpm import FFHQ_UNET_CONFIG, LatentDiffusion
+        ldm = LatentDiffusion(dict(FFHQ_UNET_CONFIG))
+        synth.fill_module_(ldm.unet, seed=0)
+        _FULL["m"] = ldm.to(DEV)
+    return _FULL["m"]
+
+
+def test_ddim_three_steps_and_inversion_vs_oracle(small):
+    ldm, sampler, sd = small
+    F_, h, w = 2, 32, 32
+    x_T = synth.synth_normal("ddim.xT", (F_, 4, h, w))
+    c, uc, tc = (synth.synth_normal(f"ddim.{k}", (F_, 1, 768)) for k in ("c", "uc", "tc"))
+    inp = synth.synth_normal("ddim.inpaint", (F_, 4, h, w)) * 0.18215
+    mask = synth.synth_mask(F_, h, w)
+    flow = [synth.synth_flow(F_ - 1, h, w)[i][None] for i in range(F_ - 1)]
+    inv = {int(s): synth.synth_normal(f"ddim.inv.{int(s)}", (F_, 4, h, w)) for s in oddim.ddim_timesteps(50)}
+    d = lambda v: v.to(DEV)
+    img, inter = sampler.sample(S=50, batch_size=F_, shape=[4, h, w], conditioning=d(c), target_conditioning=d(tc),
+                                inverse_results_dir={k: d(v) for k, v in inv.items()}, verbose=False,
+                                unconditional_guidance_scale=3.0, unconditional_conditioning=d(uc), eta=0.0,
+                                x_T=d(x_T), flow=flow, test_model_kwargs={"inpaint_image": d(inp), "inpaint_mask": d(mask)},
+                                log_every_t=1, max_steps=3)
+    names = ounet.attn1_names(SMALL)
+
+    def apply_model(x, t, cc, reg):
+        return ounet.unet_forward(sd, SMALL, x, t, cc, reg)
+
+    ref, trace = oddim.sample(apply_model, names, 50, x_T, c, uc, tc, inv, inp, mask, scale=3.0, eta=0.0, flow=flow,
+                              steps_limit=3)
+    err = rel_l2(img.cpu(), ref)
+    print(f"ddim 3 steps: rel-L2 {err:.3e}")
+    assert err < 2e-3
+    assert len(inter["x_inter"]) == 4
+    # inversion, 2 steps, hooks off, stores the target half device-resident
+    x0 = synth.synth_normal("ddim.z2", (2 * F_, 4, h, w))
+    cond2 = torch.cat([tc, c], 0)
+    store = {}
+    xn, _ = sampler.ddim_invert(x=d(x0), cond=d(cond2), S=50, shape=[4, h, w], inverse_dir=store, batch_size=F_,
+                                test_model_kwargs={"inpaint_image": d(torch.cat([inp] * 2)),
+                                                   "inpaint_mask": d(torch.cat([mask] * 2))}, max_steps=2)
+    rxn, rsaved = oddim.invert(lambda x, t, cc, reg: ounet.unet_forward(sd, SMALL, x, t, cc, None), 50, x0, cond2,
+                               torch.cat([inp] * 2), torch.cat([mask] * 2), batch_size=F_, steps_limit=2)
+    assert rel_l2(xn.cpu(), rxn) < 2e-3
+    assert sorted(store) == [1, 21] and rel_l2(store[21].cpu(), rsaved[21]) < 2e-3
+
+
+def test_flow_resolution_mismatch_raises_like_reference(small):
+    """a 512x512 flow against a 64x64 map is a RuntimeError in the reference's warp_image."""
+    ldm, sampler, _ = small
+    F_, h, w = 2, 32, 32
+    z = torch.zeros(F_, 4, h, w, device=DEV)
+    cc = torch.zeros(F_, 1, 768, device=DEV)
+    with pytest.raises(RuntimeError):
+        sampler.sample(S=50, batch_size=F_, shape=[4, h, w], conditioning=cc, target_conditioning=cc,
+                       inverse_results_dir={}, verbose=False, unconditional_guidance_scale=3.0,
+                       unconditional_conditioning=cc, x_T=z, flow=[torch.zeros(1, 2, 8 * h, 8 * w)],
+                       test_model_kwargs={"inpaint_image": z, "inpaint_mask": z[:, :1]})

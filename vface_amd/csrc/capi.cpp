@@ -208,9 +208,9 @@ int vface_nhwc_to_nchw_f32(const float* x, int64_t ldx, float* out, int N, int C
 }
 int vface_ddim_step(const float* eps, int64_t lde, const float* x, const float* inv, float* x_prev, float* pred_x0,
                     float* x_prev_recon, int F, int C, int hw, float scale, float a_t, float a_prev, float sigma_t,
-                    float sqrt_one_minus_at, const float* noise, void* stream) {
+                    float sqrt_one_minus_at, const float* noise, int single_branch, void* stream) {
     return vf_launch_ddim_step(eps, lde, x, inv, x_prev, pred_x0, x_prev_recon, F, C, hw, scale, a_t, a_prev, sigma_t,
-                               sqrt_one_minus_at, noise, S(stream));
+                               sqrt_one_minus_at, noise, single_branch, S(stream));
 }
 int vface_copy2d(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows, int cols, int dtype,
                  void* stream) {

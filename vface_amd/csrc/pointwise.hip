@@ -318,7 +318,7 @@ __global__ void ddim_step_kernel(const float* __restrict__ eps, long lde, const 
                                  const float* __restrict__ inv, float* __restrict__ x_prev,
                                  float* __restrict__ pred_x0, float* __restrict__ x_prev_recon, int F, int C, int hw,
                                  float scale, float a_t, float a_prev, float sigma_t, float sqrt_1m_at,
-                                 const float* __restrict__ noise) {
+                                 const float* __restrict__ noise, int single) {
     const long total = (long)F * C * hw;
     const float sqrt_at = sqrtf(a_t), sqrt_ap = sqrtf(a_prev);
     const float dir = sqrtf(1.0f - a_prev - sigma_t * sigma_t);
@@ -328,9 +328,10 @@ __global__ void ddim_step_kernel(const float* __restrict__ eps, long lde, const 
         const int c = (int)(fc % C);
         const int f = (int)(fc / C);
         const float eu = eps[((long)f * hw + pix) * lde + c];
-        const float ec = eps[((long)(F + f) * hw + pix) * lde + c];
-        const float er = eps[((long)(2 * F + f) * hw + pix) * lde + c];
-        const float e_t = eu + scale * (ec - eu);
+        // single: eps holds one branch only (DDIM inversion, no guidance, ddim_w_inv.py:426-427)
+        const float ec = single ? eu : eps[((long)(F + f) * hw + pix) * lde + c];
+        const float er = single ? eu : eps[((long)(2 * F + f) * hw + pix) * lde + c];
+        const float e_t = single ? eu : eu + scale * (ec - eu);
         const float p0 = (x[i] - sqrt_1m_at * e_t) / sqrt_at;
         const float nz = noise ? sigma_t * noise[i] : 0.f;
         x_prev[i] = sqrt_ap * p0 + dir * e_t + nz;
@@ -507,11 +508,11 @@ int vf_launch_nhwc_to_nchw_f32(const float* x, long ldx, float* out, int N, int 
 
 int vf_launch_ddim_step(const float* eps, long lde, const float* x, const float* inv, float* x_prev, float* pred_x0,
                         float* x_prev_recon, int F, int C, int hw, float scale, float a_t, float a_prev, float sigma_t,
-                        float sqrt_1m_at, const float* noise, hipStream_t stream) {
+                        float sqrt_1m_at, const float* noise, int single, hipStream_t stream) {
     if (!eps || !x || !x_prev || F <= 0 || C <= 0 || hw <= 0 || lde < C) return VF_ERR_ARG;
     const long total = (long)F * C * hw;
     hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(total)), dim3(256), 0, stream, eps, lde, x, inv, x_prev, pred_x0,
-                       x_prev_recon, F, C, hw, scale, a_t, a_prev, sigma_t, sqrt_1m_at, noise);
+                       x_prev_recon, F, C, hw, scale, a_t, a_prev, sigma_t, sqrt_1m_at, noise, single);
     return ok();
 }
 

@@ -62,7 +62,7 @@ int vf_launch_nchw_to_nhwc(const float* x, void* out, int N, int C, int hw, int 
 int vf_launch_nhwc_to_nchw_f32(const float* x, long ldx, float* out, int N, int C, int hw, hipStream_t stream);
 int vf_launch_ddim_step(const float* eps, long lde, const float* x, const float* inv, float* x_prev, float* pred_x0,
                         float* x_prev_recon, int F, int C, int hw, float scale, float a_t, float a_prev, float sigma_t,
-                        float sqrt_1m_at, const float* noise, hipStream_t stream);
+                        float sqrt_1m_at, const float* noise, int single, hipStream_t stream);
 int vf_launch_copy2d(const void* src, long lds, void* dst, long ldd, long rows, int cols, int dtype,
                      hipStream_t stream);
 int vf_launch_cast(const float* src, void* dst, long count, int dtype, hipStream_t stream);

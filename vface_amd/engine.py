@@ -1,0 +1,497 @@
+"""Device-resident execution of the hooked ldm UNet on MI355X.
+
+The nn.Modules in ``vface_amd.ldm`` only own parameters (with the reference's state-dict names); this
+engine walks them and issues hand-written HIP kernels (``vface_amd/hip.py`` -> ``libvface_hip.so``):
+
+* activations live in HBM as token-major / NHWC 16-bit matrices ``[N*H*W, C]`` -- the layout in which the
+  reference's ``b c h w <-> b (h w) c`` rearranges (attention.py:284,287) are no-ops, every conv is an
+  implicit GEMM over contiguous channels, and ``th.cat([h, hs.pop()], 1)`` (openaimodel.py:898) is two
+  producers writing disjoint column ranges of one buffer;
+* per-sample additive terms (the time-embedding projection of every ResBlock, and the single-token
+  cross-attention, which reduces to ``to_out(to_v(ctx))`` broadcast over tokens -- SURVEY F11) are computed
+  once per forward as small GEMMs and folded into GEMM epilogues as a row bias;
+* the attn1 hook (pnp_utils.py:94-287) is executed from its configuration, not from the closure: "replace"
+  is an index map inside the attention kernel, FSAI / mix are folded into the q,k projection weights, and
+  the flow warp is one gather kernel on chunk 1's fused q|k.
+
+There is no CPU path here.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from . import hip, packing
+
+
+@dataclass
+class HookCfg:
+    """Captured arguments of ``register_spa_attn_injection`` (pnp_utils.py:57) for one attn1 module."""
+    switch_on: bool = True
+    chunks: int = 3
+    fusion: str = "replace"
+    flow: Optional[torch.Tensor] = None  # [F-1, 2, h, w] fp32 on the device, or None
+    split_ratio_fft: float = 0.8
+    alpha: float = 0.8
+
+
+class Act:
+    """A 2-D view ``[rows, C]`` (stride ``(ld, 1)``) of a 16-bit device buffer, with its image geometry."""
+    __slots__ = ("t", "N", "H", "W")
+
+    def __init__(self, t: torch.Tensor, N: int, H: int, W: int):
+        assert t.dim() == 2 and t.stride(1) == 1
+        self.t, self.N, self.H, self.W = t, N, H, W
+
+    @property
+    def C(self):
+        return self.t.shape[1]
+
+    @property
+    def ld(self):
+        return self.t.stride(0)
+
+    @property
+    def M(self):
+        return self.t.shape[0]
+
+    @property
+    def hw(self):
+        return self.H * self.W
+
+
+def _dev_flow(flow, device) -> Optional[torch.Tensor]:
+    """Accept the reference's ``list of [1,2,h,w]`` or a stacked tensor; return [F-1,2,h,w] fp32 on device."""
+    if flow is None:
+        return None
+    if isinstance(flow, (list, tuple)):
+        if len(flow) == 0:
+            return None
+        flow = torch.cat([f.reshape(1, 2, f.shape[-2], f.shape[-1]) for f in flow], 0)
+    return flow.to(device=device, dtype=torch.float32).contiguous()
+
+
+def plan_fusion(cfg: Optional[HookCfg], N: int, n: int) -> dict:
+    """Map a hook configuration onto the kernels' mechanisms (pnp_utils.py:129-262).
+    Returns fusion code, chunks, which folded weight to use, and the flow / v-broadcast options."""
+    pl = {"fusion": hip.FUSION_NONE, "chunks": 1, "wlin": None, "flow": None, "alpha": 0.8, "v_fixed": False}
+    if cfg is None or not cfg.switch_on:
+        return pl
+    chunks = cfg.chunks
+    if chunks not in (2, 3):
+        return pl  # the reference edits nothing for other values
+    if N % chunks:
+        raise hip.VFaceHipError(f"hooked attn1: batch {N} is not divisible by chunks={chunks}")
+    pl["chunks"] = chunks
+    f = cfg.fusion
+    if chunks == 2 or f == "replace":
+        pl["fusion"] = hip.FUSION_REPLACE
+    elif f in ("fft", "flow_fix", "fft_vfixed"):
+        pl["fusion"] = hip.FUSION_LINEAR
+        pl["wlin"] = ("fsai", 0.8 if f == "fft_vfixed" else cfg.split_ratio_fft)
+        pl["v_fixed"] = f == "fft_vfixed"
+        if f == "flow_fix" and cfg.flow is not None and cfg.flow.shape[-2] * cfg.flow.shape[-1] == n:
+            # pnp_utils.py:201 gates on n == 4096 with a hard-coded 64x64 reshape; generalised to "the level
+            # whose token count equals the flow field's h*w" (identical at 512x512)
+            if cfg.flow.shape[0] != N // chunks - 1:
+                raise RuntimeError(f"flow has {cfg.flow.shape[0]} fields for {N // chunks} frames "
+                                   "(align_by_flow needs F-1, temporal_flow.py:231-233)")
+            pl["flow"], pl["alpha"] = cfg.flow, cfg.alpha
+    elif f == "mix":
+        pl["fusion"], pl["wlin"] = hip.FUSION_LINEAR, ("mix", 0.5)
+    elif f in ("temporal", "adaIn"):
+        raise NotImplementedError(f"fusion={f!r} has no HIP kernel yet (inactive in the shipped sampler, "
+                                  "ddim_w_inv.py:289-305); refusing to fall back to a CPU path")
+    else:
+        pl["chunks"] = 1  # unknown fusion strings edit nothing in the reference
+    return pl
+
+
+COMPUTE_DTYPE = torch.float16  # module-level default for standalone module calls
+
+
+def attn_module_forward(mod, x: torch.Tensor, context: Optional[torch.Tensor], cfg: Optional[HookCfg]):
+    """``CrossAttention.forward`` / the hooked closure for a stand-alone module call on ``[B, n, d]`` CUDA
+    tensors (attention.py:179-221, pnp_utils.py:94-287).  Returns the 16-bit result, as autocast does."""
+    from . import packing
+    dt = x.dtype if x.dtype in (torch.float16, torch.bfloat16) else COMPUTE_DTYPE
+    pk = mod._packed(dt)
+    B, n, d_in = x.shape
+    d = mod.heads * mod.dim_head
+    dev = x.device
+
+    def to16(t):
+        t = t.contiguous()
+        if t.dtype == dt:
+            return t
+        o = torch.empty(t.shape, dtype=dt, device=dev)
+        hip.cast_f32(t.float(), o)
+        return o
+
+    x16 = to16(x).reshape(B * n, d_in)
+    out = torch.empty(B * n, mod.to_out[0].weight.shape[0], dtype=dt, device=dev)
+    if context is None:
+        pl = plan_fusion(cfg, B, n)
+        chunks = pl["chunks"]
+        wlin = None
+        if pl["wlin"]:
+            key = (pl["wlin"][0], round(float(pl["wlin"][1]), 9))
+            if key not in pk["wlin"]:
+                wq, wk = mod.to_q.weight.detach().float().cpu(), mod.to_k.weight.detach().float().cpu()
+                w = packing.fold_fsai(wq, wk, key[1]) if key[0] == "fsai" else packing.fold_mix(wq, wk, key[1])
+                pk["wlin"][key] = w.to(device=dev, dtype=dt).contiguous()
+            wlin = pk["wlin"][key]
+        idx = torch.arange(B, dtype=torch.int32)
+        c = B // chunks
+        qk_map = (idx % c).to(dev) if pl["fusion"] == hip.FUSION_REPLACE else None
+        v_map = torch.where(idx < c, idx, (idx // c) * c).to(dev) if pl["v_fixed"] else None
+        ws = torch.empty(hip.attn1_workspace_bytes(B, n, d, chunks), dtype=torch.uint8, device=dev)
+        flow = pl["flow"]
+        hip.attn1_forward(x16, pk["wqkv"], wlin, pk["wo"], pk["bo"], out, B=B, n=n, d=d, heads=mod.heads,
+                          chunks=chunks, fusion=pl["fusion"], ldx=d_in, ldo=out.shape[1], workspace=ws,
+                          v_fixed=pl["v_fixed"], flow=flow, h=flow.shape[-2] if flow is not None else 0,
+                          w=flow.shape[-1] if flow is not None else 0, alpha=pl["alpha"], qk_map=qk_map, v_map=v_map)
+    else:
+        m = context.shape[1]
+        c16 = to16(context).reshape(B * m, context.shape[2])
+        q = torch.empty(B * n, d, dtype=dt, device=dev)
+        k = torch.empty(B * m, d, dtype=dt, device=dev)
+        v = torch.empty(B * m, d, dtype=dt, device=dev)
+        hip.gemm(x16, pk["wq"], q, M=B * n, N=d, K=d_in, lda=d_in, ldc=d)
+        hip.gemm(c16, pk["wk"], k, M=B * m, N=d, K=c16.shape[1], lda=c16.shape[1], ldc=d)
+        hip.gemm(c16, pk["wv"], v, M=B * m, N=d, K=c16.shape[1], lda=c16.shape[1], ldc=d)
+        att = torch.empty(B * n, d, dtype=dt, device=dev)
+        hip.attention(q, k, v, att, B=B, heads=mod.heads, n=n, nk=m, dh=mod.dim_head, ldq=d, ldk=d, ldv=d, bsq=n * d,
+                      bsk=m * d, bsv=m * d, ldo=d, bso=n * d, scale=mod.scale)
+        hip.gemm(att, pk["wo"], out, M=B * n, N=out.shape[1], K=d, lda=d, ldc=out.shape[1], bias=pk["bo"])
+    return out.reshape(B, n, -1)
+
+
+class UNetEngine:
+    """Packed weights + kernel sequencing for one ``UNetModel``."""
+
+    def __init__(self, unet, dtype: torch.dtype = torch.float16):
+        self.unet = unet
+        self.dtype = dtype
+        self._packed: Dict[str, dict] = {}
+        self._maps: Dict[tuple, torch.Tensor] = {}
+        self._version = None
+        # multi-GPU: callable(tail [n, 2d]) -> (halo [n, 2d] or None); installed by parallel.FrameShard
+        self.halo_exchange: Optional[Callable] = None
+        self.halo_flow: Optional[torch.Tensor] = None  # flow from the previous rank's last frame into our frame 0
+        hip.load()
+
+    # ------------------------------------------------------------------ weights
+    @property
+    def device(self):
+        return next(self.unet.parameters()).device
+
+    def _w16(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(device=self.device, dtype=self.dtype).contiguous()
+
+    def _f32(self, t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(device=self.device, dtype=torch.float32).contiguous()
+
+    def pack(self):
+        """(Re)build every packed device weight from the module parameters."""
+        u = self.unet
+        if not next(u.parameters()).is_cuda:
+            raise hip.VFaceHipError("UNetModel parameters are not on the GPU: the VFace path has no CPU fallback")
+        P = self._packed = {}
+        sd = {k: v.detach() for k, v in u.state_dict().items()}
+        cpu = lambda k: sd[k].float().cpu()
+
+        def conv3(prefix):
+            return {"w": self._w16(packing.pack_conv3x3(cpu(prefix + ".weight"))),
+                    "b": self._f32(sd[prefix + ".bias"]), "cin": sd[prefix + ".weight"].shape[1],
+                    "cinp": (sd[prefix + ".weight"].shape[1] + 7) // 8 * 8, "cout": sd[prefix + ".weight"].shape[0]}
+
+        def lin(prefix, bias=True, conv=False):
+            w = sd[prefix + ".weight"]
+            w = w.reshape(w.shape[0], w.shape[1]) if conv else w
+            return {"w": self._w16(w), "b": self._f32(sd[prefix + ".bias"]) if bias else None}
+
+        P["time_embed.0"] = lin("time_embed.0")
+        P["time_embed.2"] = lin("time_embed.2")
+        emb_w, emb_b, off = [], [], 0
+        vcat_w, voff = [], 0
+        for kind, prefix, mod in u.layer_table():
+            if kind == "conv":
+                P[prefix] = conv3(prefix)
+            elif kind == "down":
+                P[prefix] = conv3(prefix + ".op")
+            elif kind == "up":
+                P[prefix] = conv3(prefix + ".conv")
+            elif kind == "res":
+                d = {"in_gn": (self._f32(sd[prefix + ".in_layers.0.weight"]), self._f32(sd[prefix + ".in_layers.0.bias"])),
+                     "conv1": conv3(prefix + ".in_layers.2"),
+                     "out_gn": (self._f32(sd[prefix + ".out_layers.0.weight"]), self._f32(sd[prefix + ".out_layers.0.bias"])),
+                     "conv2": conv3(prefix + ".out_layers.3")}
+                if (prefix + ".skip_connection.weight") in sd:
+                    d["skip"] = lin(prefix + ".skip_connection", conv=True)
+                cout = d["conv1"]["cout"]
+                emb_w.append(sd[prefix + ".emb_layers.1.weight"].float())
+                emb_b.append(sd[prefix + ".emb_layers.1.bias"].float())
+                d["emb_slice"] = (off, off + cout)
+                off += cout
+                P[prefix] = d
+            elif kind == "st":
+                t = prefix + ".transformer_blocks.0"
+                c = sd[prefix + ".proj_in.weight"].shape[0]
+                ffw, ffb = packing.pack_geglu(cpu(t + ".ff.net.0.proj.weight"), cpu(t + ".ff.net.0.proj.bias"))
+                d = {"gn": (self._f32(sd[prefix + ".norm.weight"]), self._f32(sd[prefix + ".norm.bias"])),
+                     "proj_in": lin(prefix + ".proj_in", conv=True), "proj_out": lin(prefix + ".proj_out", conv=True),
+                     "ln1": (self._f32(sd[t + ".norm1.weight"]), self._f32(sd[t + ".norm1.bias"])),
+                     "ln3": (self._f32(sd[t + ".norm3.weight"]), self._f32(sd[t + ".norm3.bias"])),
+                     "wqkv": self._w16(packing.pack_qkv(sd[t + ".attn1.to_q.weight"], sd[t + ".attn1.to_k.weight"],
+                                                       sd[t + ".attn1.to_v.weight"])),
+                     "wo": lin(t + ".attn1.to_out.0"),
+                     "ff1": {"w": self._w16(ffw), "b": self._f32(ffb)}, "ff2": lin(t + ".ff.net.2"),
+                     "a2_out": lin(t + ".attn2.to_out.0"), "a2_slice": (voff, voff + c), "c": c,
+                     "wlin": {}, "attn1_name": t + ".attn1"}
+                vcat_w.append(sd[t + ".attn2.to_v.weight"].float())
+                voff += c
+                P[prefix] = d
+        P["emb_all"] = {"w": self._w16(torch.cat(emb_w, 0)), "b": self._f32(torch.cat(emb_b, 0)), "n": off}
+        P["a2_v_all"] = {"w": self._w16(torch.cat(vcat_w, 0)), "n": voff}
+        P["out.gn"] = (self._f32(sd["out.0.weight"]), self._f32(sd["out.0.bias"]))
+        P["out.conv"] = conv3("out.2")
+        self._version = self._param_version()
+
+    def _param_version(self):
+        return tuple(p._version for p in self.unet.parameters())
+
+    def _ensure_packed(self):
+        if not self._packed or self._version != self._param_version():
+            self.pack()
+
+    def _wlin(self, st: dict, kind: str, param: float) -> torch.Tensor:
+        key = (kind, round(float(param), 9))
+        if key not in st["wlin"]:
+            sd = self.unet.state_dict()
+            wq = sd[st["attn1_name"] + ".to_q.weight"].float().cpu()
+            wk = sd[st["attn1_name"] + ".to_k.weight"].float().cpu()
+            w = packing.fold_fsai(wq, wk, param) if kind == "fsai" else packing.fold_mix(wq, wk, param)
+            st["wlin"][key] = self._w16(w)
+        return st["wlin"][key]
+
+    def _map(self, kind: str, B: int, c: int) -> torch.Tensor:
+        key = (kind, B, c)
+        if key not in self._maps:
+            if kind == "qk_replace":
+                m = torch.arange(B, dtype=torch.int32) % c
+            else:  # v_fixed: chunk 0 identity, chunk k >= 1 -> its first frame
+                idx = torch.arange(B, dtype=torch.int32)
+                m = torch.where(idx < c, idx, (idx // c) * c)
+            self._maps[key] = m.to(self.device)
+        return self._maps[key]
+
+    # ------------------------------------------------------------------ primitive steps
+    def _new(self, rows: int, cols: int, dtype=None) -> torch.Tensor:
+        return torch.empty(rows, cols, dtype=dtype or self.dtype, device=self.device)
+
+    def _gemm(self, a: torch.Tensor, w: dict, out: torch.Tensor, **kw):
+        K = a.shape[1]
+        hip.gemm(a, w["w"], out, M=a.shape[0], N=w["w"].shape[0], K=K, lda=a.stride(0), ldc=out.stride(0),
+                 ldw=w["w"].shape[1], bias=w.get("b"), **kw)
+
+    def _gn(self, x: Act, gn, eps: float, silu: bool) -> Act:
+        st = hip.groupnorm_stats(x.t, nimg=x.N, hw=x.hw, C_=x.C, ldx=x.ld, eps=eps)
+        y = self._new(x.M, x.C)
+        hip.groupnorm_apply(x.t, st, gn[0], gn[1], y, nimg=x.N, hw=x.hw, C_=x.C, ldx=x.ld, ldy=x.C, silu=silu)
+        return Act(y, x.N, x.H, x.W)
+
+    def _conv(self, x: Act, w: dict, out: Optional[torch.Tensor], stride=1, upsample=False, rowbias=None,
+              residual: Optional[torch.Tensor] = None, out_f32=False) -> Act:
+        VH, VW = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
+        OH, OW = (VH - 1) // stride + 1, (VW - 1) // stride + 1
+        if out is None:
+            out = self._new(x.N * OH * OW, w["cout"], torch.float32 if out_f32 else None)
+        assert x.C == w["cinp"], (x.C, w["cinp"])
+        hip.conv3x3(x.t, w["w"], out, nimg=x.N, H=x.H, W=x.W, cin=w["cinp"], cout=w["cout"], ldx=x.ld,
+                    ldy=out.stride(0), stride=stride, upsample=upsample, bias=w["b"], rowbias=rowbias,
+                    residual=residual, ldr=residual.stride(0) if residual is not None else 0,
+                    flags=hip.EPI_OUT_F32 if out_f32 else 0)
+        return Act(out, x.N, OH, OW)
+
+    def _res(self, x: Act, p: dict, emb_all: torch.Tensor, out: Optional[torch.Tensor]) -> Act:
+        """ResBlock._forward (openaimodel.py:255-275), non-updown, no scale-shift."""
+        h = self._gn(x, p["in_gn"], 1e-5, True)
+        a, b = p["emb_slice"]
+        h = self._conv(h, p["conv1"], None, rowbias=emb_all[:, a:b])
+        h = self._gn(h, p["out_gn"], 1e-5, True)
+        if "skip" in p:
+            skip = self._new(x.M, p["conv2"]["cout"])
+            self._gemm(x.t, p["skip"], skip)
+        else:
+            skip = x.t
+        return self._conv(h, p["conv2"], out, residual=skip)
+
+    def _attn1(self, xln: torch.Tensor, resid: torch.Tensor, p: dict, cfg: Optional[HookCfg], a2vec: torch.Tensor,
+               N: int, n: int, heads: int, hw) -> torch.Tensor:
+        d = p["c"]
+        out = self._new(N * n, d)
+        pl = plan_fusion(cfg, N, n)
+        fusion, chunks, flow, alpha, v_fixed = pl["fusion"], pl["chunks"], pl["flow"], pl["alpha"], pl["v_fixed"]
+        wlin = self._wlin(p, *pl["wlin"]) if pl["wlin"] else None
+        qk_map = self._map("qk_replace", N, N // chunks) if fusion == hip.FUSION_REPLACE else None
+        v_map = self._map("v_fixed", N, N // chunks) if v_fixed else None
+        ws = torch.empty(hip.attn1_workspace_bytes(N, n, d, chunks), dtype=torch.uint8, device=self.device)
+        if flow is not None and self.halo_exchange is not None:
+            return self._attn1_sharded(xln, resid, p, wlin, a2vec, N, n, heads, flow, alpha, out)
+        hip.attn1_forward(xln, p["wqkv"], wlin, p["wo"]["w"], p["wo"]["b"], out, B=N, n=n, d=d, heads=heads,
+                          chunks=chunks, fusion=fusion, ldx=xln.stride(0), ldo=d, workspace=ws,
+                          rowbias=a2vec, residual=resid, ldr=resid.stride(0), v_fixed=v_fixed, flow=flow,
+                          h=flow.shape[-2] if flow is not None else 0, w=flow.shape[-1] if flow is not None else 0,
+                          alpha=alpha, qk_map=qk_map, v_map=v_map)
+        return out
+
+    def _attn1_sharded(self, xln, resid, p, wlin, a2vec, N, n, heads, flow, alpha, out):
+        """flow_fix with frames sharded across ranks: the same kernels as vface_attn1_forward, sequenced here
+        so the one-neighbour boundary exchange sits between the fused projection and the warp."""
+        d = p["c"]
+        F_ = N // 3
+        Fn = F_ * n
+        qkv = self._new(N * n, 3 * d)
+        T = self._new(Fn, 2 * d)
+        hip.gemm(xln, p["wqkv"], qkv, M=Fn, N=3 * d, K=d, lda=xln.stride(0), ldc=3 * d)
+        hip.gemm(xln[Fn:], p["wqkv"][2 * d:], qkv[Fn:, 2 * d:], M=N * n - Fn, N=d, K=d, lda=xln.stride(0), ldc=3 * d)
+        for c in (1, 2):
+            dst = T if c == 1 else qkv[2 * Fn:, :2 * d]
+            hip.gemm(xln[c * Fn:], wlin, dst, M=Fn, N=2 * d, K=2 * d, lda=xln.stride(0), ldc=dst.stride(0), ldw=2 * d,
+                     a2=xln, lda2=xln.stride(0), k1=d)
+        halo = self.halo_exchange(T[(F_ - 1) * n:])  # my last frame's fused q|k -> next rank; get previous rank's
+        dst = qkv[Fn:2 * Fn, :2 * d]
+        hip.flow_warp(T, dst, flow, F=F_, h=flow.shape[-2], w=flow.shape[-1], C_=2 * d, ld_src=2 * d, fs_src=n * 2 * d,
+                      ld_dst=3 * d, fs_dst=n * 3 * d, alpha=alpha, prev=halo, ld_prev=2 * d,
+                      flow_prev=self.halo_flow if halo is not None else None)
+        att = self._new(N * n, d)
+        hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=N, heads=heads, n=n, nk=n, dh=d // heads, ldq=3 * d,
+                      ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d, ldo=d, bso=n * d,
+                      scale=(d // heads) ** -0.5)
+        hip.gemm(att, p["wo"]["w"], out, M=N * n, N=d, K=d, lda=d, ldc=d, bias=p["wo"]["b"], rowbias=a2vec,
+                 rows_per_sample=n, residual=resid, ldr=resid.stride(0))
+        return out
+
+    def _st(self, x: Act, p: dict, mod, a2_all: torch.Tensor, out: Optional[torch.Tensor]) -> Act:
+        """SpatialTransformer.forward + BasicTransformerBlock._forward (attention.py:278-289, 239-243)."""
+        N, n, c = x.N, x.hw, p["c"]
+        g = self._gn(x, p["gn"], 1e-6, False)
+        t0 = self._new(x.M, c)
+        self._gemm(g.t, p["proj_in"], t0)
+        ln = self._new(x.M, c)
+        hip.layernorm(t0, p["ln1"][0], p["ln1"][1], ln, M=x.M, C_=c, ldx=c, ldy=c)
+        a, b = p["a2_slice"]
+        attn1 = mod.transformer_blocks[0].attn1
+        cfg = getattr(attn1, "_vface_cfg", None)
+        fw = attn1.__dict__.get("forward")
+        if fw is not None and not getattr(fw, "_vface", False):
+            raise hip.VFaceHipError("attn1.forward was replaced by a closure this engine does not know; use "
+                                    "vface_amd.ldm.models.pnp_utils.register_spa_attn_injection")
+        t1 = self._attn1(ln, t0, p, cfg, a2_all[:, a:b], N, n, attn1.heads, (x.H, x.W))
+        hip.layernorm(t1, p["ln3"][0], p["ln3"][1], ln, M=x.M, C_=c, ldx=c, ldy=c)
+        ff = self._new(x.M, 4 * c)
+        hip.gemm(ln, p["ff1"]["w"], ff, M=x.M, N=8 * c, K=c, lda=c, ldc=4 * c, bias=p["ff1"]["b"], flags=hip.EPI_GEGLU)
+        t2 = self._new(x.M, c)
+        self._gemm(ff, p["ff2"], t2, residual=t1, ldr=c)
+        if out is None:
+            out = self._new(x.M, c)
+        self._gemm(t2, p["proj_out"], out, residual=x.t, ldr=x.ld)
+        return Act(out, x.N, x.H, x.W)
+
+    # ------------------------------------------------------------------ the forward
+    def embeddings(self, timesteps: torch.Tensor, context: torch.Tensor):
+        """time_embed -> every ResBlock's emb_layers (openaimodel.py:874-875,264-271), and every attn2's
+        ``to_out(to_v(ctx))``, as fp32 row-bias matrices."""
+        P, N = self._packed, timesteps.shape[0]
+        mc = self.unet.model_channels
+        temb = self._new(N, mc)
+        hip.timestep_embedding(timesteps.to(device=self.device, dtype=torch.int64).contiguous(), temb, mc)
+        e0 = self._new(N, 4 * mc)
+        self._gemm(temb, P["time_embed.0"], e0)
+        hip.silu(e0, e0)
+        emb = self._new(N, 4 * mc)
+        self._gemm(e0, P["time_embed.2"], emb)
+        hip.silu(emb, emb)
+        emb_all = self._new(N, P["emb_all"]["n"], torch.float32)
+        self._gemm(emb, P["emb_all"], emb_all, flags=hip.EPI_OUT_F32)
+        ctx = context.reshape(N, -1)
+        if ctx.shape[1] != self.unet.context_dim:
+            raise hip.VFaceHipError(f"context must be [N, 1, {self.unet.context_dim}] (single token, SURVEY F11); "
+                                    f"got {tuple(context.shape)}")
+        ctx16 = self._new(N, ctx.shape[1])
+        hip.cast_f32(ctx.to(device=self.device, dtype=torch.float32).contiguous(), ctx16)
+        v_all = self._new(N, P["a2_v_all"]["n"])
+        self._gemm(ctx16, {"w": P["a2_v_all"]["w"]}, v_all)
+        a2_all = self._new(N, P["a2_v_all"]["n"], torch.float32)
+        for kind, prefix, _ in self.unet.layer_table():
+            if kind == "st":
+                a, b = P[prefix]["a2_slice"]
+                self._gemm(v_all[:, a:b], P[prefix]["a2_out"], a2_all[:, a:b], flags=hip.EPI_OUT_F32)
+        return emb_all, a2_all
+
+    def forward_nhwc(self, x: Act, timesteps: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+        """UNetModel.forward (openaimodel.py:860-907) on an NHWC 16-bit input (channels padded to 8k).
+        Returns eps as fp32 NHWC ``[N*H*W, out_channels]``."""
+        self._ensure_packed()
+        P, u = self._packed, self.unet
+        emb_all, a2_all = self.embeddings(timesteps, context)
+        blocks_in, mid, blocks_out = u.block_table()
+
+        def run(block, h: Act, out: Optional[torch.Tensor]) -> Act:
+            for i, (kind, prefix, mod) in enumerate(block):
+                tgt = out if i == len(block) - 1 else None
+                if kind == "conv":
+                    h = self._conv(h, P[prefix], tgt)
+                elif kind == "res":
+                    h = self._res(h, P[prefix], emb_all, tgt)
+                elif kind == "st":
+                    h = self._st(h, P[prefix], mod, a2_all, tgt)
+                elif kind == "down":
+                    h = self._conv(h, P[prefix], tgt, stride=2)
+                elif kind == "up":
+                    h = self._conv(h, P[prefix], tgt, upsample=True)
+            return h
+
+        # geometry pass: output shape of every input block, to size the concat buffers
+        shapes = []
+        H, W = x.H, x.W
+        for block in blocks_in:
+            for kind, prefix, _ in block:
+                if kind == "down":
+                    H, W = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+            shapes.append((H, W, u.block_out_channels(block)))
+        nb = len(blocks_in)
+        h_ch = [u.block_out_channels(mid)] + [u.block_out_channels(b) for b in blocks_out[:-1]]
+        cats = []
+        for j in range(nb):  # output block j consumes cat([h_{j}, skip_{nb-1-j}])
+            sh, sw, sc = shapes[nb - 1 - j]
+            cats.append(self._new(x.N * sh * sw, h_ch[j] + sc))
+        h = x
+        for i, block in enumerate(blocks_in):
+            j = nb - 1 - i
+            h = run(block, h, cats[j][:, h_ch[j]:])
+        h = run(mid, h, cats[0][:, :h_ch[0]])
+        for j, block in enumerate(blocks_out):
+            sh, sw, _ = shapes[nb - 1 - j]
+            inp = Act(cats[j], x.N, sh, sw)
+            tgt = cats[j + 1][:, :h_ch[j + 1]] if j + 1 < nb else None
+            h = run(block, inp, tgt)
+        h = self._gn(h, P["out.gn"], 1e-5, True)
+        return self._conv(h, P["out.conv"], None, out_f32=True).t
+
+    def forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+        """NCHW fp32 in, NCHW fp32 out -- the signature of the reference's ``UNetModel.forward``."""
+        if not x.is_cuda:
+            raise hip.VFaceHipError("UNetModel.forward needs CUDA tensors: the VFace path has no CPU fallback")
+        N, C, H, W = x.shape
+        cpad = (C + 7) // 8 * 8
+        xin = self._new(N * H * W, cpad)
+        hip.nchw_to_nhwc(x.float().contiguous(), xin, N=N, C_=C, hw=H * W, cpad=cpad)
+        eps = self.forward_nhwc(Act(xin, N, H, W), timesteps, context)
+        out = torch.empty(N, eps.shape[1], H, W, dtype=torch.float32, device=x.device)
+        hip.nhwc_to_nchw_f32(eps, out, N=N, C_=eps.shape[1], hw=H * W, ldx=eps.stride(0))
+        return out

@@ -48,7 +48,7 @@ SIGNATURES = {
     "vface_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vface_nhwc_to_nchw_f32": (C.c_int, [_vp, _i64, _vp, _i32, _i32, _i32, _vp]),
     "vface_ddim_step": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _f32, _f32, _f32, _f32,
-                                  _vp, _vp]),
+                                  _vp, _i32, _vp]),
     "vface_copy2d": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
 }
 
@@ -123,7 +123,7 @@ def gemm(a: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     """out[M, :N] = a[M, :K] @ wt[:N, :K]^T (+ epilogue).  Tensors are device buffers; M/N/K/ld* describe the view."""
     lib = load()
     rc = lib.vface_gemm(_p(a), lda, _p(a2), lda2, k1, a2_row_mod, _p(wt), ldw if ldw is not None else K, M, N, K,
-                        _p(bias), _p(rowbias), rows_per_sample, rowbias.shape[-1] if rowbias is not None else 0,
+                        _p(bias), _p(rowbias), rows_per_sample, rowbias.stride(0) if rowbias is not None else 0,
                         _p(residual), ldr, _p(out), ldc, _p(zeros_page(a.device)), flags, dtype_code(a.dtype),
                         _stream())
     _check(rc, "vface_gemm")
@@ -134,7 +134,7 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, 
             ldr: int = 0, flags: int = 0):
     lib = load()
     rc = lib.vface_conv3x3(_p(x), ldx, nimg, H, W, cin, _p(wt), 9 * cin, cout, stride, int(upsample), _p(bias),
-                           _p(rowbias), rowbias.shape[-1] if rowbias is not None else 0, _p(residual), ldr, _p(out),
+                           _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, _p(residual), ldr, _p(out),
                            ldy, _p(zeros_page(x.device)), flags, dtype_code(x.dtype), _stream())
     _check(rc, "vface_conv3x3")
 
@@ -191,7 +191,7 @@ def attn1_forward(x, wqkv, wlin, wo, bo, out, *, B, n, d, heads, chunks, fusion,
                   residual=None, ldr=0, v_fixed=False, flow=None, h=0, w=0, alpha=0.8, cuda_recip_div=False,
                   halo_qk=None, halo_flow=None, tail_qk=None, qk_map=None, v_map=None):
     rc = load().vface_attn1_forward(_p(x), ldx, _p(wqkv), _p(wlin), _p(wo), _p(bo), _p(rowbias),
-                                    rowbias.shape[-1] if rowbias is not None else 0, _p(residual), ldr, _p(out), ldo,
+                                    rowbias.stride(0) if rowbias is not None else 0, _p(residual), ldr, _p(out), ldo,
                                     B, n, d, heads, chunks, fusion, int(v_fixed), _p(flow), h, w, float(alpha),
                                     float(1.0 - alpha), int(cuda_recip_div), _p(halo_qk), _p(halo_flow), _p(tail_qk),
                                     _p(qk_map), _p(v_map), _p(workspace), workspace.numel() * workspace.element_size(),
@@ -233,9 +233,10 @@ def nhwc_to_nchw_f32(x: torch.Tensor, out: torch.Tensor, *, N: int, C_: int, hw:
 
 
 def ddim_step(eps, x, inv, x_prev, *, F, C_, hw, lde, scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, pred_x0=None,
-              x_prev_recon=None, noise=None):
+              x_prev_recon=None, noise=None, single_branch=False):
     rc = load().vface_ddim_step(_p(eps), lde, _p(x), _p(inv), _p(x_prev), _p(pred_x0), _p(x_prev_recon), F, C_, hw,
-                                scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, _p(noise), _stream())
+                                scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, _p(noise), int(single_branch),
+                                _stream())
     _check(rc, "vface_ddim_step")
 
 

@@ -1,0 +1,45 @@
+"""One small invocation of the hot path on cuda:0, checked against the CPU oracle (driver smoke test)."""
+import torch
+
+
+def run(verbose: bool = True) -> float:
+    from oracle import hooks as ohooks
+    from oracle import unet as ounet
+    from vface_amd import hip
+    from vface_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler
+    from vface_amd.ldm.models.pnp_utils import register_spa_attn_injection
+    from vface_amd.utils import synth
+
+    hip.load()
+    dev = "cuda:0"
+    spec = ounet.UNetSpec(model_channels=64)
+    cfg = dict(image_size=32, in_channels=9, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1],
+               num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+               transformer_depth=1, context_dim=768, legacy=False)
+    ldm = LatentDiffusion(cfg)
+    synth.fill_module_(ldm.unet, seed=0)
+    ldm = ldm.to(dev)
+    sampler = DDIMSampler(ldm)
+    F_, h, w = 2, 16, 16
+    x = synth.synth_normal("smoke.x", (3 * F_, 9, h, w))
+    ctx = synth.synth_normal("smoke.ctx", (3 * F_, 1, 768))
+    t = torch.full((3 * F_,), 481, dtype=torch.long)
+    flow = synth.synth_flow(F_ - 1, h, w)
+    register_spa_attn_injection(sampler, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True)
+    register_spa_attn_injection(sampler, 1, switch_on=True, input_blocks=True, middle_block=False, output_blocks=False,
+                                flow=[flow[i][None] for i in range(F_ - 1)], chunks=3, block_indices=list(range(9)),
+                                fusion="flow_fix", split_ratio_fft=0.8, alpha=0.8)
+    got = ldm.apply_model(x.to(dev), t.to(dev), ctx.to(dev)).float().cpu()
+    sd = {k: v.float().cpu() for k, v in ldm.unet.state_dict().items()}
+    names = ounet.attn1_names(spec)
+    reg = {}
+    ohooks.register_spa_attn_injection(reg, names, 1, switch_on=True, input_blocks=True, middle_block=False,
+                                       output_blocks=False, flow=[flow[i][None] for i in range(F_ - 1)], chunks=3,
+                                       block_indices=list(range(9)), fusion="flow_fix")
+    ref = ounet.unet_forward(sd, spec, x, t, ctx, reg)
+    err = float((got - ref).norm() / ref.norm())
+    if verbose:
+        print(f"smoke: hooked UNet (flow_fix) on {torch.cuda.get_device_name(0)}: rel-L2 vs CPU oracle = {err:.3e}")
+    assert err < 5e-3, err
+    return err
