@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Benchmark of the VFace per-frame DDIM denoising hot path on MI355X.
+
+A "step" is ONE DDIM step of the hot path over one batch of synthetic input: pack [uncond ; cond ; recon]
+(3F samples) -> hooked UNet forward -> guidance + x_{t-1} update, for the F frames this rank owns.
+`value` = swapped frames/s for the whole job at 50 DDIM steps per frame = (F * n_gpus) / (50 * s_per_step).
+
+Default workload (N = 1): BASELINE.json configs[1] -- an 8-frame 512x512 clip (latent 64x64), 50-step DDIM
+schedule, structure attention injection only (fusion "replace" on the input-block attn1 modules), synthetic
+latents / conditioning / weights (name-keyed deterministic fill; there are no checkpoints on the GPU box).
+Inputs are resident in HBM when the timed region starts.  With --gpus N every rank runs the same per-GPU
+workload on its own frames (weak scaling); `--fusion flow_fix` adds the FSAI + flow path, whose one-neighbour
+boundary exchange runs over RCCL.
+
+Also reported on the same JSON line:
+  roofline     -- the dominant kernel (implicit-GEMM 3x3 conv): algorithmic FLOPs per launch / mean launch
+                  duration, timed with HIP events on the launch stream inside the timed region, against the
+                  dense 16-bit MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference, pinned to reference-generated
+                  golden vectors) timed on this box's host cores on a bounded sample: F=1 (batch 3) UNet
+                  forwards at 64x64 with the same hook mode, extrapolated to 50 steps per frame.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=8, help="frames per GPU")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--fusion", default="replace", help="replace | fft | flow_fix | none")
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-forwards", type=int, default=2)
+    return ap.parse_args()
+
+
+class ConvTimer:
+    """HIP-event timing of every launch of the dominant kernel inside the timed region."""
+
+    def __init__(self):
+        self.events, self.flops, self.on = [], 0.0, False
+
+    def wrap(self, hip):
+        orig = hip.conv3x3
+        timer = self
+
+        def conv3x3(x, wt, out, *, nimg, H, W, cin, cout, stride=1, upsample=False, **kw):
+            if not timer.on:
+                return orig(x, wt, out, nimg=nimg, H=H, W=W, cin=cin, cout=cout, stride=stride, upsample=upsample, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig(x, wt, out, nimg=nimg, H=H, W=W, cin=cin, cout=cout, stride=stride, upsample=upsample, **kw)
+            e1.record()
+            VH, VW = (2 * H, 2 * W) if upsample else (H, W)
+            OH, OW = (VH - 1) // stride + 1, (VW - 1) // stride + 1
+            timer.events.append((e0, e1))
+            timer.flops += 2.0 * nimg * OH * OW * cout * 9 * cin
+        hip.conv3x3 = conv3x3
+
+    def summary(self):
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        n = len(self.events)
+        return n, ms, self.flops
+
+
+def cpu_baseline(fusion, n_forwards, ddim_steps):
+    """Oracle (kind 'port') timed on the host cores: F=1, 64x64, full-size UNet, same hook mode."""
+    from oracle import hooks as ohooks
+    from oracle import unet as ounet
+    from vface_amd.utils import synth
+    torch.set_num_threads(os.cpu_count() or 1)
+    spec = ounet.UNetSpec()
+    sd = synth.synth_state_dict(ounet.param_shapes(spec), seed=0)
+    x = synth.synth_normal("bench.cpu.x", (3, 9, 64, 64))
+    ctx = synth.synth_normal("bench.cpu.ctx", (3, 1, 768))
+    t = torch.full((3,), 481, dtype=torch.long)
+    reg = {}
+    if fusion != "none":
+        ohooks.register_spa_attn_injection(reg, ounet.attn1_names(spec), 1, switch_on=True, input_blocks=True,
+                                           middle_block=False, output_blocks=False, chunks=3,
+                                           block_indices=list(range(9)), fusion=fusion)
+    with torch.no_grad():
+        ounet.unet_forward(sd, spec, x, t, ctx, reg)  # warm-up
+        t0 = time.time()
+        for _ in range(n_forwards):
+            ounet.unet_forward(sd, spec, x, t, ctx, reg)
+        dt = (time.time() - t0) / n_forwards
+    return {"value": 1.0 / (ddim_steps * dt), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_forwards} timed hooked-UNet forwards (+1 warm-up) of the CPU oracle, F=1 (batch 3), 64x64 "
+                      f"latent, fp32, fusion={fusion}; {dt:.2f} s per forward, x{ddim_steps} steps per frame"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback on the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    from vface_amd import hip
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler, HookPlan
+    from vface_amd.ldm.models.diffusion.ddpm import FFHQ_UNET_CONFIG, LatentDiffusion
+    from vface_amd.parallel import FrameShard
+    from vface_amd.utils import synth
+
+    hip.load()
+    timer = ConvTimer()
+    timer.wrap(hip)
+    dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
+    F_, h = a.frames, a.res // 8
+    ldm = LatentDiffusion(dict(FFHQ_UNET_CONFIG, compute_dtype=dt))
+    synth.fill_module_(ldm.unet, seed=0)
+    ldm = ldm.to(dev)
+    sampler = DDIMSampler(ldm)
+    sampler.hook_plan = HookPlan(fusion=a.fusion, enabled=a.fusion != "none")
+    shard = FrameShard(rank, world, F_ * world, dist)
+    g0 = shard.first  # global index of this rank's first frame
+    tag = lambda s, f: f"bench.{s}.{g0 + f}"
+    stack = lambda s, shape: torch.stack([synth.synth_normal(tag(s, f), shape) for f in range(F_)]).to(dev)
+    x_T = stack("xT", (4, h, h))
+    c, uc, tc = stack("c", (1, 768)), stack("uc", (1, 768)), stack("tc", (1, 768))
+    inp = stack("inp", (4, h, h)) * 0.18215
+    mask = synth.synth_mask(F_, h, h).to(dev)
+    sampler.make_schedule(a.ddim_steps, ddim_eta=0.0, verbose=False)
+    steps = [int(s) for s in sampler.ddim_timesteps[::-1]]
+    inv = {s: stack(f"inv{s}", (4, h, h)) for s in steps}  # device-resident recon latents
+    flow = None
+    if a.fusion == "flow_fix":
+        gflow = synth.synth_flow(F_ * world - 1, h, h)  # one field per consecutive global frame pair
+        flow = shard.local_flow(gflow).to(dev)
+        shard.install(ldm.unet.engine, gflow, dev)
+    kw = {"inpaint_image": inp, "inpaint_mask": mask}
+
+    def one_step(img, i):
+        s = steps[i % len(steps)]
+        sampler._register_step_hooks(flow)
+        ts = torch.full((F_,), s, device=dev, dtype=torch.long)
+        img, _ = sampler.p_sample_ddim_with_inverse(img, c, ts, index=len(steps) - 1 - (i % len(steps)),
+                                                    target_conditioning=tc, inverse_results_dir=inv,
+                                                    unconditional_guidance_scale=3.0, flow=flow,
+                                                    unconditional_conditioning=uc, test_model_kwargs=kw)
+        return img
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        img = x_T
+        for i in range(a.warmup):
+            img = one_step(img, i)
+        img = x_T
+        fence()
+        timer.on = True
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            img = one_step(img, i)
+        fence()
+        el = time.perf_counter() - t0
+        timer.on = False
+    assert torch.isfinite(img).all(), "non-finite latents"
+    if dist is not None:
+        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    ms_step = el / a.steps * 1e3
+    fps = (F_ * world) / (a.ddim_steps * ms_step / 1e3)
+    n_launch, conv_ms, conv_flops = timer.summary()
+    out = None
+    if rank == 0:
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        unet_tflops = 3 * F_ * 796.94e9 / (ms_step * 1e-3) / 1e12 if h == 64 else None
+        out = {
+            "metric": "swapped frames/sec at 512x512, 50-step DDIM", "value": fps, "unit": "frames/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if a.dtype == "fp16" else "bf16",
+            "data": "synthetic",
+            "config": {"workload": f"{F_}-frame {a.res}x{a.res} clip per GPU, {a.ddim_steps}-step DDIM, hooked REFace "
+                                   f"UNet (859.5M params), attn1 fusion={a.fusion} on input blocks, CFG scale 3.0, "
+                                   f"batch [uncond;cond;recon] = {3 * F_} samples per step",
+                       "frames_per_gpu": F_, "latent": [h, h], "fusion": a.fusion,
+                       "unet_algorithmic_tflops_per_gpu": unet_tflops},
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<MODE_CONV> (implicit-GEMM 3x3 conv)",
+                         "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "launches": n_launch, "mean_launch_us": conv_ms * 1e3 / max(n_launch, 1),
+                         "share_of_step_time": conv_ms / (el * 1e3)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.fusion, a.cpu_forwards, a.ddim_steps)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

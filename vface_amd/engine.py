@@ -179,8 +179,8 @@ class UNetEngine:
         self._packed: Dict[str, dict] = {}
         self._maps: Dict[tuple, torch.Tensor] = {}
         self._version = None
-        # multi-GPU: callable(tail [n, 2d]) -> (halo [n, 2d] or None); installed by parallel.FrameShard
-        self.halo_exchange: Optional[Callable] = None
+        # multi-GPU: a parallel.FrameShard (start_exchange / finish_exchange), installed by FrameShard.install
+        self.halo_exchange = None
         self.halo_flow: Optional[torch.Tensor] = None  # flow from the previous rank's last frame into our frame 0
         hip.load()
 
@@ -357,13 +357,18 @@ class UNetEngine:
         Fn = F_ * n
         qkv = self._new(N * n, 3 * d)
         T = self._new(Fn, 2 * d)
-        hip.gemm(xln, p["wqkv"], qkv, M=Fn, N=3 * d, K=d, lda=xln.stride(0), ldc=3 * d)
-        hip.gemm(xln[Fn:], p["wqkv"][2 * d:], qkv[Fn:, 2 * d:], M=N * n - Fn, N=d, K=d, lda=xln.stride(0), ldc=3 * d)
-        for c in (1, 2):
-            dst = T if c == 1 else qkv[2 * Fn:, :2 * d]
+        def fused(c, dst):
             hip.gemm(xln[c * Fn:], wlin, dst, M=Fn, N=2 * d, K=2 * d, lda=xln.stride(0), ldc=dst.stride(0), ldw=2 * d,
                      a2=xln, lda2=xln.stride(0), k1=d)
-        halo = self.halo_exchange(T[(F_ - 1) * n:])  # my last frame's fused q|k -> next rank; get previous rank's
+
+        fused(1, T)
+        # my last frame's fused q|k goes to the next rank; the previous rank's arrives while chunk 0 / chunk 2 /
+        # the v projections below are computed
+        handle = self.halo_exchange.start_exchange(T[(F_ - 1) * n:])
+        hip.gemm(xln, p["wqkv"], qkv, M=Fn, N=3 * d, K=d, lda=xln.stride(0), ldc=3 * d)
+        hip.gemm(xln[Fn:], p["wqkv"][2 * d:], qkv[Fn:, 2 * d:], M=N * n - Fn, N=d, K=d, lda=xln.stride(0), ldc=3 * d)
+        fused(2, qkv[2 * Fn:, :2 * d])
+        halo = self.halo_exchange.finish_exchange(handle)
         dst = qkv[Fn:2 * Fn, :2 * d]
         hip.flow_warp(T, dst, flow, F=F_, h=flow.shape[-2], w=flow.shape[-1], C_=2 * d, ld_src=2 * d, fs_src=n * 2 * d,
                       ld_dst=3 * d, fs_dst=n * 3 * d, alpha=alpha, prev=halo, ld_prev=2 * d,

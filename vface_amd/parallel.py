@@ -1,0 +1,82 @@
+"""Frame sharding of a clip across the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+The hot path shards by frame: every rank runs the full 3-way batch for a contiguous range of frames.  FSAI and
+structure injection have no cross-frame dependency; flow-guided smoothing reads exactly one
+neighbour (F9): rank r needs rank r-1's LAST frame's fused q|k of chunk 1 at the level-0 hooked layers.  That is
+the only exchange step on the path, and the only collective this module issues: per hooked level-0 layer and
+DDIM step, a ``[n, 2d]`` 16-bit slab (2.6 MB at 512x512) moves one hop down the chain -- point-to-point
+``isend/irecv`` (xGMI is point-to-point, so a one-hop shift costs one link transfer), or an all-gather of the
+slabs when ``mode="allgather"``.  The transfer is started right after chunk 1's fused projection and waited for
+just before the warp, so it overlaps chunk 2's projection (see ``UNetEngine._attn1_sharded``).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+
+def frame_range(rank: int, world: int, total: int):
+    """Contiguous split of ``total`` frames; the first ``total % world`` ranks get one extra."""
+    base, extra = divmod(total, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+class FrameShard:
+    def __init__(self, rank: int, world: int, total_frames: int, dist=None, mode: str = "p2p"):
+        self.rank, self.world, self.total = rank, world, total_frames
+        self.first, self.count = frame_range(rank, world, total_frames)
+        self.dist = dist
+        self.mode = mode
+        if world > 1 and dist is None:
+            raise ValueError("world_size > 1 needs torch.distributed")
+
+    # ---- flow bookkeeping: global flow[i] maps frame i -> frame i+1 (temporal_flow.py:163-188, F-1 fields)
+    def local_flow(self, global_flow: torch.Tensor) -> torch.Tensor:
+        """Fields between consecutive frames INSIDE this shard: ``[count-1, 2, h, w]``."""
+        return global_flow[self.first:self.first + self.count - 1]
+
+    def halo_flow(self, global_flow: torch.Tensor) -> Optional[torch.Tensor]:
+        """The field from the previous rank's last frame into this shard's first frame, or None on rank 0."""
+        if self.first == 0:
+            return None
+        return global_flow[self.first - 1]
+
+    # ---- the boundary exchange
+    def start_exchange(self, tail: torch.Tensor):
+        """Send this shard's last-frame slab to rank+1 and start receiving rank-1's.  Returns a handle."""
+        if self.world == 1:
+            return None
+        d = self.dist
+        if self.mode == "allgather":
+            t = tail.contiguous()
+            bufs = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            work = d.all_gather_into_tensor(bufs, t, async_op=True)  # rank r's slab = rows [r*n, (r+1)*n)
+            return ("ag", work, bufs.view((self.world,) + tuple(t.shape)))
+        ops, halo = [], None
+        if self.rank + 1 < self.world:
+            ops.append(d.P2POp(d.isend, tail.contiguous(), self.rank + 1))
+        if self.rank > 0:
+            halo = torch.empty_like(tail)
+            ops.append(d.P2POp(d.irecv, halo, self.rank - 1))
+        works = d.batch_isend_irecv(ops) if ops else []
+        return ("p2p", works, halo)
+
+    def finish_exchange(self, handle) -> Optional[torch.Tensor]:
+        """Wait for the transfer; returns the previous rank's slab (None on rank 0 / single rank)."""
+        if handle is None:
+            return None
+        kind, work, buf = handle
+        if kind == "ag":
+            work.wait()
+            return buf[self.rank - 1] if self.rank > 0 else None
+        for w in work:
+            w.wait()
+        return buf
+
+    def install(self, engine, global_flow: torch.Tensor, device) -> None:
+        """Hook the exchange into a ``UNetEngine`` (used by flow_fix layers only)."""
+        hf = self.halo_flow(global_flow)
+        engine.halo_flow = hf.to(device=device, dtype=torch.float32).contiguous() if hf is not None else None
+        engine.halo_exchange = self if self.world > 1 else None
