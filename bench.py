@@ -34,6 +34,11 @@ import torch  # noqa: E402
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 
 
+def log(msg):
+    if int(os.environ.get("RANK", 0)) == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,7 +88,10 @@ def cpu_baseline(fusion, n_forwards, ddim_steps):
     from oracle import hooks as ohooks
     from oracle import unet as ounet
     from vface_amd.utils import synth
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one GPU's share of the host (16 cores); never oversubscribe beyond the affinity mask
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    log(f"cpu_baseline: oracle on {cores} threads ...")
     spec = ounet.UNetSpec()
     sd = synth.synth_state_dict(ounet.param_shapes(spec), seed=0)
     x = synth.synth_normal("bench.cpu.x", (3, 9, 64, 64))
@@ -95,7 +103,9 @@ def cpu_baseline(fusion, n_forwards, ddim_steps):
                                            middle_block=False, output_blocks=False, chunks=3,
                                            block_indices=list(range(9)), fusion=fusion)
     with torch.no_grad():
+        t0 = time.time()
         ounet.unet_forward(sd, spec, x, t, ctx, reg)  # warm-up
+        log(f"cpu_baseline: warm-up forward {time.time() - t0:.1f} s")
         t0 = time.time()
         for _ in range(n_forwards):
             ounet.unet_forward(sd, spec, x, t, ctx, reg)
@@ -126,6 +136,7 @@ def main():
     from vface_amd.utils import synth
 
     hip.load()
+    log(f"building the 859.5M-parameter UNet with synthetic weights (rank {rank}/{world}) ...")
     timer = ConvTimer()
     timer.wrap(hip)
     dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
@@ -169,6 +180,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    log("weights resident; warm-up ...")
     with torch.no_grad():
         img = x_T
         for i in range(a.warmup):
@@ -188,6 +200,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     ms_step = el / a.steps * 1e3
+    log(f"timed {a.steps} steps: {ms_step:.2f} ms/step")
     fps = (F_ * world) / (a.ddim_steps * ms_step / 1e3)
     n_launch, conv_ms, conv_flops = timer.summary()
     out = None
