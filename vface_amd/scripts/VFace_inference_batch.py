@@ -1,0 +1,159 @@
+"""Entry point of the VFace path with the reference's flags (``REFace/scripts/VFace_inference_batch.py:673-860``).
+
+What runs here is the part of ``run_inference`` that is the hot path (``:529-594``): optional DDIM inversion of
+the target latents into a latent cache, then ``sampler.sample`` over batches of ``--n_samples`` frames with the
+shipped hook schedule.  Everything around it in the reference -- video decoding, dlib crop/align, face parsing,
+CLIP/ArcFace/landmark conditioning, the KL-VAE and paste-back (``:193-528, 596-670``) -- is out of scope of this
+build: it needs checkpoints and third-party models that are not available offline.  ``--synthetic``
+therefore stands in for those stages with seeded synthetic latents / conditioning / flow of the right shapes and
+writes the denoised latents; without it the script stops with a message saying what is missing.
+
+    python -m vface_amd.scripts.VFace_inference_batch --synthetic --n_frames 24 --n_samples 8 --ddim_steps 50
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+
+def build_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser()
+    # flags of the reference (same names, defaults and meaning)
+    p.add_argument("--prompt", type=str, nargs="?", default="a photograph of an astronaut riding a horse")
+    p.add_argument("--data_config", type=str, nargs="?", default=None, help="yaml of (video dir, source image) pairs")
+    p.add_argument("--Base_dir", type=str, nargs="?", default="results_video_new", help="dir to write results to")
+    p.add_argument("--skip_grid", action="store_true")
+    p.add_argument("--skip_save", action="store_true")
+    p.add_argument("--ddim_steps", type=int, default=50, help="number of ddim sampling steps")
+    p.add_argument("--plms", action="store_true")
+    p.add_argument("--laion400m", action="store_true")
+    p.add_argument("--fixed_code", action="store_true")
+    p.add_argument("--Start_from_target", action="store_true", default=True)
+    p.add_argument("--only_target_crop", action="store_true", default=True)
+    p.add_argument("--target_start_noise_t", type=int, default=1000)
+    p.add_argument("--ddim_eta", type=float, default=0.0)
+    p.add_argument("--n_iter", type=int, default=2)
+    p.add_argument("--H", type=int, default=512)
+    p.add_argument("--W", type=int, default=512)
+    p.add_argument("--C", type=int, default=4, help="latent channels")
+    p.add_argument("--f", type=int, default=8, help="downsampling factor")
+    p.add_argument("--n_samples", type=int, default=6, help="frames per sampler batch")
+    p.add_argument("--n_frames", type=int, default=24)
+    p.add_argument("--n_rows", type=int, default=0)
+    p.add_argument("--scale", type=float, default=3.0, help="unconditional guidance scale")
+    p.add_argument("--src_image_mask", type=str, default=None)
+    p.add_argument("--from-file", type=str, default=None)
+    p.add_argument("--config", type=str, default=None, help="project_ffhq.yaml (UNet hyper-parameters)")
+    p.add_argument("--ckpt", type=str, default=None, help="last.ckpt; its model.diffusion_model.* keys are loaded")
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--rank", type=int, default=0)
+    p.add_argument("--precision", type=str, choices=["full", "autocast"], default="autocast")
+    # additions of this build
+    p.add_argument("--synthetic", action="store_true", help="synthetic latents/conditioning/flow instead of video I/O")
+    p.add_argument("--fusion", type=str, default="flow_fix", help="hook mode on the input-block attn1 modules")
+    p.add_argument("--no_inversion", action="store_true", help="use random recon latents instead of DDIM inversion")
+    p.add_argument("--compute_dtype", choices=["fp16", "bf16"], default="fp16")
+    p.add_argument("--max_steps", type=int, default=None, help="stop after this many DDIM steps (smoke runs)")
+    return p
+
+
+def load_unet_config(path):
+    from ..ldm.models.diffusion.ddpm import FFHQ_UNET_CONFIG
+    if path is None:
+        return dict(FFHQ_UNET_CONFIG)
+    import yaml
+    with open(path) as f:
+        cfg = yaml.safe_load(f)
+    return dict(cfg["model"]["params"]["unet_config"]["params"])
+
+
+def run_synthetic(opt) -> dict:
+    from ..ldm.models.diffusion.ddim_w_inv import DDIMSampler, HookPlan
+    from ..ldm.models.diffusion.ddpm import LatentDiffusion
+    from ..utils import synth
+
+    dev = torch.device("cuda", 0)
+    dt = torch.float16 if opt.compute_dtype == "fp16" else torch.bfloat16
+    cfg = load_unet_config(opt.config)
+    cfg["compute_dtype"] = dt
+    model = LatentDiffusion(cfg)
+    if opt.ckpt:
+        sd = torch.load(opt.ckpt, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        missing, unexpected = model.load_state_dict(
+            {k: v for k, v in sd.items() if k.startswith("model.diffusion_model.")}, strict=False)
+        print(f"loaded {opt.ckpt}: {len(missing)} missing, {len(unexpected)} unexpected keys")
+    else:
+        synth.fill_module_(model.unet, seed=0)
+    model = model.to(dev).eval()
+    sampler = DDIMSampler(model)
+    sampler.hook_plan = HookPlan(fusion=opt.fusion, enabled=opt.fusion != "none")
+    h, w = opt.H // opt.f, opt.W // opt.f
+    F_ = opt.n_samples
+    os.makedirs(opt.Base_dir, exist_ok=True)
+    results, t_all = [], time.time()
+    for batch_id in range(opt.n_frames // F_):  # DataLoader(batch_size=n_samples, drop_last=True) (:376-382)
+        tag = lambda s: f"cli.{s}.{batch_id}"
+        d = lambda t: t.to(dev)
+        c, uc, tc = (d(synth.synth_normal(tag(k), (F_, 1, 768))) for k in ("c", "uc", "tc"))
+        z_inp = d(synth.synth_normal(tag("inp"), (F_, opt.C, h, w)) * 0.18215)
+        mask = d(synth.synth_mask(F_, h, w))
+        flow = [f[None] for f in synth.synth_flow(F_ - 1, h, w, seed=opt.seed + batch_id)]
+        kw = {"inpaint_image": z_inp, "inpaint_mask": mask}
+        inv_store = {}
+        if opt.no_inversion:
+            sampler.make_schedule(opt.ddim_steps, ddim_eta=opt.ddim_eta, verbose=False)
+            for s in sampler.ddim_timesteps:
+                inv_store[int(s)] = d(synth.synth_normal(tag(f"inv{int(s)}"), (F_, opt.C, h, w)))
+        else:
+            # :531-540: invert [target ; source] (2F), hooks off; the target half is cached per timestep
+            z2 = d(synth.synth_normal(tag("z2"), (2 * F_, opt.C, h, w)))
+            kw2 = {"inpaint_image": torch.cat([z_inp, z_inp]), "inpaint_mask": torch.cat([mask, mask])}
+            sampler.ddim_invert(x=z2, cond=torch.cat([tc, c]), S=opt.ddim_steps, shape=[opt.C, h, w], eta=opt.ddim_eta,
+                                unconditional_guidance_scale=opt.scale, unconditional_conditioning=None,
+                                inverse_dir=inv_store, batch_size=F_, test_model_kwargs=kw2, max_steps=opt.max_steps)
+        # :541 start code = the cached latent of the second-highest timestep ("ddim_latents_961.pt" at 50 steps)
+        sampler.make_schedule(opt.ddim_steps, ddim_eta=opt.ddim_eta, verbose=False)
+        ts = [int(s) for s in sampler.ddim_timesteps]
+        start_t = ts[-2] if ts[-2] in inv_store else max(inv_store)
+        x_T = inv_store[start_t]
+        if opt.max_steps is not None:  # smoke runs: the remaining cache entries are never read
+            for s in ts:
+                inv_store.setdefault(s, x_T)
+        t0 = time.time()
+        samples, _ = sampler.sample(S=opt.ddim_steps, conditioning=c, target_conditioning=tc,
+                                    inverse_results_dir=inv_store, batch_size=F_, shape=[opt.C, h, w], verbose=False,
+                                    unconditional_guidance_scale=opt.scale, unconditional_conditioning=uc,
+                                    eta=opt.ddim_eta, x_T=x_T, flow=flow if opt.fusion == "flow_fix" else None,
+                                    test_model_kwargs=kw, max_steps=opt.max_steps)
+        torch.cuda.synchronize()
+        dt_s = time.time() - t0
+        if not opt.skip_save:
+            torch.save(samples.cpu(), os.path.join(opt.Base_dir, f"samples_batch{batch_id}.pt"))
+        results.append({"batch": batch_id, "frames": F_, "sample_seconds": dt_s,
+                        "finite": bool(torch.isfinite(samples).all())})
+        print(f"batch {batch_id}: {F_} frames sampled in {dt_s:.2f} s")
+    return {"batches": results, "total_seconds": time.time() - t_all}
+
+
+def main(argv=None):
+    opt = build_parser().parse_args(argv)
+    torch.manual_seed(opt.seed)  # seed_everything(42) (:862)
+    if opt.plms:
+        raise NotImplementedError("--plms selects PLMSSampler, which is outside the VFace hot path (SURVEY §2)")
+    if not opt.synthetic:
+        sys.exit("Only the denoising hot path is built here.  Video decoding, dlib/BiSeNet pre-processing, CLIP/ArcFace "
+                 "conditioning, the KL-VAE and paste-back (VFace_inference_batch.py:193-528,596-670) need checkpoints "
+                 "that are not available offline; run with --synthetic, or feed real latents through "
+                 "vface_amd.ldm.models.diffusion.ddim_w_inv.DDIMSampler (see INTEGRATION.md).")
+    if not torch.cuda.is_available():
+        sys.exit("An MI355X is required: the VFace hot path has no CPU fallback.")
+    return run_synthetic(opt)
+
+
+if __name__ == "__main__":
+    main()
