@@ -45,6 +45,7 @@ extern "C" {
 /* epilogue flags of vface_gemm / vface_conv3x3 */
 #define VFACE_EPI_GEGLU 1   /* out[m][c] = (acc_val + b) * gelu(acc_gate + b); Wt rows packed by vface layout */
 #define VFACE_EPI_OUT_F32 2 /* store fp32 instead of the 16-bit type */
+#define VFACE_TUNE_VARIANT(v) ((v) << 8) /* bits 8..11: force GEMM schedule variant v (1..8); 0 = automatic */
 
 /* fusion modes of the attn1 hook (pnp_utils.py:133-262) understood by vface_attn1_forward */
 #define VFACE_FUSION_NONE 0       /* switch_on == False, or unpatched CrossAttention.forward */

@@ -26,19 +26,27 @@ def rnd(shape, seed, dt, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dt)
 
 
+VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7, 8]  # 0 = automatic schedule; 1..8 forced (include/vface_hip.h)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (200, 72, 136), (1000, 320, 320), (24, 1280, 320), (4096, 960, 320)])
-def test_gemm_plain_bias_residual(dt, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (200, 72, 136), (1000, 320, 320), (24, 1280, 320), (4096, 960, 320),
+                                   (700, 160, 1096)])
+def test_gemm_plain_bias_residual(dt, M, N, K, variant):
     h = hip()
+    if variant and dt == torch.bfloat16 and (M, N, K) != (1000, 320, 320):
+        pytest.skip("forced variants: bf16 checked on one shape")
     a, w = rnd((M, K), 1, dt), rnd((N, K), 2, dt, 1 / math.sqrt(K))
     bias = rnd((N,), 3, torch.float32)
     res = rnd((M, N), 4, dt)
     out = torch.empty(M, N, dtype=dt, device=DEV)
-    h.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias.to(DEV), residual=res.to(DEV), ldr=N)
+    h.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, lda=K, ldc=N, bias=bias.to(DEV), residual=res.to(DEV), ldr=N,
+           flags=variant << 8)
     ref = a.float() @ w.float().t() + bias + res.float()
     assert rel_l2(out.cpu().float(), ref) < TOL[dt]
     out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
-    h.gemm(a.to(DEV), w.to(DEV), out32, M=M, N=N, K=K, lda=K, ldc=N, flags=h.EPI_OUT_F32)
+    h.gemm(a.to(DEV), w.to(DEV), out32, M=M, N=N, K=K, lda=K, ldc=N, flags=h.EPI_OUT_F32 | (variant << 8))
     assert rel_l2(out32.cpu(), a.float() @ w.float().t()) < 1e-5
 
 
@@ -61,7 +69,8 @@ def test_gemm_strided_views_rowbias_dual_source():
     assert got[:, :32].abs().max() == 0 and got[:, 32 + N:].abs().max() == 0  # nothing outside the view
 
 
-def test_gemm_geglu():
+@pytest.mark.parametrize("variant", [0, 1, 3, 5, 7])
+def test_gemm_geglu(variant):
     h = hip()
     dt = torch.float16
     M, d = 300, 64
@@ -71,17 +80,22 @@ def test_gemm_geglu():
     from vface_amd.packing import pack_geglu
     wp, bp = pack_geglu(w, b)
     out = torch.empty(M, 4 * d, dtype=dt, device=DEV)
-    h.gemm(x.to(DEV), wp.to(DEV), out, M=M, N=8 * d, K=d, lda=d, ldc=4 * d, bias=bp.to(DEV), flags=h.EPI_GEGLU)
+    h.gemm(x.to(DEV), wp.to(DEV), out, M=M, N=8 * d, K=d, lda=d, ldc=4 * d, bias=bp.to(DEV),
+           flags=h.EPI_GEGLU | (variant << 8))
     y = x.float() @ w.float().t() + b
     val, gate = y.chunk(2, -1)
     assert rel_l2(out.cpu().float(), val * F.gelu(gate)) < 1e-3
 
 
+@pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("cin,cout,H,W,stride,up", [(16, 64, 12, 10, 1, False), (64, 72, 16, 16, 2, False),
-                                                    (64, 64, 8, 8, 1, True), (320, 320, 16, 16, 1, False)])
-def test_conv3x3(dt, cin, cout, H, W, stride, up):
+                                                    (64, 64, 8, 8, 1, True), (320, 320, 16, 16, 1, False),
+                                                    (128, 160, 20, 12, 1, False)])
+def test_conv3x3(dt, cin, cout, H, W, stride, up, variant):
     h = hip()
+    if variant and dt == torch.bfloat16:
+        pytest.skip("forced variants: fp16 only")
     from vface_amd.packing import pack_conv3x3
     nimg = 3
     x = rnd((nimg, cin, H, W), 1, dt)
@@ -96,7 +110,8 @@ def test_conv3x3(dt, cin, cout, H, W, stride, up):
     xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
     out = torch.empty(nimg, OH, OW, cout, dtype=dt, device=DEV)
     h.conv3x3(xn, pack_conv3x3(w).to(DEV), out, nimg=nimg, H=H, W=W, cin=cin, cout=cout, ldx=cin, ldy=cout,
-              stride=stride, upsample=up, bias=b.to(DEV), rowbias=rb.to(DEV), residual=res.to(DEV), ldr=cout)
+              stride=stride, upsample=up, bias=b.to(DEV), rowbias=rb.to(DEV), residual=res.to(DEV), ldr=cout,
+              flags=variant << 8)
     assert rel_l2(out.cpu().float().permute(0, 3, 1, 2), ref) < TOL[dt]
 
 

@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Per-kernel throughput on the MI355X for the shapes the F=8, 512x512 UNet step issues (A/B tuning aid).
+Interleaved rounds in one process (guide rule 24); random data (rule 25)."""
+import argparse
+import math
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vface_amd import hip
+from vface_amd.packing import pack_conv3x3
+
+DEV = "cuda"
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record()
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--what", default="conv,gemm,attn,norm")
+    a = ap.parse_args()
+    hip.load()
+    N = 3 * a.frames
+    dt = torch.float16
+    g = torch.Generator(device="cpu").manual_seed(0)
+    rnd = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dt).to(DEV)
+    variants = {"auto": 0, "db128": 0x500, "db160": 0x600, "db128nox": 0x1500, "db160nox": 0x1600}
+    if "conv" in a.what:
+        print("== conv3x3 implicit GEMM (TFLOP/s median | best), variants:", list(variants))
+        for (H, cin, cout, stride) in [(64, 320, 320, 1), (64, 640, 320, 1), (64, 960, 320, 1), (32, 640, 640, 1),
+                                       (32, 1280, 640, 1), (16, 1280, 1280, 1), (16, 2560, 1280, 1), (8, 1280, 1280, 1),
+                                       (64, 320, 320, 2)]:
+            x = rnd(N * H * H, cin)
+            w = pack_conv3x3((torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))).to(dt).to(DEV)
+            OH = (H - 1) // stride + 1
+            out = torch.empty(N * OH * OH, cout, dtype=dt, device=DEV)
+            b = torch.zeros(cout, device=DEV)
+            fl = 2.0 * N * OH * OH * cout * 9 * cin
+            row = f"H{H:3d} {cin:4d}->{cout:4d} s{stride}: "
+            for name, f in variants.items():
+                med, best = timeit(lambda: hip.conv3x3(x, w, out, nimg=N, H=H, W=H, cin=cin, cout=cout, ldx=cin, ldy=cout,
+                                                       stride=stride, bias=b, flags=f))
+                row += f"{name} {fl / med / 1e9:6.0f}|{fl / best / 1e9:6.0f}  "
+            print(row, flush=True)
+    if "gemm" in a.what:
+        print("== plain GEMM")
+        for (M, Nn, K, name0) in [(N * 4096, 960, 320, "qkv L0"), (N * 4096, 320, 320, "proj L0"), (N * 4096, 2560, 320, "ff1 L0"),
+                                  (N * 4096, 320, 1280, "ff2 L0"), (N * 1024, 1920, 640, "qkv L1"), (N * 1024, 5120, 640, "ff1 L1"),
+                                  (N * 1024, 640, 2560, "ff2 L1"), (N * 256, 3840, 1280, "qkv L2"), (N * 256, 10240, 1280, "ff1 L2"),
+                                  (N * 256, 1280, 5120, "ff2 L2")]:
+            x, w = rnd(M, K), rnd(Nn, K)
+            geglu = name0.startswith("ff1")
+            out = torch.empty(M, Nn // 2 if geglu else Nn, dtype=dt, device=DEV)
+            bias = torch.zeros(Nn, device=DEV)
+            fl = 2.0 * M * Nn * K
+            row = f"{name0:8s} M{M:6d} N{Nn:5d} K{K:5d}: "
+            for name, f in variants.items():
+                if geglu and name in ("db160", "db160nox"):
+                    continue
+                ff = f | (hip.EPI_GEGLU if geglu else 0)
+                med, best = timeit(lambda: hip.gemm(x, w, out, M=M, N=Nn, K=K, lda=K, ldc=out.shape[1], bias=bias, flags=ff))
+                row += f"{name} {fl / med / 1e9:6.0f}|{fl / best / 1e9:6.0f}  "
+            print(row, flush=True)
+    if "attn" in a.what:
+        print("== attention")
+        for (n, dh) in [(4096, 40), (1024, 80), (256, 160), (64, 160)]:
+            d = 8 * dh
+            qkv = rnd(N, n, 3 * d)
+            out = torch.empty(N, n, d, dtype=dt, device=DEV)
+            fl = 4.0 * N * 8 * n * n * dh
+            med, best = timeit(lambda: hip.attention(qkv, qkv[:, :, d:], qkv[:, :, 2 * d:], out, B=N, heads=8, n=n, nk=n, dh=dh,
+                                                     ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d,
+                                                     ldo=d, bso=n * d, scale=dh ** -0.5))
+            print(f"n{n:5d} dh{dh:4d}: {fl / med / 1e9:6.0f}|{fl / best / 1e9:6.0f} TFLOP/s  ({med * 1e3:.0f} us)", flush=True)
+    if "norm" in a.what:
+        print("== GroupNorm / LayerNorm (GB/s of algorithmic bytes)")
+        for (hw, C) in [(4096, 320), (4096, 640), (4096, 960), (1024, 640), (1024, 1920), (256, 1280), (256, 2560), (64, 1280)]:
+            x = rnd(N * hw, C)
+            y = torch.empty_like(x)
+            gm, bt = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+            st = hip.groupnorm_stats(x, nimg=N, hw=hw, C_=C, ldx=C)
+            m1, _ = timeit(lambda: hip.groupnorm_stats(x, nimg=N, hw=hw, C_=C, ldx=C))
+            m2, _ = timeit(lambda: hip.groupnorm_apply(x, st, gm, bt, y, nimg=N, hw=hw, C_=C, ldx=C, ldy=C, silu=True))
+            by = N * hw * C * 2
+            print(f"GN hw{hw:5d} C{C:5d}: stats {by / m1 / 1e6:6.0f} GB/s ({m1 * 1e3:.0f} us)  apply {2 * by / m2 / 1e6:6.0f} GB/s ({m2 * 1e3:.0f} us)", flush=True)
+        for (M, C) in [(N * 4096, 320), (N * 1024, 640), (N * 256, 1280)]:
+            x = rnd(M, C); y = torch.empty_like(x)
+            gm, bt = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+            m, _ = timeit(lambda: hip.layernorm(x, gm, bt, y, M=M, C_=C, ldx=C, ldy=C))
+            print(f"LN M{M:6d} C{C:5d}: {2 * M * C * 2 / m / 1e6:6.0f} GB/s ({m * 1e3:.0f} us)", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -29,12 +29,18 @@ constexpr int v_pitch_bytes(int dvp) {
 }
 
 template <class TT, int DH, int QT>
-__global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
     using V4 = typename TT::v4;
-    constexpr int DKP = round_up(DH, 32), NKS = DKP / 32;
+    // QK^T contraction: NKS steps of 32 (mfma 16x16x32) + one step of 16 (mfma 16x16x16) when DH % 32 is 8 or 16,
+    // so head dim 40 costs 48 instead of 64, and 80 costs exactly 80.
+    constexpr int NKS = DH / 32, TAIL = (DH % 32) ? 1 : 0;
+    static_assert(DH % 32 == 0 || DH % 32 == 8 || DH % 32 == 16, "head dim");
+    constexpr int DKP = NKS * 32 + TAIL * 16;
     constexpr int DVP = round_up(DH, 16), NC = DVP / 16;
+    // spare V column (DVP > DH): filled with ones, so the MFMA that builds O also builds the softmax denominator
+    constexpr bool ONES = DVP > DH;
     constexpr int KROW = DKP + 8;                    // elements
     constexpr int VROW = v_pitch_bytes(DVP) / 2;     // elements
     constexpr int CPR = DH / 8;                      // 16-B chunks per row
@@ -62,9 +68,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
         constexpr int total16 = (2 * KVB * KROW + 2 * KVB * VROW) * 2 / 16;
         for (int i = t; i < total16; i += 256) z[i] = make_uint4(0, 0, 0, 0);
     }
+    if (ONES) {
+        __syncthreads();
+        if (t < 2 * KVB) sV[t * VROW + DH] = (E)1.0f;
+    }
 
     // Q fragments (B operand of S^T = K Q^T): lane (query fr, group fg) holds dh 32*ks + 8*fg .. +7
-    V8 qf[QT][NKS];
+    V8 qf[QT][NKS > 0 ? NKS : 1];
+    V4 qt4[QT];  // tail step: dh 32*NKS + 4*fg .. +3
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int q = q0 + qt * 16 + fr;
@@ -74,9 +85,14 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
             V8 v;
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (E)0.0f;
-            if (q < p.n && d < DH) v = *reinterpret_cast<const V8*>(Qg + (long)q * p.ldq + d);
+            if (q < p.n) v = *reinterpret_cast<const V8*>(Qg + (long)q * p.ldq + d);
             qf[qt][ks] = v;
         }
+        V4 w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (E)0.0f;
+        if (TAIL && q < p.n && NKS * 32 + fg * 4 < DH) w = *reinterpret_cast<const V4*>(Qg + (long)q * p.ldq + NKS * 32 + fg * 4);
+        qt4[qt] = w;
     }
 
     uint4 kreg[SR], vreg[SR];
@@ -144,6 +160,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) s[tl][qt] = TT::mfma32(kf, qf[qt][ks], s[tl][qt]);
             }
+            if (TAIL) {
+                const V4 kf = *reinterpret_cast<const V4*>(cK + (tl * 16 + fr) * KROW + NKS * 32 + fg * 4);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) s[tl][qt] = TT::mfma16(kf, qt4[qt], s[tl][qt]);
+            }
         }
         // ---- online softmax (fp32)
         const bool tail = (kb + 1) * KVB > nk;
@@ -158,26 +179,30 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
                     if (tail && kb * KVB + tl * 16 + fg * 4 + r >= nk) s[tl][qt][r] = -1e30f;
                     mx = fmaxf(mx, s[tl][qt][r]);
                 }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = quad_row_max(mx);
             const float m_new = fmaxf(m_run[qt], mx);
-            const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * cexp);
-            m_run[qt] = m_new;
-            const float mc = m_new * cexp;
+            // the running max rarely moves after the first key blocks: rescale only when some query's did
+            // (alpha == 1 exactly otherwise, so skipping is exact, not an approximation)
+            if (__any(m_new > m_run[qt])) {
+                const float alpha = __builtin_amdgcn_exp2f((m_run[qt] - m_new) * cexp);
+                m_run[qt] = m_new;
+                if (!ONES) l_run[qt] *= alpha;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[c][qt][r] *= alpha;
+            }
+            const float mc = m_run[qt] * cexp;
             float ls = 0.f;
 #pragma unroll
             for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(s[tl][qt][r] * cexp - mc);
+                    const float pv = __builtin_amdgcn_exp2f(fmaf(s[tl][qt][r], cexp, -mc));
                     s[tl][qt][r] = pv;
-                    ls += pv;
+                    if (!ONES) ls += pv;
                 }
-            l_run[qt] = l_run[qt] * alpha + ls;
-#pragma unroll
-            for (int c = 0; c < NC; ++c)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[c][qt][r] *= alpha;
+            if (!ONES) l_run[qt] += ls;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 V8 v;
@@ -212,9 +237,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
     E* Og = reinterpret_cast<E*>(p.O) + (long)b * p.bso + h * DH;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        float l = l_run[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        float l;
+        if (ONES) {
+            // the denominator is row DH of O^T: held by lane group (DH % 16) / 4 in register 0 of tile DH / 16
+            l = __shfl(o[DH / 16][qt][0], fr + 16 * ((DH % 16) / 4), 64);
+        } else {
+            l = quad_row_sum(l_run[qt]);
+        }
         const float inv = 1.0f / l;
         const int q = q0 + qt * 16 + fr;
         if (q >= p.n) continue;
@@ -232,7 +261,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnParams p) {
 
 template <class TT, int DH, int QT>
 int launch(const AttnParams& p, hipStream_t stream) {
-    constexpr int DKP = round_up(DH, 32), DVP = round_up(DH, 16);
+    constexpr int DKP = (DH / 32) * 32 + ((DH % 32) ? 16 : 0), DVP = round_up(DH, 16);
     constexpr int KROW = DKP + 8, VROW = v_pitch_bytes(DVP) / 2;
     constexpr size_t lds = (size_t)(2 * KVB * KROW + 2 * KVB * VROW) * 2;
     auto kern = attn_kernel<TT, DH, QT>;

@@ -22,6 +22,9 @@ struct F16 {
     static __device__ __forceinline__ f4_t mfma32(v8 a, v8 b, f4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f4_t mfma16(v4 a, v4 b, f4_t c) {  // 16x16x16: lane holds k = 4*(lane>>4) + j
+        return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+    }
     static __device__ __forceinline__ v4 tr_read(const elem* lds) {
         return __builtin_bit_cast(v4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                                           (__attribute__((address_space(3))) s4_t*)(lds)));
@@ -34,6 +37,9 @@ struct BF16 {
     static __device__ __forceinline__ f4_t mfma32(v8 a, v8 b, f4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f4_t mfma16(v4 a, v4 b, f4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4_t, a), __builtin_bit_cast(s4_t, b), c, 0, 0, 0);
+    }
     static __device__ __forceinline__ v4 tr_read(const elem* lds) {
         return __builtin_bit_cast(v4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                                           (__attribute__((address_space(3))) s4_t*)(lds)));
@@ -44,7 +50,40 @@ template <class E> __device__ __forceinline__ float to_f32(E x) { return (float)
 template <class E> __device__ __forceinline__ E from_f32(float x) { return (E)x; }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute): 1 - (a1 t + ... + a5 t^5) exp(-z^2),
+// t = 1 / (1 + p z).  Two transcendentals (v_rcp, v_exp) instead of the device library's branchy erff.
+__device__ __forceinline__ float erf_as_f(float x) {
+    const float z = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    poly *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+    const float r = 1.0f - poly * e;
+    return copysignf(r, x);
+}
+// F.gelu (erf form, attention.py:44)
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f)); }
+
+// max over the 4 lanes {l, l^16, l^32, l^48} with VALU lane swaps (no LDS round trip)
+__device__ __forceinline__ float quad_row_max(float v) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+    u = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+__device__ __forceinline__ float quad_row_sum(float v) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    u = __builtin_bit_cast(unsigned, v);
+    auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

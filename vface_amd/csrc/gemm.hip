@@ -3,158 +3,230 @@
 //   C[m, n] = epilogue( sum_k A(m, k) * Wt[n, k] )
 //
 // * Wt is the nn.Linear / packed conv weight: [N][Kp] row-major, K contiguous (the natural "B^T" form).
-// * A is either a plain row-major [M][K] matrix with leading dimension lda (tokens x channels, NHWC
-//   activations are exactly this), or -- MODE_CONV -- the im2col view of an NHWC image
-//   [img][H][W][ldpix >= Cin] under a 3x3 window with padding 1, stride 1|2 and optional nearest x2
-//   upsampling of the input (openaimodel.py Downsample :151-153, Upsample :116-118, ResBlock convs
-//   :201-205,225-232), k = (ky*3 + kx)*Cin + ci.  Nothing is materialised: each 16-byte k-chunk of the
-//   A tile is fetched straight from its source pixel by a direct global->LDS load; padding taps read a
-//   zero page.
-// * Tile 128(m) x 128(n) x 64(k), 4 waves (2x2), each wave 64x64 = 4x4 mfma_f32_16x16x32 tiles, fp32
-//   accumulate.  Two LDS buffers; the next K tile's global_load_lds (16 B/lane) is in flight while the
-//   current one feeds the MFMAs.  LDS rows are 128 B; the 16-B slot of k-chunk c of row r is
-//   c ^ ((r>>1)&7), applied on the per-lane SOURCE address (the LDS image of a wave-instruction is
-//   lane-linear) and again on the fragment read: ds_read_b128 of 16 rows x one chunk is conflict-free.
+// * A is either a plain row-major [M][K] matrix with leading dimension lda (tokens x channels; NHWC
+//   activations are exactly this), or the im2col view of an NHWC image [img][H][W][ld >= Cin] under a 3x3
+//   window with padding 1, stride 1|2 and optional nearest x2 upsampling of the input (openaimodel.py
+//   Downsample :151-153, Upsample :116-118, ResBlock convs :201-205,225-232), k = (ky*3 + kx)*Cin + ci.
+//   Nothing is materialised: each 16-byte k-chunk of the A tile is fetched straight from its source pixel by
+//   a direct global->LDS load; padding taps and tile tails read a zero page (no divergent loads).
+// * Block tile 128(m) x BN(n) x 64(k), BN = 128 or 160, 4 waves as 2(m) x 2(n); a wave owns 64 x BN/2 =
+//   4 x NT mfma_f32_16x16x32 tiles (NT = 4 | 5), fp32 accumulate.  Every channel count of the real UNet is
+//   a multiple of 320, so BN = 160 tiles N exactly where BN = 128 would idle 1/6 of the MFMAs at N = 320.
+// * LDS rows are 128 B (64 k); the 16-B slot of k-chunk c of row r is c ^ ((r>>1)&7), applied on the
+//   per-lane SOURCE address (the LDS image of one global_load_lds wave-instruction is lane-linear) and
+//   again on the fragment read: a ds_read_b128 of 16 rows x one chunk is conflict-free.
+// * Source pointers live in registers and advance by one K tile per step; for convolutions with
+//   Cin % 64 == 0 the tap of a K tile is wave-uniform, so the per-row work per step is one validity-bit
+//   test and one 64-bit add.
 // * Weights are the MFMA "A" operand and activations the "B" operand, so a lane ends up with 4
 //   consecutive output channels of one row: 8-byte stores, and bias / residual / GEGLU pair up in-lane.
 //
-// Epilogue (all fp32): + bias[n] + rowbias[m / rows_per_sample][n] (time-embedding add of ResBlock
-// :264-271, or the degenerate single-token cross-attention vector), optional GEGLU
-// (attention.py:37-45, weight rows pre-permuted so value/gate tiles alternate), + residual[m][n],
-// store as fp16/bf16 or fp32.
+// Epilogue (fp32): + bias[n] + rowbias[m / rows_per_sample][n] (time-embedding add of ResBlock :264-271, or
+// the degenerate single-token cross-attention vector), optional GEGLU (attention.py:37-45,
+// weight rows pre-permuted so value / gate tiles alternate), + residual[m][n], store 16-bit or fp32.
 #include "common.hpp"
 #include "vface_kernels.hpp"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_ELEMS = BM * BK;  // 8192 elems = 16 KiB
+constexpr int BM = 128, BK = 64;
+enum { MODE_PLAIN = 0, MODE_CONV_FAST = 1, MODE_CONV_GENERIC = 2 };
 
-template <class TT, int MODE>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+template <class TT, int MODE, int NT, bool DB>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
+    constexpr int BN = 32 * NT;               // 128 | 160
+    constexpr int BROUNDS = BN / 32;          // staging rounds of the weight tile (32 rows per round)
+    constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    E* smem = reinterpret_cast<E*>(smem_raw);  // [2][A tile | B tile]
+    E* smem = reinterpret_cast<E*>(smem_raw);
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order (guide T1).  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2.
+    // Every XCD gets a contiguous run of the tile sequence L (bijective for any grid size: q = nwg/8, r = nwg%8),
+    // and L walks the tile grid in column groups of GN = 8 n-tiles, m-major inside a group: the ~64 tiles an XCD
+    // has in flight then cover ~8 m-tiles x 8 n-tiles, so both the activation panels (and the neighbouring
+    // m-tiles whose 3x3 windows overlap them) and the weight panels are re-used out of that XCD's L2.
+    int m0, n0;
+    {
+        const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
+        int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        if (p.flags & GEMM_NO_XCD_REMAP) L = id;
+        constexpr int GN = 8;
+        const int g = L / (GN * ntm);
+        const int rem = L - g * (GN * ntm);
+        const int gw = min(GN, ntn - g * GN);
+        const int tm = rem / gw;
+        m0 = tm * BM;
+        n0 = (g * GN + (rem - tm * gw)) * BN;
+    }
 
     const E* __restrict__ A = reinterpret_cast<const E*>(p.A);
     const E* __restrict__ A2 = reinterpret_cast<const E*>(p.A2);
     const E* __restrict__ Wt = reinterpret_cast<const E*>(p.Wt);
     const E* zeros = reinterpret_cast<const E*>(p.zeros);
 
-    // ---- staging map: slot = rr*256 + t -> row rr*32 + (t>>3), 16-B slot t&7, logical k-chunk below
+    // staging map: slot = rr*256 + t -> row rr*32 + (t>>3), 16-B slot t&7 holds logical k-chunk schunk
     const int srow = t >> 3;
     const int schunk = (t & 7) ^ ((t >> 4) & 7);
 
-    // per-round source row state
-    long a_row_off[4], a2_row_off[4];
-    int a_oy[4], a_ox[4];
-    bool a_ok[4];
-    long b_row_off[4];
-    bool b_ok[4];
+    const E* a_ptr[4];       // plain: row pointer at k = schunk*8; conv-fast: pointer of tap (0,0), ci = schunk*8
+    const E* a2_ptr[4];
+    unsigned a_mask[4];      // conv-fast: bit tap = tap in bounds; plain: row valid
+    int g_oy[4], g_ox[4];    // conv-generic
+    long g_img[4];
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int m = m0 + rr * 32 + srow;
-        a_ok[rr] = m < p.M;
-        a2_row_off[rr] = 0;
-        if (MODE == 0) {
-            a_row_off[rr] = (long)m * p.lda;
-            a_oy[rr] = a_ox[rr] = 0;
-            if (p.A2) a2_row_off[rr] = (long)(p.a2_row_mod > 0 ? m % p.a2_row_mod : m) * p.lda2;
+        const bool ok = m < p.M;
+        a2_ptr[rr] = zeros;
+        if (MODE == MODE_PLAIN) {
+            a_ptr[rr] = A + (long)m * p.lda + schunk * 8;
+            a_mask[rr] = ok ? 1u : 0u;
+            if (p.A2) a2_ptr[rr] = A2 + (long)(p.a2_row_mod > 0 ? m % p.a2_row_mod : m) * p.lda2 + schunk * 8;
         } else {
             const int hw = p.OH * p.OW;
             const int img = m / hw;
             const int rem = m - img * hw;
-            const int oy = rem / p.OW;
-            a_oy[rr] = oy * p.stride - 1;
-            a_ox[rr] = (rem - oy * p.OW) * p.stride - 1;
-            a_row_off[rr] = (long)img * p.H * p.W;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+            const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
+            if (MODE == MODE_CONV_FAST) {
+                unsigned mk = 0;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int vy = y0 + tp / 3, vx = x0 + tp % 3;
+                    if (ok && (unsigned)vy < (unsigned)p.H && (unsigned)vx < (unsigned)p.W) mk |= 1u << tp;
+                }
+                a_mask[rr] = mk;
+                a_ptr[rr] = A + (((long)img * p.H + y0) * p.W + x0) * p.lda + schunk * 8;
+            } else {
+                a_mask[rr] = ok ? 1u : 0u;
+                g_oy[rr] = y0; g_ox[rr] = x0; g_img[rr] = (long)img * p.H * p.W;
+                a_ptr[rr] = A;
+            }
         }
+    }
+    const E* b_ptr[BROUNDS];
+    bool b_ok[BROUNDS];
+#pragma unroll
+    for (int rr = 0; rr < BROUNDS; ++rr) {
         const int n = n0 + rr * 32 + srow;
         b_ok[rr] = n < p.N;
-        b_row_off[rr] = (long)n * p.ldw;
+        b_ptr[rr] = Wt + (long)n * p.ldw + schunk * 8;
     }
 
     auto stage = [&](int kt, int buf) {
-        const int k = kt * BK + schunk * 8;
-        E* sA = smem + buf * 2 * TILE_ELEMS;
-        E* sB = sA + TILE_ELEMS;
+        E* sA = smem + buf * STAGE;
+        E* sB = sA + A_ELEMS;
+        const int kbase = kt * BK;           // wave-uniform
+        const int k = kbase + schunk * 8;
         const bool kin = k < p.K;
-        int ky = 0, kx = 0, ci = k;
-        if (MODE == 1) {
-            const int tap = k / p.Cin;
-            ci = k - tap * p.Cin;
-            ky = tap / 3;
-            kx = tap - ky * 3;
-        }
+        if (MODE == MODE_PLAIN) {
+            const bool second = A2 && kbase >= p.K1;
+            const long koff = second ? kbase - p.K1 : kbase;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const E* src;
-            if (MODE == 0) {
-                // dual-source K: columns [0, K1) come from A, [K1, K) from A2 (K1 is a multiple of BK,
-                // so a K tile never straddles).  This is how [own | structure] feeds the folded FSAI
-                // projection without concatenating anything.
-                if (A2 && kt * BK >= p.K1) src = (a_ok[rr] && kin) ? A2 + a2_row_off[rr] + (k - p.K1) : zeros;
-                else src = (a_ok[rr] && kin) ? A + a_row_off[rr] + k : zeros;
-            } else {
-                const int vy = a_oy[rr] + ky, vx = a_ox[rr] + kx;
-                const int VH = p.upsample ? 2 * p.H : p.H, VW = p.upsample ? 2 * p.W : p.W;
-                const bool ok = a_ok[rr] && kin && (unsigned)vy < (unsigned)VH && (unsigned)vx < (unsigned)VW;
-                const int sy = p.upsample ? (vy >> 1) : vy, sx = p.upsample ? (vx >> 1) : vx;
-                src = ok ? A + (a_row_off[rr] + (long)sy * p.W + sx) * p.lda + ci : zeros;
+            for (int rr = 0; rr < 4; ++rr) {
+                const E* src = (second ? a2_ptr[rr] : a_ptr[rr]) + koff;
+                src = (a_mask[rr] && kin) ? src : zeros;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, 0, 0);
             }
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, 0, 0);
-        }
+        } else if (MODE == MODE_CONV_FAST) {
+            const int tap = kbase / p.Cin;       // uniform: Cin % 64 == 0
+            const int ci0 = kbase - tap * p.Cin;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const long toff = ((long)ky * p.W + kx) * p.lda + ci0;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const E* src = (b_ok[rr] && k < p.Kw) ? Wt + b_row_off[rr] + k : zeros;
+            for (int rr = 0; rr < 4; ++rr) {
+                const E* src = ((a_mask[rr] >> tap) & 1u) ? a_ptr[rr] + toff : zeros;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, 0, 0);
+            }
+        } else {
+            const int tap = k / p.Cin;
+            const int ci = k - tap * p.Cin;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int VH = p.upsample ? 2 * p.H : p.H, VW = p.upsample ? 2 * p.W : p.W;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int vy = g_oy[rr] + ky, vx = g_ox[rr] + kx;
+                const bool ok = a_mask[rr] && kin && (unsigned)vy < (unsigned)VH && (unsigned)vx < (unsigned)VW;
+                const int sy = p.upsample ? (vy >> 1) : vy, sx = p.upsample ? (vx >> 1) : vx;
+                const E* src = ok ? A + (g_img[rr] + (long)sy * p.W + sx) * p.lda + ci : zeros;
+                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, 0, 0);
+            }
+        }
+        const bool kwin = k < p.Kw;
+#pragma unroll
+        for (int rr = 0; rr < BROUNDS; ++rr) {
+            const E* src = (b_ok[rr] && kwin) ? b_ptr[rr] + kbase : zeros;
             __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sB + (rr * 256 + wave * 64) * 8), 16, 0, 0);
         }
     };
 
-    f4_t acc[4][4];  // [n tile j][m tile i]
+    f4_t acc[NT][4];  // [n tile j][m tile i]
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = f4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nt = (p.K + BK - 1) / BK;
     const int fr = lane & 15, fq = lane >> 4;
 
-    stage(0, 0);
-    for (int kt = 0; kt < nt; ++kt) {
-        const int cur = kt & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nt) stage(kt + 1, cur ^ 1);
-        const E* sA = smem + cur * 2 * TILE_ELEMS;
-        const E* sB = sA + TILE_ELEMS;
+    // Fragment reads of BOTH k32 halves are issued up front (two register sets): the second half's LDS latency
+    // hides under the first half's MFMAs instead of stalling on lgkmcnt(0) four times per tile.
+    auto compute = [&](int buf) {
+        const E* sA = smem + buf * STAGE;
+        const E* sB = sA + A_ELEMS;
+        V8 af[2][4], bf[2][NT];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            V8 af[4], bf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = wm * 64 + i * 16 + fr;
                 const int slot = (kk * 4 + fq) ^ ((row >> 1) & 7);
-                af[i] = *reinterpret_cast<const V8*>(sA + row * BK + slot * 8);
+                af[kk][i] = *reinterpret_cast<const V8*>(sA + row * BK + slot * 8);
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wn * 64 + j * 16 + fr;
+            for (int j = 0; j < NT; ++j) {
+                const int row = wn * (BN / 2) + j * 16 + fr;
                 const int slot = (kk * 4 + fq) ^ ((row >> 1) & 7);
-                bf[j] = *reinterpret_cast<const V8*>(sB + row * BK + slot * 8);
+                bf[kk][j] = *reinterpret_cast<const V8*>(sB + row * BK + slot * 8);
             }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep all 2 x (4 + NT) reads ahead of the MFMAs (hipcc sinks them otherwise)
+        if (!(p.flags & GEMM_NO_SETPRIO)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[j], af[i], acc[j][i]);
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[kk][j], af[kk][i], acc[j][i]);
+        if (!(p.flags & GEMM_NO_SETPRIO)) __builtin_amdgcn_s_setprio(0);
+    };
+
+    if (DB) {
+        // two LDS stages: tile kt+1 is in flight while tile kt feeds the MFMAs; one barrier per K tile
+        stage(0, 0);
+        for (int kt = 0; kt < nt; ++kt) {
+            const int cur = kt & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nt) stage(kt + 1, cur ^ 1);
+            compute(cur);
+        }
+    } else {
+        // one LDS stage, two barriers per K tile; latency is hidden by the other workgroups on the CU
+        for (int kt = 0; kt < nt; ++kt) {
+            stage(kt, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();
         }
     }
 
@@ -171,8 +243,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         const float* rb = rowbias ? rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
         if (!geglu) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int nb = n0 + wn * 64 + j * 16 + fq * 4;
+            for (int j = 0; j < NT; ++j) {
+                const int nb = n0 + wn * (BN / 2) + j * 16 + fq * 4;
                 if (nb >= p.N) continue;
                 float v[4];
 #pragma unroll
@@ -201,16 +273,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                 }
             }
         } else {
-            // packed rows: every 32-row block of Wt is [16 value rows ; 16 gate rows] of the same 16
-            // output channels -> tiles (j, j+1) pair up; output channel = (n/32)*16 + n%16.
+            // packed rows: every 32-row block of Wt is [16 value rows ; 16 gate rows] of the same 16 output
+            // channels -> global 16-row tile index even = value, odd = gate; output channel = (n/32)*16 + n%16.
+            // A wave's first tile index wn*(BN/32)... is even for BN = 128; for BN = 160 (5 tiles per wave) the
+            // second wave starts on an odd tile, so pair by GLOBAL tile parity through the block's 10 tiles.
 #pragma unroll
-            for (int jj = 0; jj < 2; ++jj) {
-                const int nb = n0 + wn * 64 + jj * 32 + fq * 4;  // packed index of the value rows
+            for (int j = 0; j < NT; ++j) {
+                const int gt = wn * NT + j;              // tile index inside the block (BN/16 tiles)
+                if (gt & 1) continue;                    // value tiles only; the gate is tile gt+1
+                const int nb = n0 + gt * 16 + fq * 4;    // packed index of the value rows
                 if (nb >= p.N) continue;
                 const int oc = (nb >> 5) * 16 + (nb & 15);
                 float a[4], g[4];
+                // the gate tile lives in this wave iff j+1 < NT
+                if (j + 1 < NT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { a[r] = acc[2 * jj][i][r]; g[r] = acc[2 * jj + 1][i][r]; }
+                    for (int r = 0; r < 4; ++r) { a[r] = acc[j][i][r]; g[r] = acc[j + 1 < NT ? j + 1 : j][i][r]; }
+                } else {
+                    continue;  // handled below through LDS exchange (BN = 160 only)
+                }
                 if (bias) {
                     const float4 ba = *reinterpret_cast<const float4*>(bias + nb);
                     const float4 bg = *reinterpret_cast<const float4*>(bias + nb + 16);
@@ -226,16 +307,47 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 }
 
-template <class TT>
-int launch_gemm(const GemmParams& p, hipStream_t stream) {
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN);
-    const size_t lds = 2 * 2 * TILE_ELEMS * sizeof(typename TT::elem);
-    if (p.mode == 0) {
-        hipLaunchKernelGGL((gemm_kernel<TT, 0>), grid, dim3(256), lds, stream, p);
-    } else {
-        hipLaunchKernelGGL((gemm_kernel<TT, 1>), grid, dim3(256), lds, stream, p);
+template <class TT, int MODE, int NT, bool DB>
+int launch_one(const GemmParams& p, hipStream_t stream) {
+    constexpr int BN = 32 * NT;
+    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN));
+    const size_t lds = (size_t)(DB ? 2 : 1) * (BM + BN) * BK * sizeof(typename TT::elem);
+    auto kern = gemm_kernel<TT, MODE, NT, DB>;
+    static bool attr_set = false;
+    if (lds > 64 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return VF_ERR_LAUNCH;
+        attr_set = true;
     }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
+}
+
+template <class TT, int MODE>
+int launch_mode(const GemmParams& p, int variant, hipStream_t stream) {
+    switch (variant) {
+        case 5: return launch_one<TT, MODE, 4, true>(p, stream);   // 128x128x64, two stages
+        case 6: return launch_one<TT, MODE, 5, true>(p, stream);   // 128x160x64, two stages
+        case 7: return launch_one<TT, MODE, 4, false>(p, stream);  // 128x128x64, one stage
+        default: return launch_one<TT, MODE, 5, false>(p, stream); // 128x160x64, one stage
+    }
+}
+
+template <class TT>
+int launch_gemm(const GemmParams& p, int variant, hipStream_t stream) {
+    if (p.mode == 0) return launch_mode<TT, MODE_PLAIN>(p, variant, stream);
+    if (!p.upsample && (p.Cin % 64 == 0)) return launch_mode<TT, MODE_CONV_FAST>(p, variant, stream);
+    return launch_mode<TT, MODE_CONV_GENERIC>(p, variant, stream);
+}
+
+// Schedule choice.  `flags` bits 8..11 force a variant (A/B benchmarking); 0 = automatic.
+int pick_variant(const GemmParams& p) {
+    const int forced = (p.flags >> 8) & 0xF;
+    if (forced) return forced;
+    const bool geglu = p.flags & GEMM_GEGLU;
+    const bool n160 = !geglu && (p.N % 160 == 0) && (p.N % 128 != 0);
+    return n160 ? 6 : 5;
 }
 
 }  // namespace
@@ -254,7 +366,10 @@ int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream) {
         if (p.Cin <= 0 || (p.Cin & 7) || p.K != 9 * p.Cin) return VF_ERR_SHAPE;
         if (p.stride != 1 && p.stride != 2) return VF_ERR_SHAPE;
     }
-    if (dtype == VF_DTYPE_F16) return launch_gemm<F16>(p, stream);
-    if (dtype == VF_DTYPE_BF16) return launch_gemm<BF16>(p, stream);
+    const int variant = pick_variant(p);
+    if ((p.flags & GEMM_GEGLU) && (variant == 2 || variant == 4 || variant == 6 || variant == 8)) return VF_ERR_SHAPE;
+    if (variant >= 1 && variant <= 4) return vf_launch_gemm_pipe(p, dtype, variant, stream);
+    if (dtype == VF_DTYPE_F16) return launch_gemm<F16>(p, variant, stream);
+    if (dtype == VF_DTYPE_BF16) return launch_gemm<BF16>(p, variant, stream);
     return VF_ERR_DTYPE;
 }

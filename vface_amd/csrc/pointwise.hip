@@ -64,43 +64,49 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const typename TT::elem*
 // group is a slab of C/groups adjacent channels of every pixel.  Pass 1: each workgroup reduces a
 // range of pixels over ALL channels (coalesced rows) into per-group (sum, sumsq) partials; pass 2
 // folds the partials in double precision into (mean, rstd).
-constexpr int GN_PIX = 64;  // pixels per workgroup in pass 1
+constexpr int GN_PIX = 128;  // pixels per workgroup
 
+// Thread t owns one 16-B channel chunk (t % CPB) and one pixel lane (t / CPB): its 8 channels' (sum, sumsq)
+// stay in registers across the pixel loop; one LDS atomic per channel per thread folds the pixel lanes.
 template <class TT>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const typename TT::elem* __restrict__ x, long ldx, int hw,
                                                          int C, int groups, float* __restrict__ partial) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
-    __shared__ float acc[2 * 64];  // groups <= 64
-    const int img = blockIdx.y, chunk = blockIdx.x;
-    const int cpg = C / groups;
-    for (int i = threadIdx.x; i < 2 * groups; i += 256) acc[i] = 0.f;
+    extern __shared__ float gn_acc[];  // [C][2]
+    const int img = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
+    const int cpg = C / groups, c8 = C / 8;
+    for (int i = t; i < 2 * C; i += 256) gn_acc[i] = 0.f;
     __syncthreads();
-    const int c8 = C / 8;
     const int p0 = chunk * GN_PIX, p1 = min(hw, p0 + GN_PIX);
-    const long total = (long)(p1 - p0) * c8;
-    const E* base = x + ((long)img * hw + p0) * ldx;
-    // a thread keeps one channel chunk when 256 % c8 == 0 is false as well: accumulate per element group
-    for (long i = threadIdx.x; i < total; i += 256) {
-        const int pix = (int)(i / c8), cc = (int)(i - (long)pix * c8) * 8;
-        const V8 t = *reinterpret_cast<const V8*>(base + (long)pix * ldx + cc);
-        int g = cc / cpg;
-        int left = (g + 1) * cpg - cc;  // channels left in group g from cc
-        float s = 0.f, q = 0.f;
+    const E* base = x + (long)img * hw * ldx;
+    const int CPB = min(c8, 256), PP = 256 / CPB;
+    const int lanep = t / CPB, cl = t - lanep * CPB;
+    for (int cb = 0; cb < c8; cb += CPB) {
+        const int ch = cb + cl;
+        if (lanep < PP && ch < c8) {
+            float s[8], q[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (left == 0) {
-                atomicAdd(&acc[2 * g], s); atomicAdd(&acc[2 * g + 1], q);
-                s = q = 0.f; ++g; left = cpg;
+            for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+            for (int p = p0 + lanep; p < p1; p += PP) {
+                const V8 v = *reinterpret_cast<const V8*>(base + (long)p * ldx + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = to_f32(v[j]); s[j] += f; q[j] += f * f; }
             }
-            const float f = to_f32(t[j]);
-            s += f; q += f * f; --left;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(&gn_acc[2 * (ch * 8 + j)], s[j]);
+                atomicAdd(&gn_acc[2 * (ch * 8 + j) + 1], q[j]);
+            }
         }
-        atomicAdd(&acc[2 * g], s); atomicAdd(&acc[2 * g + 1], q);
     }
     __syncthreads();
     float* out = partial + ((long)img * gridDim.x + chunk) * 2 * groups;
-    for (int i = threadIdx.x; i < 2 * groups; i += 256) out[i] = acc[i];
+    for (int g = t; g < groups; g += 256) {
+        float s = 0.f, q = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += gn_acc[2 * c]; q += gn_acc[2 * c + 1]; }
+        out[2 * g] = s; out[2 * g + 1] = q;
+    }
 }
 
 __global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunks, int groups, double count,
@@ -120,31 +126,45 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk
     }
 }
 
+// y = silu?( x * a[c] + b[c] ) with a = rstd * gamma, b = beta - mean * rstd * gamma held in registers per thread
 template <class TT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const typename TT::elem* __restrict__ x, long ldx,
                                                        const float* __restrict__ stats,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        typename TT::elem* __restrict__ y, long ldy, int hw, int C,
-                                                       int groups, int silu, long total) {
+                                                       int groups, int silu, int pix_per_block) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
+    const int img = blockIdx.y, t = threadIdx.x;
     const int c8 = C / 8, cpg = C / groups;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long pix = i / c8;
-        const int cc = (int)(i - pix * c8) * 8;
-        const int img = (int)(pix / hw);
-        const V8 t = *reinterpret_cast<const V8*>(x + pix * ldx + cc);
-        const float* st = stats + (long)img * groups * 2;
-        V8 o;
+    const int p0 = blockIdx.x * pix_per_block, p1 = min(hw, p0 + pix_per_block);
+    const float* st = stats + (long)img * groups * 2;
+    const E* xb = x + (long)img * hw * ldx;
+    E* yb = y + (long)img * hw * ldy;
+    const int CPB = min(c8, 256), PP = 256 / CPB;
+    const int lanep = t / CPB, cl = t - lanep * CPB;
+    for (int cb = 0; cb < c8; cb += CPB) {
+        const int ch = cb + cl;
+        if (lanep >= PP || ch >= c8) continue;
+        float a[8], b[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = cc + j, g = c / cpg;
-            float f = (to_f32(t[j]) - st[2 * g]) * st[2 * g + 1] * gamma[c] + beta[c];
-            if (silu) f = silu_f(f);
-            o[j] = from_f32<E>(f);
+            const int c = ch * 8 + j, g = c / cpg;
+            a[j] = st[2 * g + 1] * gamma[c];
+            b[j] = beta[c] - st[2 * g] * a[j];
         }
-        *reinterpret_cast<V8*>(y + pix * ldy + cc) = o;
+        for (int p = p0 + lanep; p < p1; p += PP) {
+            const V8 v = *reinterpret_cast<const V8*>(xb + (long)p * ldx + ch * 8);
+            V8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float f = to_f32(v[j]) * a[j] + b[j];
+                if (silu) f = silu_f(f);
+                o[j] = from_f32<E>(f);
+            }
+            *reinterpret_cast<V8*>(yb + (long)p * ldy + ch * 8) = o;
+        }
     }
 }
 
@@ -406,7 +426,7 @@ int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int gro
     dim3 grid(nchunks, nimg);
     DISPATCH_DTYPE(dtype, {
         using E = typename TT::elem;
-        hipLaunchKernelGGL((gn_partial_kernel<TT>), grid, dim3(256), 0, stream, (const E*)x, ldx, hw, C, groups, partial);
+        hipLaunchKernelGGL((gn_partial_kernel<TT>), grid, dim3(256), (size_t)2 * C * sizeof(float), stream, (const E*)x, ldx, hw, C, groups, partial);
     });
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg), dim3(64), 0, stream, (const float*)partial, nchunks, groups,
                        (double)hw * (C / groups), eps, stats);
@@ -418,11 +438,15 @@ int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float*
     if (!x || !stats || !gamma || !beta || !y || nimg <= 0 || hw <= 0) return VF_ERR_ARG;
     if ((C & 7) || (ldx & 7) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VF_ERR_ALIGN;
     if (groups > 64 || C % groups) return VF_ERR_SHAPE;
-    const long total = (long)nimg * hw * (C / 8);
+    // enough workgroups to fill 256 CUs several times over, but long enough pixel loops to amortise the
+    // per-thread scale/shift set-up
+    int ppb = 128;
+    while (ppb > 16 && (long)nimg * ((hw + ppb - 1) / ppb) < 1024) ppb >>= 1;
+    dim3 grid((hw + ppb - 1) / ppb, nimg);
     DISPATCH_DTYPE(dtype, {
         using E = typename TT::elem;
-        hipLaunchKernelGGL((gn_apply_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, stream, (const E*)x, ldx, stats,
-                           gamma, beta, (E*)y, ldy, hw, C, groups, silu, total);
+        hipLaunchKernelGGL((gn_apply_kernel<TT>), grid, dim3(256), 0, stream, (const E*)x, ldx, stats,
+                           gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
     });
     return ok();
 }

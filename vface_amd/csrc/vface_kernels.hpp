@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-enum { GEMM_GEGLU = 1, GEMM_OUT_F32 = 2 };
+enum { GEMM_GEGLU = 1, GEMM_OUT_F32 = 2, GEMM_NO_XCD_REMAP = 0x1000, GEMM_NO_SETPRIO = 0x2000 };  // bits 8..11 of flags: forced schedule variant (0 = automatic)
 
 struct GemmParams {
     int mode;  // 0: plain A[M][K]; 1: implicit 3x3 conv over NHWC
@@ -30,6 +30,7 @@ struct GemmParams {
     int flags;
 };
 int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
+int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream);
 
 struct AttnParams {
     const void* Q; const void* K; const void* V;  // [B][n][ld*], head h at column h*dh
