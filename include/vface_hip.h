@@ -67,7 +67,8 @@ int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1,
                int dtype, void* stream);
 
 /* Y = conv3x3(X) over NHWC, padding 1, stride 1|2, optional nearest x2 upsampling of X first, as an
- * implicit GEMM (nothing materialised).  Wt packed [Cout][3][3][Cin].
+ * implicit GEMM (nothing materialised).  Wt is packed [Cout][K = 9*Cin]: K order (64-channel chunk, tap, channel)
+ * when Cin % 64 == 0, else (tap, channel) -- vface_amd/packing.py::pack_conv3x3.
  * Replaces nn.Conv2d in ResBlock.in_layers/out_layers (openaimodel.py:201-232), Downsample.op (:151-153),
  * Upsample.conv after F.interpolate (:108-118), input_blocks.0 (:668-674) and `out` (:821-825). */
 int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw, int Cout,

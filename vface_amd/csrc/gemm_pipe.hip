@@ -83,14 +83,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_pipe_kernel(GemmParams p) {
             const int oy = rem / p.OW, ox = rem - oy * p.OW;
             const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
             if (MODE == MODE_CONV_FAST) {
+                const int VH = p.upsample ? 2 * p.H : p.H, VW = p.upsample ? 2 * p.W : p.W;
                 unsigned mk = 0;
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp) {
                     const int vy = y0 + tp / 3, vx = x0 + tp % 3;
-                    if (ok && (unsigned)vy < (unsigned)p.H && (unsigned)vx < (unsigned)p.W) mk |= 1u << tp;
+                    if (ok && (unsigned)vy < (unsigned)VH && (unsigned)vx < (unsigned)VW) mk |= 1u << tp;
                 }
                 a_mask[rr] = mk;
                 a_ptr[rr] = A + (((long)img * p.H + y0) * p.W + x0) * p.lda + schunk * 8;
+                g_oy[rr] = y0; g_ox[rr] = x0; g_img[rr] = (long)img * p.H * p.W;
             } else {
                 a_mask[rr] = ok ? 1u : 0u;
                 g_oy[rr] = y0; g_ox[rr] = x0; g_img[rr] = (long)img * p.H * p.W;
@@ -129,15 +131,29 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_pipe_kernel(GemmParams p) {
                 __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (rr * NTHR + wave * 64) * 8), 16, 0, 0);
             }
         } else if (MODE == MODE_CONV_FAST) {
-            const int tap = kbase / p.Cin;  // uniform: Cin % 64 == 0 and BKK | 64
-            const int ci0 = kbase - tap * p.Cin;
+            // (64-channel chunk, tap, channel) K order, see gemm.hip
+            constexpr int TPC = 9 * (64 / BKK);           // K tiles per 64-channel chunk
+            const int cc = kt / TPC, rem = kt - cc * TPC;
+            const int tap = rem / (64 / BKK), sub = rem - tap * (64 / BKK);
             const int ky = tap / 3, kx = tap - ky * 3;
-            const long toff = ((long)ky * p.W + kx) * p.lda + ci0;
+            const int ci0 = cc * 64 + sub * BKK;
+            if (!p.upsample) {
+                const long toff = ((long)ky * p.W + kx) * p.lda + ci0;
 #pragma unroll
-            for (int rr = 0; rr < AR; ++rr) {
-                if (rr * RPR + wave_row0 >= BM) continue;
-                const E* src = ((a_mask[rr] >> tap) & 1u) ? a_ptr[rr] + toff : zeros;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (rr * NTHR + wave * 64) * 8), 16, 0, 0);
+                for (int rr = 0; rr < AR; ++rr) {
+                    if (rr * RPR + wave_row0 >= BM) continue;
+                    const E* src = ((a_mask[rr] >> tap) & 1u) ? a_ptr[rr] + toff : zeros;
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (rr * NTHR + wave * 64) * 8), 16, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int rr = 0; rr < AR; ++rr) {
+                    if (rr * RPR + wave_row0 >= BM) continue;
+                    const int sy = (g_oy[rr] + ky) >> 1, sx = (g_ox[rr] + kx) >> 1;
+                    const E* src = ((a_mask[rr] >> tap) & 1u)
+                                       ? A + (g_img[rr] + (long)sy * p.W + sx) * p.lda + ci0 + schunk * 8 : zeros;
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (rr * NTHR + wave * 64) * 8), 16, 0, 0);
+                }
             }
         } else {
             const int tap = k / p.Cin;
@@ -316,7 +332,7 @@ int launch_mode(const GemmParams& p, int variant, hipStream_t stream) {
 
 int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream) {
     if ((p.flags & GEMM_GEGLU) && (variant == 2 || variant == 4)) return VF_ERR_SHAPE;
-    const int mode = p.mode == 0 ? MODE_PLAIN : ((!p.upsample && (p.Cin % 64 == 0)) ? MODE_CONV_FAST : MODE_CONV_GENERIC);
+    const int mode = p.mode == 0 ? MODE_PLAIN : ((p.Cin % 64 == 0) ? MODE_CONV_FAST : MODE_CONV_GENERIC);
 #define GO(TT)                                                                   \
     switch (mode) {                                                              \
         case MODE_PLAIN: return launch_mode<TT, MODE_PLAIN>(p, variant, stream); \
