@@ -127,6 +127,16 @@ int vface_attn1_forward(const void* x, int64_t ldx, const void* Wqkv, const void
                         const int32_t* qk_map, const int32_t* v_map, void* workspace, size_t workspace_bytes,
                         const void* zeros, int dtype, void* stream);
 
+/* fusion="temporal" (pnp_utils.py:59-90,145-154): 5-tap Gaussian (sigma 1, renormalised at the clip ends) over the
+ * FRAME axis of src [F][n][C] (chunk 0's q|k), written to dst1 and dst2 (chunk 1 and chunk 2). */
+int vface_temporal_gauss(const void* src, int64_t ld_src, int64_t fs_src, void* dst1, void* dst2, int64_t ld_dst,
+                         int64_t fs_dst, int F, int n, int C, int dtype, void* stream);
+/* fusion="adaIn" (face_swap_utils.py:372-389, normalized=True): per-row AdaIN of a (structure) to b (own) over
+ * the channel axis, then division by the GLOBAL unbiased std of the fused tensor: dst [rows][C]. */
+size_t vface_adain_workspace_bytes(int64_t rows, int C);
+int vface_adain_fusion(const void* a, int64_t lda, const void* b, int64_t ldb, void* dst, int64_t ldd, int64_t rows, int C,
+                       void* workspace, size_t workspace_bytes, int dtype, void* stream);
+
 /* Small ops */
 /* util.py:151-171 timestep_embedding: out[N][dim] = [cos(t f_i) | sin(t f_i)] */
 int vface_timestep_embedding(const int64_t* t, void* out, int N, int dim, int dtype, void* stream);

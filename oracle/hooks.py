@@ -160,8 +160,12 @@ def _flow_gate(n: int, spatial_hw) -> bool:
     return n == spatial_hw[0] * spatial_hw[1]
 
 
+def _ident(t):
+    return t
+
+
 def attention(x, wq, wk, wv, wo, bo, heads: int, context=None, cfg: Optional[HookCfg] = None,
-              level0_hw=None, rnd: Callable[[torch.Tensor], torch.Tensor] = lambda t: t):
+              level0_hw=None, rnd: Callable[[torch.Tensor], torch.Tensor] = _ident):
     """``CrossAttention.forward`` (attention.py:179-221) and its hooked replacement
     (pnp_utils.py:94-287).  ``rnd`` marks the reference's fp16 rounding points under CUDA autocast
     (identity in the default fp32 oracle)."""
@@ -181,6 +185,11 @@ def attention(x, wq, wk, wv, wo, bo, heads: int, context=None, cfg: Optional[Hoo
         return t.reshape(B, t.shape[1], heads, dh).permute(0, 2, 1, 3)
 
     qh, kh, vh = split(q), split(k), split(v)
+    if rnd is _ident:
+        # fp32 oracle: the same softmax(q k^T * scale) v without materialising [B*h, n, n] (minutes -> seconds on CPU)
+        out = torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, scale=scale)
+        out = out.permute(0, 2, 1, 3).reshape(B, n, d)
+        return out @ wo.t() + bo
     sim = rnd(rnd(qh @ kh.transpose(-1, -2)) * scale)
     attn = rnd(sim.float().softmax(dim=-1))  # autocast: softmax in fp32, result cast for the fp16 bmm
     out = rnd(attn @ vh)

@@ -158,7 +158,7 @@ class _Ctx:
     def __init__(self, sd, half):
         self.half = half
         if half is None:
-            self.rnd = lambda t: t
+            self.rnd = ohooks._ident
             self.sd = {k: v.float() for k, v in sd.items()}
         else:
             self.rnd = lambda t: t.to(half).float()

@@ -80,10 +80,13 @@ def main():
             qkv = rnd(N, n, 3 * d)
             out = torch.empty(N, n, d, dtype=dt, device=DEV)
             fl = 4.0 * N * 8 * n * n * dh
-            med, best = timeit(lambda: hip.attention(qkv, qkv[:, :, d:], qkv[:, :, 2 * d:], out, B=N, heads=8, n=n, nk=n, dh=dh,
-                                                     ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d,
-                                                     ldo=d, bso=n * d, scale=dh ** -0.5))
-            print(f"n{n:5d} dh{dh:4d}: {fl / med / 1e9:6.0f}|{fl / best / 1e9:6.0f} TFLOP/s  ({med * 1e3:.0f} us)", flush=True)
+            row = f"n{n:5d} dh{dh:4d}: "
+            for var in (0, 1, 2):
+                med, best = timeit(lambda: hip.attention(qkv, qkv[:, :, d:], qkv[:, :, 2 * d:], out, B=N, heads=8, n=n, nk=n, dh=dh,
+                                                         ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d,
+                                                         ldo=d, bso=n * d, scale=dh ** -0.5, variant=var))
+                row += f"v{var} {fl / med / 1e9:6.0f}|{fl / best / 1e9:6.0f} ({med * 1e3:.0f} us)  "
+            print(row, flush=True)
     if "norm" in a.what:
         print("== GroupNorm / LayerNorm (GB/s of algorithmic bytes)")
         for (hw, C) in [(4096, 320), (4096, 640), (4096, 960), (1024, 640), (1024, 1920), (256, 1280), (256, 2560), (64, 1280)]:

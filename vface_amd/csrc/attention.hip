@@ -21,6 +21,13 @@ namespace {
 constexpr int KVB = 64;
 
 constexpr int round_up(int a, int b) { return (a + b - 1) / b * b; }
+constexpr int k_row_elems(int dkp) { return dkp <= 64 ? 64 : (dkp <= 128 ? 128 : dkp + 8); }
+// 16-B slot of logical chunk c in row r
+template <int KROW> __device__ __forceinline__ int k_slot(int r, int c) {
+    if (KROW == 64) return c ^ ((r >> 1) & 7);
+    if (KROW == 128) return c ^ (r & 15);
+    return c;
+}
 // V row pitch in bytes: an odd multiple of 32 B so the 8 rows a 32-lane half touches in one
 // ds_read_b64_tr_b16 fall in 8 distinct 32-B bank ranges of the 256-B bank row.
 constexpr int v_pitch_bytes(int dvp) {
@@ -41,7 +48,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     constexpr int DVP = round_up(DH, 16), NC = DVP / 16;
     // spare V column (DVP > DH): filled with ones, so the MFMA that builds O also builds the softmax denominator
     constexpr bool ONES = DVP > DH;
-    constexpr int KROW = DKP + 8;                    // elements
+    // K block rows: 128 B (DKP <= 64) or 256 B (DKP <= 128), 16-B slots XOR-swizzled by the row so a ds_read_b128 of
+    // 16 keys x one k-chunk is bank-conflict free (same rule as the GEMM tiles); larger head dims keep padded rows.
+    constexpr int KROW = k_row_elems(DKP);           // elements
     constexpr int VROW = v_pitch_bytes(DVP) / 2;     // elements
     constexpr int CPR = DH / 8;                      // 16-B chunks per row
     constexpr int NCH = KVB * CPR;                   // chunks per K (or V) block
@@ -95,33 +104,48 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         qt4[qt] = w;
     }
 
+    // staging map, fixed for the whole walk: thread t moves 16-B chunk min(r*256 + t, NCH-1) of the K and V blocks
+    // (the clamp makes the last round's surplus threads repeat chunk NCH-1: same bytes to the same place, no branch)
     uint4 kreg[SR], vreg[SR];
-    auto load_block = [&](int kb) {
+    const E* kptr[SR];
+    const E* vptr[SR];
+    int srow[SR], lds_k[SR], lds_v[SR];
 #pragma unroll
-        for (int r = 0; r < SR; ++r) {
-            const int id = r * 256 + t;
-            const int row = id / CPR, c = id - row * CPR;
-            const int key = kb * KVB + row;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if (id < NCH && key < nk) {
-                kv = *reinterpret_cast<const uint4*>(Kg + (long)key * p.ldk + c * 8);
-                vv = *reinterpret_cast<const uint4*>(Vg + (long)key * p.ldv + c * 8);
+    for (int r = 0; r < SR; ++r) {
+        const int id = min(r * 256 + t, NCH - 1);
+        const int row = id / CPR, c = id - row * CPR;
+        srow[r] = row;
+        kptr[r] = Kg + (long)row * p.ldk + c * 8;
+        vptr[r] = Vg + (long)row * p.ldv + c * 8;
+        lds_k[r] = row * KROW + k_slot<KROW>(row, c) * 8;
+        lds_v[r] = row * VROW + c * 8;
+    }
+    const long kstep = (long)KVB * p.ldk, vstep = (long)KVB * p.ldv;
+    auto load_block = [&](int kb) {
+        if ((kb + 1) * KVB <= nk) {  // full block (wave-uniform): no per-key guard
+#pragma unroll
+            for (int r = 0; r < SR; ++r) {
+                kreg[r] = *reinterpret_cast<const uint4*>(kptr[r]);
+                vreg[r] = *reinterpret_cast<const uint4*>(vptr[r]);
             }
-            kreg[r] = kv;
-            vreg[r] = vv;
+        } else {
+#pragma unroll
+            for (int r = 0; r < SR; ++r) {
+                const bool ok = kb * KVB + srow[r] < nk;
+                kreg[r] = ok ? *reinterpret_cast<const uint4*>(kptr[r]) : make_uint4(0, 0, 0, 0);
+                vreg[r] = ok ? *reinterpret_cast<const uint4*>(vptr[r]) : make_uint4(0, 0, 0, 0);
+            }
         }
+#pragma unroll
+        for (int r = 0; r < SR; ++r) { kptr[r] += kstep; vptr[r] += vstep; }
     };
     auto store_block = [&](int buf) {
         E* dK = sK + buf * KVB * KROW;
         E* dV = sV + buf * KVB * VROW;
 #pragma unroll
         for (int r = 0; r < SR; ++r) {
-            const int id = r * 256 + t;
-            const int row = id / CPR, c = id - row * CPR;
-            if (id < NCH) {
-                *reinterpret_cast<uint4*>(dK + row * KROW + c * 8) = kreg[r];
-                *reinterpret_cast<uint4*>(dV + row * VROW + c * 8) = vreg[r];
-            }
+            *reinterpret_cast<uint4*>(dK + lds_k[r]) = kreg[r];
+            *reinterpret_cast<uint4*>(dV + lds_v[r]) = vreg[r];
         }
     };
 
@@ -156,12 +180,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
             for (int qt = 0; qt < QT; ++qt) s[tl][qt] = f4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                const V8 kf = *reinterpret_cast<const V8*>(cK + (tl * 16 + fr) * KROW + ks * 32 + fg * 8);
+                const V8 kf = *reinterpret_cast<const V8*>(cK + (tl * 16 + fr) * KROW + k_slot<KROW>(tl * 16 + fr, ks * 4 + fg) * 8);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) s[tl][qt] = TT::mfma32(kf, qf[qt][ks], s[tl][qt]);
             }
             if (TAIL) {
-                const V4 kf = *reinterpret_cast<const V4*>(cK + (tl * 16 + fr) * KROW + NKS * 32 + fg * 4);
+                const V4 kf = *reinterpret_cast<const V4*>(cK + (tl * 16 + fr) * KROW + k_slot<KROW>(tl * 16 + fr, NKS * 4 + (fg >> 1)) * 8 + (fg & 1) * 4);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) s[tl][qt] = TT::mfma16(kf, qt4[qt], s[tl][qt]);
             }
@@ -171,14 +195,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         V8 pf[QT][2];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
+            if (tail) {
+#pragma unroll
+                for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kb * KVB + tl * 16 + fg * 4 + r >= nk) s[tl][qt][r] = -1e30f;
+            }
             float mx = -1e30f;
 #pragma unroll
             for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    if (tail && kb * KVB + tl * 16 + fg * 4 + r >= nk) s[tl][qt][r] = -1e30f;
-                    mx = fmaxf(mx, s[tl][qt][r]);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[tl][qt][r]);
             mx = quad_row_max(mx);
             const float m_new = fmaxf(m_run[qt], mx);
             // the running max rarely moves after the first key blocks: rescale only when some query's did
@@ -262,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 template <class TT, int DH, int QT>
 int launch(const AttnParams& p, hipStream_t stream) {
     constexpr int DKP = (DH / 32) * 32 + ((DH % 32) ? 16 : 0), DVP = round_up(DH, 16);
-    constexpr int KROW = DKP + 8, VROW = v_pitch_bytes(DVP) / 2;
+    constexpr int KROW = k_row_elems(DKP), VROW = v_pitch_bytes(DVP) / 2;
     constexpr size_t lds = (size_t)(2 * KVB * KROW + 2 * KVB * VROW) * 2;
     auto kern = attn_kernel<TT, DH, QT>;
     static bool attr_set = false;
@@ -283,7 +311,7 @@ int dispatch(const AttnParams& p, hipStream_t stream) {
         case 8: return launch<TT, 8, 2>(p, stream);
         case 16: return launch<TT, 16, 2>(p, stream);
         case 32: return launch<TT, 32, 2>(p, stream);
-        case 40: return launch<TT, 40, 2>(p, stream);
+        case 40: return p.variant == 1 ? launch<TT, 40, 2>(p, stream) : launch<TT, 40, 4>(p, stream);
         case 80: return launch<TT, 80, 2>(p, stream);
         case 160: return launch<TT, 160, 1>(p, stream);
         default: return VF_ERR_SHAPE;

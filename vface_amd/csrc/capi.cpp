@@ -72,7 +72,8 @@ int vface_attention(const void* Q, const void* K, const void* V, int64_t ldq, in
     p.Q = Q; p.K = K; p.V = V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.bsq = bsq; p.bsk = bsk; p.bsv = bsv;
     p.qk_map = qk_map; p.v_map = v_map; p.O = O; p.ldo = ldo; p.bso = bso;
     p.B = B; p.heads = heads; p.n = n; p.nk = nk; p.dh = dh; p.scale = scale;
-    return vf_launch_attention(p, dtype, S(stream));
+    p.variant = dtype >> 8;  // bits 8+ of dtype: schedule variant (benchmarking); 0 = automatic
+    return vf_launch_attention(p, dtype & 0xFF, S(stream));
 }
 
 int vface_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy, int M,
@@ -185,6 +186,17 @@ int vface_attn1_forward(const void* x, int64_t ldx, const void* Wqkv, const void
     po.rowbias = rowbias; po.rows_per_sample = n; po.ld_rowbias = ld_rowbias;
     po.residual = residual; po.ldr = ldr;
     return vf_launch_gemm(po, dtype, st);
+}
+
+int vface_temporal_gauss(const void* src, int64_t ld_src, int64_t fs_src, void* dst1, void* dst2, int64_t ld_dst,
+                         int64_t fs_dst, int F, int n, int C, int dtype, void* stream) {
+    return vf_launch_temporal_gauss(src, ld_src, fs_src, dst1, dst2, ld_dst, fs_dst, F, n, C, dtype, S(stream));
+}
+size_t vface_adain_workspace_bytes(int64_t rows, int C) { return rows > 0 && C > 0 ? vf_adain_workspace_bytes(rows, C) : 0; }
+int vface_adain_fusion(const void* a, int64_t lda, const void* b, int64_t ldb, void* dst, int64_t ldd, int64_t rows, int C,
+                       void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+    if (rows > 0 && C > 0 && workspace_bytes < vf_adain_workspace_bytes(rows, C)) return VFACE_ERR_WORKSPACE;
+    return vf_launch_adain(a, lda, b, ldb, dst, ldd, rows, C, workspace, dtype, S(stream));
 }
 
 int vface_timestep_embedding(const int64_t* t, void* out, int N, int dim, int dtype, void* stream) {

@@ -251,6 +251,150 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(const typename TT::elem*
     }
 }
 
+// ------------------------------------------------------------------------------------------ inactive hook modes
+// fusion="temporal" (pnp_utils.py:59-90,145-154): Gaussian-weighted mean over the FRAME axis of chunk 0's q|k
+// (window 5, sigma 1, renormalised at the clip ends), written to chunk 1 and chunk 2.  fp32 math, one rounding.
+template <class TT>
+__global__ __launch_bounds__(256) void temporal_gauss_kernel(const typename TT::elem* __restrict__ src, long ld_src,
+                                                             long fs_src, typename TT::elem* __restrict__ dst1,
+                                                             typename TT::elem* __restrict__ dst2, long ld_dst,
+                                                             long fs_dst, int F, int n, int C) {
+    using E = typename TT::elem;
+    using V8 = typename TT::v8;
+    const float g1 = 0.60653065971263342f, g2 = 0.13533528323661270f;  // exp(-0.5), exp(-2)
+    const float gs = 1.0f + 2.0f * g1 + 2.0f * g2;
+    const float w[5] = {g2 / gs, g1 / gs, 1.0f / gs, g1 / gs, g2 / gs};
+    const int c8 = C / 8, f = blockIdx.y;
+    const long total = (long)n * c8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long tok = i / c8;
+        const int cc = (int)(i - tok * c8) * 8;
+        float acc[8], wt = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int o = -2; o <= 2; ++o) {
+            const int ff = f + o;
+            if (ff < 0 || ff >= F) continue;
+            const V8 v = *reinterpret_cast<const V8*>(src + (long)ff * fs_src + tok * ld_src + cc);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w[o + 2] * to_f32(v[j]);
+            wt += w[o + 2];
+        }
+        V8 o8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = from_f32<E>(acc[j] / wt);
+        *reinterpret_cast<V8*>(dst1 + (long)f * fs_dst + tok * ld_dst + cc) = o8;
+        *reinterpret_cast<V8*>(dst2 + (long)f * fs_dst + tok * ld_dst + cc) = o8;
+    }
+}
+
+// fusion="adaIn" (face_swap_utils.py:372-389 with normalized=True): per token, AdaIN of the structure row `a`
+// to the own row `b` over the channel axis (unbiased std), then the whole tensor is divided by its GLOBAL
+// unbiased std.  Pass 1: one wave per token row writes the fused row (fp32) and block partial (sum, sumsq);
+// pass 2 (adain_scale) folds the partials in fp64 and writes fused / (std + 1e-5) in the 16-bit type.
+template <class TT, int CH8>
+__global__ __launch_bounds__(256) void adain_rows_kernel(const typename TT::elem* __restrict__ a, long lda,
+                                                         const typename TT::elem* __restrict__ b, long ldb,
+                                                         float* __restrict__ fused, long ldf, int rows, int C,
+                                                         double* __restrict__ partial) {
+    using E = typename TT::elem;
+    using V8 = typename TT::v8;
+    __shared__ double red[8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wv;
+    double bs = 0.0, bq = 0.0;
+    if (row < rows) {
+        float va[CH8][8], vb[CH8][8];
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH8; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < C) {
+                const V8 ta = *reinterpret_cast<const V8*>(a + (long)row * lda + c);
+                const V8 tb = *reinterpret_cast<const V8*>(b + (long)row * ldb + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { va[i][j] = to_f32(ta[j]); vb[i][j] = to_f32(tb[j]); sa += va[i][j]; sb += vb[i][j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) va[i][j] = vb[i][j] = 0.f;
+            }
+        }
+        const float ma = wave_sum(sa) / (float)C, mb = wave_sum(sb) / (float)C;
+        float qa = 0.f, qb = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH8; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < C) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float da = va[i][j] - ma, db = vb[i][j] - mb;
+                    qa += da * da; qb += db * db;
+                }
+            }
+        }
+        const float sda = sqrtf(wave_sum(qa) / (float)(C - 1)), sdb = sqrtf(wave_sum(qb) / (float)(C - 1));
+        const float k = sdb / (sda + 1e-5f);
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < CH8; ++i) {
+            const int c = (i * 64 + lane) * 8;
+            if (c < C) {
+                float o[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { o[j] = (va[i][j] - ma) * k + mb; s += o[j]; q += o[j] * o[j]; }
+                *reinterpret_cast<float4*>(fused + (long)row * ldf + c) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(fused + (long)row * ldf + c + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
+        }
+        bs = (double)wave_sum(s); bq = (double)wave_sum(q);
+    }
+    if (lane == 0) { red[2 * wv] = bs; red[2 * wv + 1] = bq; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = red[0] + red[2] + red[4] + red[6];
+        partial[2 * blockIdx.x + 1] = red[1] + red[3] + red[5] + red[7];
+    }
+}
+
+__global__ void adain_reduce_kernel(const double* __restrict__ partial, int nblocks, double count, float* __restrict__ inv) {
+    __shared__ double ss[256], qq[256];
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += 256) { s += partial[2 * i]; q += partial[2 * i + 1]; }
+    ss[threadIdx.x] = s; qq[threadIdx.x] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { ss[threadIdx.x] += ss[threadIdx.x + o]; qq[threadIdx.x] += qq[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = ss[0] / count;
+        double var = (qq[0] - count * mean * mean) / (count - 1.0);  // unbiased, as torch.std
+        if (var < 0.0) var = 0.0;
+        inv[0] = (float)(1.0 / (sqrt(var) + 1e-5));
+    }
+}
+
+template <class TT>
+__global__ void adain_scale_kernel(const float* __restrict__ fused, long ldf, const float* __restrict__ inv,
+                                   typename TT::elem* __restrict__ dst, long ldd, long rows, int C) {
+    using E = typename TT::elem;
+    using V8 = typename TT::v8;
+    const int c8 = C / 8;
+    const float k = inv[0];
+    const long total = rows * c8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c8;
+        const int c = (int)(i - r * c8) * 8;
+        const float4 x0 = *reinterpret_cast<const float4*>(fused + r * ldf + c);
+        const float4 x1 = *reinterpret_cast<const float4*>(fused + r * ldf + c + 4);
+        V8 o;
+        o[0] = from_f32<E>(x0.x * k); o[1] = from_f32<E>(x0.y * k); o[2] = from_f32<E>(x0.z * k); o[3] = from_f32<E>(x0.w * k);
+        o[4] = from_f32<E>(x1.x * k); o[5] = from_f32<E>(x1.y * k); o[6] = from_f32<E>(x1.z * k); o[7] = from_f32<E>(x1.w * k);
+        *reinterpret_cast<V8*>(dst + r * ldd + c) = o;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ small ops
 // util.py:151-171: [cos(t * f_i) | sin(t * f_i)], f_i = exp(-ln(10000) * i / half)
 template <class TT>
@@ -548,6 +692,53 @@ int vf_launch_copy2d(const void* src, long lds_, void* dst, long ldd, long rows,
     DISPATCH_DTYPE(dtype, {
         using E = typename TT::elem;
         hipLaunchKernelGGL((copy2d_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, stream, (const E*)src, lds_, (E*)dst, ldd, rows, cols);
+    });
+    return ok();
+}
+
+int vf_launch_temporal_gauss(const void* src, long ld_src, long fs_src, void* dst1, void* dst2, long ld_dst, long fs_dst,
+                             int F, int n, int C, int dtype, hipStream_t stream) {
+    if (!src || !dst1 || !dst2 || F <= 0 || n <= 0 || C <= 0) return VF_ERR_ARG;
+    if ((C & 7) || (ld_src & 7) || (ld_dst & 7) || (fs_src & 7) || (fs_dst & 7)) return VF_ERR_ALIGN;
+    if (((uintptr_t)src | (uintptr_t)dst1 | (uintptr_t)dst2) & 15) return VF_ERR_ALIGN;
+    const long total = (long)n * (C / 8);
+    dim3 grid(grid_for(total, 256, 2048), F);
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        hipLaunchKernelGGL((temporal_gauss_kernel<TT>), grid, dim3(256), 0, stream, (const E*)src, ld_src, fs_src, (E*)dst1,
+                           (E*)dst2, ld_dst, fs_dst, F, n, C);
+    });
+    return ok();
+}
+
+size_t vf_adain_workspace_bytes(long rows, int C) {
+    const long nblocks = (rows + 3) / 4;
+    return (size_t)rows * C * sizeof(float) + (size_t)nblocks * 2 * sizeof(double) + 256;
+}
+
+int vf_launch_adain(const void* a, long lda, const void* b, long ldb, void* dst, long ldd, long rows, int C, void* ws,
+                    int dtype, hipStream_t stream) {
+    if (!a || !b || !dst || !ws || rows <= 0 || C <= 1) return VF_ERR_ARG;
+    if ((C & 7) || (lda & 7) || (ldb & 7) || (ldd & 7)) return VF_ERR_ALIGN;
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)dst | (uintptr_t)ws) & 15) return VF_ERR_ALIGN;
+    if (C > 2048) return VF_ERR_SHAPE;
+    float* fused = (float*)ws;
+    const long nblocks = (rows + 3) / 4;
+    double* partial = (double*)((char*)ws + (((size_t)rows * C * sizeof(float) + 15) & ~(size_t)15));
+    float* inv = (float*)(partial + 2 * nblocks);
+    const int ch8 = (C + 511) / 512;
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        dim3 g((unsigned)nblocks);
+        switch (ch8) {
+            case 1: hipLaunchKernelGGL((adain_rows_kernel<TT, 1>), g, dim3(256), 0, stream, (const E*)a, lda, (const E*)b, ldb, fused, (long)C, (int)rows, C, partial); break;
+            case 2: hipLaunchKernelGGL((adain_rows_kernel<TT, 2>), g, dim3(256), 0, stream, (const E*)a, lda, (const E*)b, ldb, fused, (long)C, (int)rows, C, partial); break;
+            case 3: hipLaunchKernelGGL((adain_rows_kernel<TT, 3>), g, dim3(256), 0, stream, (const E*)a, lda, (const E*)b, ldb, fused, (long)C, (int)rows, C, partial); break;
+            default: hipLaunchKernelGGL((adain_rows_kernel<TT, 4>), g, dim3(256), 0, stream, (const E*)a, lda, (const E*)b, ldb, fused, (long)C, (int)rows, C, partial); break;
+        }
+        hipLaunchKernelGGL(adain_reduce_kernel, dim3(1), dim3(256), 0, stream, (const double*)partial, (int)nblocks, (double)rows * C, inv);
+        hipLaunchKernelGGL((adain_scale_kernel<TT>), dim3(grid_for(rows * (C / 8))), dim3(256), 0, stream, (const float*)fused, (long)C,
+                           (const float*)inv, (E*)dst, ldd, rows, C);
     });
     return ok();
 }

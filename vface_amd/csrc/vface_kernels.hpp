@@ -41,6 +41,7 @@ struct AttnParams {
     void* O; long ldo, bso;       // [B][n][ldo]
     int B, heads, n, nk, dh;      // nk = number of keys (== n for self-attention)
     float scale;
+    int variant;  // 0 = automatic; queries-per-wave variants for A/B benchmarking
 };
 int vf_launch_attention(const AttnParams& p, int dtype, hipStream_t stream);
 
@@ -67,3 +68,8 @@ int vf_launch_ddim_step(const float* eps, long lde, const float* x, const float*
 int vf_launch_copy2d(const void* src, long lds, void* dst, long ldd, long rows, int cols, int dtype,
                      hipStream_t stream);
 int vf_launch_cast(const float* src, void* dst, long count, int dtype, hipStream_t stream);
+int vf_launch_temporal_gauss(const void* src, long ld_src, long fs_src, void* dst1, void* dst2, long ld_dst, long fs_dst,
+                             int F, int n, int C, int dtype, hipStream_t stream);
+size_t vf_adain_workspace_bytes(long rows, int C);
+int vf_launch_adain(const void* a, long lda, const void* b, long ldb, void* dst, long ldd, long rows, int C, void* ws,
+                    int dtype, hipStream_t stream);

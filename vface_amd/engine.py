@@ -77,7 +77,8 @@ def _dev_flow(flow, device) -> Optional[torch.Tensor]:
 def plan_fusion(cfg: Optional[HookCfg], N: int, n: int) -> dict:
     """Map a hook configuration onto the kernels' mechanisms (pnp_utils.py:129-262).
     Returns fusion code, chunks, which folded weight to use, and the flow / v-broadcast options."""
-    pl = {"fusion": hip.FUSION_NONE, "chunks": 1, "wlin": None, "flow": None, "alpha": 0.8, "v_fixed": False}
+    pl = {"fusion": hip.FUSION_NONE, "chunks": 1, "wlin": None, "flow": None, "alpha": 0.8, "v_fixed": False,
+          "staged": None}
     if cfg is None or not cfg.switch_on:
         return pl
     chunks = cfg.chunks
@@ -103,11 +104,36 @@ def plan_fusion(cfg: Optional[HookCfg], N: int, n: int) -> dict:
     elif f == "mix":
         pl["fusion"], pl["wlin"] = hip.FUSION_LINEAR, ("mix", 0.5)
     elif f in ("temporal", "adaIn"):
-        raise NotImplementedError(f"fusion={f!r} has no HIP kernel yet (inactive in the shipped sampler, "
-                                  "ddim_w_inv.py:289-305); refusing to fall back to a CPU path")
+        pl["staged"] = f  # edits that are not a sample map or a folded weight: separate kernels on the qkv buffer
     else:
         pl["chunks"] = 1  # unknown fusion strings edit nothing in the reference
     return pl
+
+
+def staged_attn1(x16: torch.Tensor, wqkv, wo, bo, out, *, B, n, d, heads, mode, rowbias=None, residual=None):
+    """Hooked attn1 for fusion modes that edit q,k with their own kernels ("temporal", "adaIn"; pnp_utils.py:145-160):
+    full projection -> edit chunk 1 / chunk 2 q,k in the qkv buffer -> attention -> out-projection."""
+    dev, dt = x16.device, x16.dtype
+    c = B // 3
+    Fn = c * n
+    qkv = torch.empty(B * n, 3 * d, dtype=dt, device=dev)
+    hip.gemm(x16, wqkv, qkv, M=B * n, N=3 * d, K=x16.shape[1], lda=x16.stride(0), ldc=3 * d)
+    if mode == "temporal":
+        hip.temporal_gauss(qkv, qkv[Fn:], qkv[2 * Fn:], F=c, n=n, C_=2 * d, ld_src=3 * d, fs_src=n * 3 * d, ld_dst=3 * d,
+                           fs_dst=n * 3 * d)
+    elif mode == "adaIn":
+        for col in (0, d):  # q then k
+            for ch in (1, 2):
+                own = qkv[ch * Fn:(ch + 1) * Fn, col:col + d]
+                hip.adain_fusion(qkv[:Fn, col:col + d], own, own, rows=Fn, C_=d, lda=3 * d, ldb=3 * d, ldd=3 * d)
+    else:
+        raise ValueError(mode)
+    att = torch.empty(B * n, d, dtype=dt, device=dev)
+    hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=B, heads=heads, n=n, nk=n, dh=d // heads, ldq=3 * d, ldk=3 * d,
+                  ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d, ldo=d, bso=n * d, scale=(d // heads) ** -0.5)
+    hip.gemm(att, wo, out, M=B * n, N=out.shape[1], K=d, lda=d, ldc=out.stride(0), bias=bo, rowbias=rowbias,
+             rows_per_sample=n, residual=residual, ldr=residual.stride(0) if residual is not None else 0)
+    return out
 
 
 COMPUTE_DTYPE = torch.float16  # module-level default for standalone module calls
@@ -135,6 +161,9 @@ def attn_module_forward(mod, x: torch.Tensor, context: Optional[torch.Tensor], c
     out = torch.empty(B * n, mod.to_out[0].weight.shape[0], dtype=dt, device=dev)
     if context is None:
         pl = plan_fusion(cfg, B, n)
+        if pl["staged"]:
+            staged_attn1(x16, pk["wqkv"], pk["wo"], pk["bo"], out, B=B, n=n, d=d, heads=mod.heads, mode=pl["staged"])
+            return out.reshape(B, n, -1)
         chunks = pl["chunks"]
         wlin = None
         if pl["wlin"]:
@@ -335,6 +364,12 @@ class UNetEngine:
         d = p["c"]
         out = self._new(N * n, d)
         pl = plan_fusion(cfg, N, n)
+        if pl["staged"]:
+            if self.halo_exchange is not None:
+                raise NotImplementedError(f"fusion={pl['staged']!r} couples frames beyond one neighbour (temporal: +-2 "
+                                          "frames; adaIn: a global std) and is not sharded across GPUs")
+            return staged_attn1(xln, p["wqkv"], p["wo"]["w"], p["wo"]["b"], out, B=N, n=n, d=d, heads=heads,
+                                mode=pl["staged"], rowbias=a2vec, residual=resid)
         fusion, chunks, flow, alpha, v_fixed = pl["fusion"], pl["chunks"], pl["flow"], pl["alpha"], pl["v_fixed"]
         wlin = self._wlin(p, *pl["wlin"]) if pl["wlin"] else None
         qk_map = self._map("qk_replace", N, N // chunks) if fusion == hip.FUSION_REPLACE else None

@@ -41,6 +41,9 @@ SIGNATURES = {
     "vface_attn1_forward": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32,
                                       _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _sz, _vp, _i32, _vp]),
+    "vface_temporal_gauss": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "vface_adain_workspace_bytes": (_sz, [_i64, _i32]),
+    "vface_adain_fusion": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _sz, _i32, _vp]),
     "vface_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "vface_silu": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "vface_cast_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
@@ -141,10 +144,10 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, B: int, heads: int, n: int,
               nk: int, dh: int, ldq: int, ldk: int, ldv: int, bsq: int, bsk: int, bsv: int, ldo: int, bso: int,
-              scale: float, qk_map=None, v_map=None):
+              scale: float, qk_map=None, v_map=None, variant: int = 0):
     lib = load()
     rc = lib.vface_attention(_p(q), _p(k), _p(v), ldq, ldk, ldv, bsq, bsk, bsv, _p(qk_map), _p(v_map), _p(out), ldo,
-                             bso, B, heads, n, nk, dh, scale, dtype_code(out.dtype), _stream())
+                             bso, B, heads, n, nk, dh, scale, dtype_code(out.dtype) | (variant << 8), _stream())
     _check(rc, "vface_attention")
 
 
@@ -243,3 +246,17 @@ def ddim_step(eps, x, inv, x_prev, *, F, C_, hw, lde, scale, a_t, a_prev, sigma_
 def copy2d(src, dst, *, rows, cols, ld_src, ld_dst):
     rc = load().vface_copy2d(_p(src), ld_src, _p(dst), ld_dst, rows, cols, dtype_code(src.dtype), _stream())
     _check(rc, "vface_copy2d")
+
+
+def temporal_gauss(src, dst1, dst2, *, F, n, C_, ld_src, fs_src, ld_dst, fs_dst):
+    rc = load().vface_temporal_gauss(_p(src), ld_src, fs_src, _p(dst1), _p(dst2), ld_dst, fs_dst, F, n, C_,
+                                     dtype_code(src.dtype), _stream())
+    _check(rc, "vface_temporal_gauss")
+
+
+def adain_fusion(a, b, dst, *, rows, C_, lda, ldb, ldd):
+    lib = load()
+    ws = torch.empty(int(lib.vface_adain_workspace_bytes(rows, C_)), dtype=torch.uint8, device=a.device)
+    rc = lib.vface_adain_fusion(_p(a), lda, _p(b), ldb, _p(dst), ldd, rows, C_, _p(ws), ws.numel(), dtype_code(a.dtype),
+                                _stream())
+    _check(rc, "vface_adain_fusion")
