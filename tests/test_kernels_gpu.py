@@ -26,7 +26,7 @@ def rnd(shape, seed, dt, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dt)
 
 
-VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7, 8]  # 0 = automatic schedule; 1..8 forced (include/vface_hip.h)
+VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]  # 0 = automatic schedule; 1..8 forced (include/vface_hip.h)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -69,7 +69,7 @@ def test_gemm_strided_views_rowbias_dual_source():
     assert got[:, :32].abs().max() == 0 and got[:, 32 + N:].abs().max() == 0  # nothing outside the view
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 5, 7])
+@pytest.mark.parametrize("variant", [0, 1, 3, 5, 7, 9])
 def test_gemm_geglu(variant):
     h = hip()
     dt = torch.float16

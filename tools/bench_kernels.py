@@ -36,7 +36,7 @@ def main():
     dt = torch.float16
     g = torch.Generator(device="cpu").manual_seed(0)
     rnd = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dt).to(DEV)
-    variants = {"auto": 0, "db128": 0x500, "db160": 0x600, "db128nox": 0x1500, "db160nox": 0x1600}
+    variants = {"auto": 0, "db128": 0x500, "db160": 0x600}
     if "conv" in a.what:
         print("== conv3x3 implicit GEMM (TFLOP/s median | best), variants:", list(variants))
         for (H, cin, cout, stride) in [(64, 320, 320, 1), (64, 640, 320, 1), (64, 960, 320, 1), (32, 640, 640, 1),
@@ -67,7 +67,7 @@ def main():
             fl = 2.0 * M * Nn * K
             row = f"{name0:8s} M{M:6d} N{Nn:5d} K{K:5d}: "
             for name, f in variants.items():
-                if geglu and name in ("db160", "db160nox"):
+                if geglu and name in ("db160", "db160nox", "pp160"):
                     continue
                 ff = f | (hip.EPI_GEGLU if geglu else 0)
                 med, best = timeit(lambda: hip.gemm(x, w, out, M=M, N=Nn, K=K, lda=K, ldc=out.shape[1], bias=bias, flags=ff))

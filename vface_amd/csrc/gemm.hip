@@ -69,36 +69,42 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         n0 = (g * GN + (rem - tm * gw)) * BN;
     }
 
-    const E* __restrict__ A = reinterpret_cast<const E*>(p.A);
-    const E* __restrict__ A2 = reinterpret_cast<const E*>(p.A2);
-    const E* __restrict__ Wt = reinterpret_cast<const E*>(p.Wt);
-    const E* zeros = reinterpret_cast<const E*>(p.zeros);
+    // Operands are read through buffer descriptors (guide T8): `buffer_load_dwordx4 ... offen lds` takes a 32-bit
+    // per-lane byte offset and returns zeros for any offset >= num_records, so a padding tap / tile tail is one
+    // select of the out-of-range offset instead of a 64-bit pointer select, and the per-tile address update is one
+    // 32-bit add.  (Tensors are < 4 GiB: checked by the launcher.)
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : 0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wt), 0, (int)p.w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xFFFFFFF0u;  // >= num_records of every descriptor (launcher keeps sizes below it)
+    constexpr unsigned ES = sizeof(E);
 
     // staging map: slot = rr*256 + t -> row rr*32 + (t>>3), 16-B slot t&7 holds logical k-chunk schunk
     const int srow = t >> 3;
     const int schunk = (t & 7) ^ ((t >> 4) & 7);
 
-    const E* a_ptr[4];       // plain: row pointer at k = schunk*8; conv-fast: pointer of tap (0,0), ci = schunk*8
-    const E* a2_ptr[4];
-    unsigned a_mask[4];      // conv-fast: bit tap = tap in bounds; plain: row valid
-    int g_oy[4], g_ox[4];    // conv-generic
-    long g_img[4];
+    unsigned a_off[4];       // byte offset of (row, k = schunk*8) [plain] / of tap (0,0), channel schunk*8 [conv]
+    unsigned a2_off[4];
+    unsigned a_mask[4];      // conv-fast: bit tap = tap in bounds; else: row valid
+    int g_oy[4], g_ox[4];    // conv: top-left tap coordinates (generic / upsample paths)
+    unsigned g_img[4];       // conv: first pixel index of the row's image
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int m = m0 + rr * 32 + srow;
         const bool ok = m < p.M;
-        a2_ptr[rr] = zeros;
+        a2_off[rr] = OOB;
         g_oy[rr] = g_ox[rr] = 0; g_img[rr] = 0;
         if (MODE == MODE_PLAIN) {
-            a_ptr[rr] = A + (long)m * p.lda + schunk * 8;
+            a_off[rr] = ok ? (unsigned)(((long)m * p.lda + schunk * 8) * ES) : OOB;
             a_mask[rr] = ok ? 1u : 0u;
-            if (p.A2) a2_ptr[rr] = A2 + (long)(p.a2_row_mod > 0 ? m % p.a2_row_mod : m) * p.lda2 + schunk * 8;
+            if (p.A2 && ok) a2_off[rr] = (unsigned)(((long)(p.a2_row_mod > 0 ? m % p.a2_row_mod : m) * p.lda2 + schunk * 8) * ES);
         } else {
             const int hw = p.OH * p.OW;
             const int img = m / hw;
             const int rem = m - img * hw;
             const int oy = rem / p.OW, ox = rem - oy * p.OW;
             const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
+            g_oy[rr] = y0; g_ox[rr] = x0; g_img[rr] = (unsigned)(img * p.H * p.W);
             if (MODE == MODE_CONV_FAST) {
                 const int VH = p.upsample ? 2 * p.H : p.H, VW = p.upsample ? 2 * p.W : p.W;
                 unsigned mk = 0;
@@ -108,22 +114,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                     if (ok && (unsigned)vy < (unsigned)VH && (unsigned)vx < (unsigned)VW) mk |= 1u << tp;
                 }
                 a_mask[rr] = mk;
-                a_ptr[rr] = A + (((long)img * p.H + y0) * p.W + x0) * p.lda + schunk * 8;
-                g_oy[rr] = y0; g_ox[rr] = x0; g_img[rr] = (long)img * p.H * p.W;
+                // may wrap below zero for the halo row above the first image: only used when the tap's bit is set
+                a_off[rr] = (unsigned)(((((long)img * p.H + y0) * p.W + x0) * p.lda + schunk * 8) * ES);
             } else {
                 a_mask[rr] = ok ? 1u : 0u;
-                g_oy[rr] = y0; g_ox[rr] = x0; g_img[rr] = (long)img * p.H * p.W;
-                a_ptr[rr] = A;
+                a_off[rr] = 0;
             }
         }
     }
-    const E* b_ptr[BROUNDS];
-    bool b_ok[BROUNDS];
+    unsigned b_off[BROUNDS];
 #pragma unroll
     for (int rr = 0; rr < BROUNDS; ++rr) {
         const int n = n0 + rr * 32 + srow;
-        b_ok[rr] = n < p.N;
-        b_ptr[rr] = Wt + (long)n * p.ldw + schunk * 8;
+        b_off[rr] = n < p.N ? (unsigned)(((long)n * p.ldw + schunk * 8) * ES) : OOB;
     }
 
     auto stage = [&](int kt, int buf) {
@@ -131,15 +134,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         E* sB = sA + A_ELEMS;
         const int kbase = kt * BK;           // wave-uniform
         const int k = kbase + schunk * 8;
-        const bool kin = k < p.K;
         if (MODE == MODE_PLAIN) {
-            const bool second = A2 && kbase >= p.K1;
-            const long koff = second ? kbase - p.K1 : kbase;
+            const bool second = p.A2 && kbase >= p.K1;
+            const unsigned koff = (unsigned)(second ? kbase - p.K1 : kbase) * ES;
+            const bool kin = k < p.K;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const E* src = (second ? a2_ptr[rr] : a_ptr[rr]) + koff;
-                src = (a_mask[rr] && kin) ? src : zeros;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, 0, 0);
+                const unsigned base = second ? a2_off[rr] : a_off[rr];
+                const unsigned off = (kin && base != OOB) ? base + koff : OOB;
+                if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, off, 0, 0, 0);
             }
         } else if (MODE == MODE_CONV_FAST) {
             // K order for Cin % 64 == 0 is (64-channel chunk, tap, channel): the 9 taps of one chunk are
@@ -149,19 +153,19 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             const int ky = tap / 3, kx = tap - ky * 3;
             const int ci0 = cc * BK;
             if (!p.upsample) {
-                const long toff = ((long)ky * p.W + kx) * p.lda + ci0;
+                const unsigned toff = (unsigned)((((long)ky * p.W + kx) * p.lda + ci0) * ES);
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    const E* src = ((a_mask[rr] >> tap) & 1u) ? a_ptr[rr] + toff : zeros;
-                    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, 0, 0);
+                        const unsigned off = ((a_mask[rr] >> tap) & 1u) ? a_off[rr] + toff : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, off, 0, 0, 0);
                 }
             } else {
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
-                    const int sy = (g_oy[rr] + ky) >> 1, sx = (g_ox[rr] + kx) >> 1;
-                    const E* src = ((a_mask[rr] >> tap) & 1u)
-                                       ? A + (g_img[rr] + (long)sy * p.W + sx) * p.lda + ci0 + schunk * 8 : zeros;
-                    __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, 0, 0);
+                        const int sy = (g_oy[rr] + ky) >> 1, sx = (g_ox[rr] + kx) >> 1;
+                    const unsigned off = ((a_mask[rr] >> tap) & 1u)
+                                             ? (unsigned)((((long)g_img[rr] + (long)sy * p.W + sx) * p.lda + ci0 + schunk * 8) * ES) : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, off, 0, 0, 0);
                 }
             }
         } else {
@@ -169,20 +173,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             const int ci = k - tap * p.Cin;
             const int ky = tap / 3, kx = tap - ky * 3;
             const int VH = p.upsample ? 2 * p.H : p.H, VW = p.upsample ? 2 * p.W : p.W;
+            const bool kin = k < p.K;
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int vy = g_oy[rr] + ky, vx = g_ox[rr] + kx;
                 const bool ok = a_mask[rr] && kin && (unsigned)vy < (unsigned)VH && (unsigned)vx < (unsigned)VW;
                 const int sy = p.upsample ? (vy >> 1) : vy, sx = p.upsample ? (vx >> 1) : vx;
-                const E* src = ok ? A + (g_img[rr] + (long)sy * p.W + sx) * p.lda + ci : zeros;
-                __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, 0, 0);
+                const unsigned off = ok ? (unsigned)((((long)g_img[rr] + (long)sy * p.W + sx) * p.lda + ci) * ES) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, off, 0, 0, 0);
             }
         }
         const bool kwin = k < p.Kw;
+        const unsigned kboff = (unsigned)kbase * ES;
 #pragma unroll
         for (int rr = 0; rr < BROUNDS; ++rr) {
-            const E* src = (b_ok[rr] && kwin) ? b_ptr[rr] + kbase : zeros;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(sB + (rr * 256 + wave * 64) * 8), 16, 0, 0);
+            const unsigned off = (kwin && b_off[rr] != OOB) ? b_off[rr] + kboff : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(sB + (rr * 256 + wave * 64) * 8), 16, off, 0, 0, 0);
         }
     };
 
@@ -370,7 +376,8 @@ int pick_variant(const GemmParams& p) {
 
 }  // namespace
 
-int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream) {
+int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
+    GemmParams p = p_in;
     if (!p.A || !p.Wt || !p.C || !p.zeros) return VF_ERR_ARG;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VF_ERR_ARG;
     if ((p.K & 7) || (p.Kw & 7) || (p.lda & 7) || (p.ldw & 7) || (p.N & 3) || (p.ldc & 3)) return VF_ERR_ALIGN;
@@ -384,9 +391,21 @@ int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream) {
         if (p.Cin <= 0 || (p.Cin & 7) || p.K != 9 * p.Cin) return VF_ERR_SHAPE;
         if (p.stride != 1 && p.stride != 2) return VF_ERR_SHAPE;
     }
+    // extents of the operand views for the buffer descriptors (bytes; must stay below 4 GiB - 16)
+    {
+        const unsigned long es = 2, lim = 0xFFFFFFF0ul;
+        const unsigned long rows = p.mode == 1 ? (unsigned long)(p.M / (p.OH * p.OW)) * p.H * p.W : (unsigned long)p.M;
+        const unsigned long ab = ((rows - 1) * (unsigned long)p.lda + (p.mode == 1 ? p.Cin : (p.A2 ? p.K1 : p.K))) * es;
+        const unsigned long wb = ((unsigned long)(p.N - 1) * p.ldw + p.Kw) * es;
+        unsigned long a2b = 0;
+        if (p.A2) a2b = ((unsigned long)((p.a2_row_mod > 0 ? p.a2_row_mod : p.M) - 1) * p.lda2 + (p.K - p.K1)) * es;
+        if (ab >= lim || wb >= lim || a2b >= lim) return VF_ERR_SHAPE;
+        p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb; p.a2_bytes = (unsigned)a2b;
+    }
     const int variant = pick_variant(p);
-    if ((p.flags & GEMM_GEGLU) && (variant == 2 || variant == 4 || variant == 6 || variant == 8)) return VF_ERR_SHAPE;
+    if ((p.flags & GEMM_GEGLU) && (variant == 2 || variant == 4 || variant == 6 || variant == 8 || variant == 10)) return VF_ERR_SHAPE;
     if (variant >= 1 && variant <= 4) return vf_launch_gemm_pipe(p, dtype, variant, stream);
+    if (variant == 9 || variant == 10) return vf_launch_gemm_pp(p, dtype, variant, stream);
     if (dtype == VF_DTYPE_F16) return launch_gemm<F16>(p, variant, stream);
     if (dtype == VF_DTYPE_BF16) return launch_gemm<BF16>(p, variant, stream);
     return VF_ERR_DTYPE;

@@ -28,9 +28,11 @@ struct GemmParams {
     long ldc;
     const void* zeros;  // >= 16 zero bytes, 16-B aligned
     int flags;
+    unsigned a_bytes, a2_bytes, w_bytes;  // filled by the launcher: extents of the operand views
 };
 int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream);
+int vf_launch_gemm_pp(const GemmParams& p, int dtype, int variant, hipStream_t stream);
 
 struct AttnParams {
     const void* Q; const void* K; const void* V;  // [B][n][ld*], head h at column h*dh
