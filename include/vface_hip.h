@@ -60,11 +60,13 @@ const char* vface_error_string(int code);
  * GEGLU + FeedForward (attention.py:37-64), proj_in/proj_out (attention.py:261-276), ResBlock
  * emb_layers / skip_connection (openaimodel.py:218-241), time_embed (openaimodel.py:631-636).
  * A2 (optional): columns [K1, K) of the A operand come from A2[m % a2_row_mod][k - K1] (K1 % 64 == 0).
- * rowbias: fp32 [M/rows_per_sample][ld_rowbias] added per sample (time-embedding / cross-attention vector). */
+ * rowbias: fp32 [M/rows_per_sample][ld_rowbias] added per sample (time-embedding / cross-attention vector).
+ * colstats (optional): fp32 [ceil(M/64)][ld_colstats][2] receives, per 64-row slice and output column, the (sum, sum of
+ * squares) of the values as stored -- the statistics a following GroupNorm needs (vface_groupnorm_finalize_cols). */
 int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1, int a2_row_mod, const void* Wt,
                int64_t ldw, int M, int N, int K, const float* bias, const float* rowbias, int rows_per_sample,
                int ld_rowbias, const void* residual, int64_t ldr, void* C, int64_t ldc, const void* zeros, int flags,
-               int dtype, void* stream);
+               int dtype, float* colstats, int64_t ld_colstats, void* stream);
 
 /* Y = conv3x3(X) over NHWC, padding 1, stride 1|2, optional nearest x2 upsampling of X first, as an
  * implicit GEMM (nothing materialised).  Wt is packed [Cout][K = 9*Cin]: K order (64-channel chunk, tap, channel)
@@ -74,7 +76,7 @@ int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1,
 int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw, int Cout,
                   int stride, int upsample, const float* bias, const float* rowbias, int ld_rowbias,
                   const void* residual, int64_t ldr, void* Y, int64_t ldy, const void* zeros, int flags, int dtype,
-                  void* stream);
+                  float* colstats, int64_t ld_colstats, void* stream);
 
 /* O = softmax(Q K^T * scale) V per (sample, head), streaming softmax, no [n x n] matrix.
  * Replaces attention.py:206-220 / pnp_utils.py:270-285.  Output sample b uses q,k of sample qk_map[b] and
@@ -92,6 +94,9 @@ int vface_layernorm(const void* x, int64_t ldx, const float* gamma, const float*
 int vface_groupnorm_partial_floats(int nimg, int hw, int C, int groups);
 int vface_groupnorm_stats(const void* x, int64_t ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
                           float* stats, int dtype, void* stream);
+/* The same statistics from producer-side column sums (colstats of vface_gemm / vface_conv3x3); needs hw % 64 == 0. */
+int vface_groupnorm_finalize_cols(const float* colstats, int64_t ld_colstats, int nimg, int hw, int C, int groups, float eps,
+                                  float* stats, void* stream);
 /* y = (x - mean) * rstd * gamma + beta, then SiLU if `silu` (openaimodel.py:201-205,225-232). */
 int vface_groupnorm_apply(const void* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
                           void* y, int64_t ldy, int nimg, int hw, int C, int groups, int silu, int dtype, void* stream);

@@ -308,3 +308,29 @@ def test_attn1_forward_level0_vs_reference_golden(mode):
         flow = synth.synth_flow(F_ - 1, 64, 64).to(DEV) if mode == "flow_fix" else None
         h.attn1_forward(x, wqkv, wlin, wo, bo, out, fusion=h.FUSION_LINEAR, flow=flow, h=64, w=64, alpha=0.8, **kw)
     assert rel_l2(out[:, ::128].cpu().float(), g[mode]) < 1e-3
+
+
+@pytest.mark.parametrize("N_,cout", [(2, 320), (3, 640)])
+def test_conv_colstats_feed_groupnorm(N_, cout):
+    """Producer-side column statistics (conv epilogue) -> GroupNorm mean/rstd, against the stand-alone statistics kernel
+    and torch."""
+    h = hip()
+    from vface_amd.packing import pack_conv3x3
+    dt = torch.float16
+    cin, H = 64, 16
+    x = rnd((N_, cin, H, H), 1, dt)
+    w = rnd((cout, cin, 3, 3), 2, dt, 1 / math.sqrt(9 * cin))
+    b = rnd((cout,), 3, torch.float32, 0.1)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wide = torch.zeros(N_ * H * H, cout + 64, dtype=dt, device=DEV)       # the conv writes a column slice of a wider buffer
+    cs = torch.zeros(N_ * H * H // 64, cout + 64, 2, dtype=torch.float32, device=DEV)
+    h.conv3x3(xn, pack_conv3x3(w).to(DEV), wide[:, 32:], nimg=N_, H=H, W=H, cin=cin, cout=cout, ldx=cin, ldy=cout + 64,
+              bias=b.to(DEV), colstats=cs[:, 32:32 + cout])
+    y = wide[:, 32:32 + cout]
+    st_cols = h.groupnorm_stats_from_cols(cs[:, 32:32 + cout], nimg=N_, hw=H * H, C_=cout)
+    st_ref = h.groupnorm_stats(y, nimg=N_, hw=H * H, C_=cout, ldx=cout + 64)
+    assert torch.allclose(st_cols, st_ref, rtol=2e-4, atol=2e-5)
+    yf = y.float().cpu().reshape(N_, H * H, 32, cout // 32)
+    mean = yf.mean(dim=(1, 3))
+    assert torch.allclose(st_cols[..., 0].cpu(), mean, atol=2e-4)
+    assert cs[:, :32].abs().max() == 0 and cs[:, 32 + cout:].abs().max() == 0

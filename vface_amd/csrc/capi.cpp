@@ -39,8 +39,9 @@ const char* vface_error_string(int code) {
 int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1, int a2_row_mod, const void* Wt,
                int64_t ldw, int M, int N, int K, const float* bias, const float* rowbias, int rows_per_sample,
                int ld_rowbias, const void* residual, int64_t ldr, void* C, int64_t ldc, const void* zeros, int flags,
-               int dtype, void* stream) {
+               int dtype, float* colstats, int64_t ld_colstats, void* stream) {
     GemmParams p = plain_gemm(A, lda, Wt, ldw, M, N, K, bias, C, ldc, zeros);
+    p.colstats = colstats; p.ld_colstats = ld_colstats;
     p.A2 = A2; p.lda2 = lda2; p.K1 = K1; p.a2_row_mod = a2_row_mod;
     p.rowbias = rowbias; p.rows_per_sample = rows_per_sample; p.ld_rowbias = ld_rowbias;
     p.residual = residual; p.ldr = ldr; p.flags = flags;
@@ -50,7 +51,7 @@ int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1,
 int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw, int Cout,
                   int stride, int upsample, const float* bias, const float* rowbias, int ld_rowbias,
                   const void* residual, int64_t ldr, void* Y, int64_t ldy, const void* zeros, int flags, int dtype,
-                  void* stream) {
+                  float* colstats, int64_t ld_colstats, void* stream) {
     if (nimg <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return VFACE_ERR_ARG;
     if (stride != 1 && stride != 2) return VFACE_ERR_SHAPE;
     if (flags & VFACE_EPI_GEGLU) return VFACE_ERR_SHAPE;
@@ -62,6 +63,7 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
     p.M = nimg * p.OH * p.OW; p.N = Cout; p.K = 9 * Cin;
     p.bias = bias; p.rowbias = rowbias; p.rows_per_sample = p.OH * p.OW; p.ld_rowbias = ld_rowbias;
     p.residual = residual; p.ldr = ldr; p.C = Y; p.ldc = ldy; p.zeros = zeros; p.flags = flags;
+    p.colstats = colstats; p.ld_colstats = ld_colstats;
     return vf_launch_gemm(p, dtype, S(stream));
 }
 
@@ -89,6 +91,11 @@ int vface_groupnorm_partial_floats(int nimg, int hw, int C, int groups) {
 int vface_groupnorm_stats(const void* x, int64_t ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
                           float* stats, int dtype, void* stream) {
     return vf_launch_gn_stats(x, ldx, nimg, hw, C, groups, eps, partial, stats, dtype, S(stream));
+}
+
+int vface_groupnorm_finalize_cols(const float* colstats, int64_t ld_colstats, int nimg, int hw, int C, int groups, float eps,
+                                  float* stats, void* stream) {
+    return vf_launch_gn_finalize_cols(colstats, ld_colstats, nimg, hw, C, groups, eps, stats, S(stream));
 }
 
 int vface_groupnorm_apply(const void* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,

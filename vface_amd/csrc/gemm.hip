@@ -201,14 +201,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int nt = (p.K + BK - 1) / BK;
     const int fr = lane & 15, fq = lane >> 4;
 
-    // Fragment reads of BOTH k32 halves are issued up front (two register sets): the second half's LDS latency
-    // hides under the first half's MFMAs instead of stalling on lgkmcnt(0) four times per tile.
+    // Fragment reads are software-pipelined by hand (hipcc otherwise sinks every ds_read next to its MFMA and waits
+    // lgkmcnt(0) four times per tile): the k32-half-0 reads, the first half of its MFMAs, then the half-1 reads are
+    // issued UNDER the remaining half-0 MFMAs, so only the first read burst of a tile is exposed.
     auto compute = [&](int buf) {
         const E* sA = smem + buf * STAGE;
         const E* sB = sA + A_ELEMS;
         V8 af[2][4], bf[2][NT];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        auto read_half = [&](int kk) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = wm * 64 + i * 16 + fr;
@@ -221,15 +221,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                 const int slot = (kk * 4 + fq) ^ ((row >> 1) & 7);
                 bf[kk][j] = *reinterpret_cast<const V8*>(sB + row * BK + slot * 8);
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // keep all 2 x (4 + NT) reads ahead of the MFMAs (hipcc sinks them otherwise)
+        };
+        constexpr int JH = NT / 2;  // n-tiles whose half-0 MFMAs run before the half-1 reads are issued
+        read_half(0);
+        __builtin_amdgcn_sched_barrier(0);
         if (!(p.flags & GEMM_NO_SETPRIO)) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int j = 0; j < JH; ++j)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[0][j], af[0][i], acc[j][i]);
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[kk][j], af[kk][i], acc[j][i]);
+        for (int j = JH; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[0][j], af[0][i], acc[j][i]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[1][j], af[1][i], acc[j][i]);
         if (!(p.flags & GEMM_NO_SETPRIO)) __builtin_amdgcn_s_setprio(0);
     };
 
@@ -260,6 +271,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const E* res = reinterpret_cast<const E*>(p.residual);
     const bool geglu = p.flags & GEMM_GEGLU;
     const bool out32 = p.flags & GEMM_OUT_F32;
+    // optional per-channel (sum, sum of squares) of the STORED values over this wave's 64 rows: the GroupNorm that
+    // consumes this tensor gets its statistics from the producer instead of re-reading the tensor (util.py:214-216)
+    float* colstats = p.colstats;
+    float cs[NT][4], cq[NT][4];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[j][r] = cq[j][r] = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + fr;
@@ -294,6 +313,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = from_f32<E>(v[r]);
                     *reinterpret_cast<typename TT::v4*>(reinterpret_cast<E*>(p.C) + (long)m * p.ldc + nb) = o;
+                    if (colstats) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { const float f = to_f32(o[r]); cs[j][r] += f; cq[j][r] += f * f; }
+                    }
                 }
             }
         } else {
@@ -326,6 +349,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = from_f32<E>(a[r] * gelu_erf_f(g[r]));
                 *reinterpret_cast<typename TT::v4*>(reinterpret_cast<E*>(p.C) + (long)m * p.ldc + oc) = o;
+            }
+        }
+    }
+    if (colstats && !geglu && !out32) {
+        // fold the 16 rows-lanes of each column with DPP adds (quad_perm xor 1, xor 2, then row_ror 4, 8): no LDS
+        auto row16 = [](float v) {
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+            return v;
+        };
+        const long slice = (m0 + wm * 64) >> 6;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int nb = n0 + wn * (BN / 2) + j * 16 + fq * 4;
+            float s4[4], q4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s4[r] = row16(cs[j][r]); q4[r] = row16(cq[j][r]); }
+            if (fr == 0 && nb < p.N && m0 + wm * 64 < p.M) {
+                float* dst = colstats + (slice * p.ld_colstats + nb) * 2;
+                *reinterpret_cast<float4*>(dst) = make_float4(s4[0], q4[0], s4[1], q4[1]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(s4[2], q4[2], s4[3], q4[3]);
             }
         }
     }
@@ -386,6 +432,7 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     if (p.residual && (((uintptr_t)p.residual & 7) || (p.ldr & 3))) return VF_ERR_ALIGN;
     if (p.rowbias && (p.rows_per_sample <= 0 || (p.ld_rowbias & 3))) return VF_ERR_ARG;
     if ((p.flags & GEMM_GEGLU) && ((p.N & 31) || (p.flags & GEMM_OUT_F32) || p.residual || p.rowbias)) return VF_ERR_SHAPE;
+    if (p.colstats && ((p.flags & (GEMM_GEGLU | GEMM_OUT_F32)) || (p.ld_colstats & 1) || ((uintptr_t)p.colstats & 15))) return VF_ERR_ARG;
     if (p.A2 && (p.mode != 0 || p.K1 <= 0 || (p.K1 % BK) || (p.lda2 & 7) || ((uintptr_t)p.A2 & 15))) return VF_ERR_ALIGN;
     if (p.mode == 1) {
         if (p.Cin <= 0 || (p.Cin & 7) || p.K != 9 * p.Cin) return VF_ERR_SHAPE;
@@ -404,6 +451,7 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     }
     const int variant = pick_variant(p);
     if ((p.flags & GEMM_GEGLU) && (variant == 2 || variant == 4 || variant == 6 || variant == 8 || variant == 10)) return VF_ERR_SHAPE;
+    if (p.colstats && (variant < 5 || variant > 8)) return VF_ERR_SHAPE;
     if (variant >= 1 && variant <= 4) return vf_launch_gemm_pipe(p, dtype, variant, stream);
     if (variant == 9 || variant == 10) return vf_launch_gemm_pp(p, dtype, variant, stream);
     if (dtype == VF_DTYPE_F16) return launch_gemm<F16>(p, variant, stream);

@@ -127,6 +127,30 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk
 }
 
 // y = silu?( x * a[c] + b[c] ) with a = rstd * gamma, b = beta - mean * rstd * gamma held in registers per thread
+// (mean, rstd) from producer-side column statistics: colstats[slice][ld][2] with 64-row slices, hw % 64 == 0
+__global__ __launch_bounds__(64) void gn_finalize_cols_kernel(const float* __restrict__ colstats, long ld, int hw, int C,
+                                                              int groups, float eps, float* __restrict__ stats) {
+    const int img = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+    const int cpg = C / groups, spi = hw / 64;
+    const int total = cpg * spi;
+    double s = 0.0, q = 0.0;
+    for (int i = lane; i < total; i += 64) {
+        const int sl = i / cpg, c = g * cpg + (i - sl * cpg);
+        const float2 v = *reinterpret_cast<const float2*>(colstats + (((long)img * spi + sl) * ld + c) * 2);
+        s += v.x; q += v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (lane == 0) {
+        const double count = (double)hw * cpg;
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[((long)img * groups + g) * 2] = (float)mean;
+        stats[((long)img * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 template <class TT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const typename TT::elem* __restrict__ x, long ldx,
                                                        const float* __restrict__ stats,
@@ -740,5 +764,13 @@ int vf_launch_adain(const void* a, long lda, const void* b, long ldb, void* dst,
         hipLaunchKernelGGL((adain_scale_kernel<TT>), dim3(grid_for(rows * (C / 8))), dim3(256), 0, stream, (const float*)fused, (long)C,
                            (const float*)inv, (E*)dst, ldd, rows, C);
     });
+    return ok();
+}
+
+int vf_launch_gn_finalize_cols(const float* colstats, long ld, int nimg, int hw, int C, int groups, float eps, float* stats,
+                               hipStream_t stream) {
+    if (!colstats || !stats || nimg <= 0 || hw <= 0 || C <= 0 || groups <= 0) return VF_ERR_ARG;
+    if ((hw & 63) || (C % groups) || ld < C) return VF_ERR_SHAPE;
+    hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(groups, nimg), dim3(64), 0, stream, colstats, ld, hw, C, groups, eps, stats);
     return ok();
 }

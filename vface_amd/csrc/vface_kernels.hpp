@@ -29,6 +29,8 @@ struct GemmParams {
     const void* zeros;  // >= 16 zero bytes, 16-B aligned
     int flags;
     unsigned a_bytes, a2_bytes, w_bytes;  // filled by the launcher: extents of the operand views
+    float* colstats;     // optional [ceil(M/64)][ld_colstats][2] per-64-row-slice column (sum, sumsq) of the stored values
+    long ld_colstats;
 };
 int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream);
@@ -49,6 +51,8 @@ int vf_launch_attention(const AttnParams& p, int dtype, hipStream_t stream);
 
 int vf_launch_layernorm(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, int M,
                         int C, float eps, int dtype, hipStream_t stream);
+int vf_launch_gn_finalize_cols(const float* colstats, long ld, int nimg, int hw, int C, int groups, float eps, float* stats,
+                               hipStream_t stream);
 int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
                        float* stats, int dtype, hipStream_t stream);
 int vf_gn_partial_floats(int nimg, int hw, int C, int groups);

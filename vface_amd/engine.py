@@ -39,12 +39,14 @@ class HookCfg:
 
 
 class Act:
-    """A 2-D view ``[rows, C]`` (stride ``(ld, 1)``) of a 16-bit device buffer, with its image geometry."""
-    __slots__ = ("t", "N", "H", "W")
+    """A 2-D view ``[rows, C]`` (stride ``(ld, 1)``) of a 16-bit device buffer, with its image geometry and,
+    when its producer emitted them, the per-64-row-slice column statistics ``cs`` ``[rows/64, C, 2]`` (fp32 view)
+    from which a following GroupNorm takes mean / rstd without re-reading the tensor."""
+    __slots__ = ("t", "N", "H", "W", "cs")
 
-    def __init__(self, t: torch.Tensor, N: int, H: int, W: int):
+    def __init__(self, t: torch.Tensor, N: int, H: int, W: int, cs: Optional[torch.Tensor] = None):
         assert t.dim() == 2 and t.stride(1) == 1
-        self.t, self.N, self.H, self.W = t, N, H, W
+        self.t, self.N, self.H, self.W, self.cs = t, N, H, W, cs
 
     @property
     def C(self):
@@ -322,31 +324,49 @@ class UNetEngine:
     def _new(self, rows: int, cols: int, dtype=None) -> torch.Tensor:
         return torch.empty(rows, cols, dtype=dtype or self.dtype, device=self.device)
 
+    def _new_target(self, rows: int, cols: int, hw: int):
+        """A fresh output buffer and, when the image size allows (hw % 64 == 0), its column-statistics buffer."""
+        return self._new(rows, cols), self._new_cs(rows, cols, hw)
+
+    def _new_cs(self, rows: int, cols: int, hw: int) -> Optional[torch.Tensor]:
+        if hw % 64 or cols % 4:
+            return None
+        return torch.empty(rows // 64, cols, 2, dtype=torch.float32, device=self.device)
+
     def _gemm(self, a: torch.Tensor, w: dict, out: torch.Tensor, **kw):
         K = a.shape[1]
         hip.gemm(a, w["w"], out, M=a.shape[0], N=w["w"].shape[0], K=K, lda=a.stride(0), ldc=out.stride(0),
                  ldw=w["w"].shape[1], bias=w.get("b"), **kw)
 
     def _gn(self, x: Act, gn, eps: float, silu: bool) -> Act:
-        st = hip.groupnorm_stats(x.t, nimg=x.N, hw=x.hw, C_=x.C, ldx=x.ld, eps=eps)
+        if x.cs is not None:
+            st = hip.groupnorm_stats_from_cols(x.cs, nimg=x.N, hw=x.hw, C_=x.C, eps=eps)
+        else:
+            st = hip.groupnorm_stats(x.t, nimg=x.N, hw=x.hw, C_=x.C, ldx=x.ld, eps=eps)
         y = self._new(x.M, x.C)
         hip.groupnorm_apply(x.t, st, gn[0], gn[1], y, nimg=x.N, hw=x.hw, C_=x.C, ldx=x.ld, ldy=x.C, silu=silu)
         return Act(y, x.N, x.H, x.W)
 
-    def _conv(self, x: Act, w: dict, out: Optional[torch.Tensor], stride=1, upsample=False, rowbias=None,
+    def _conv(self, x: Act, w: dict, tgt, stride=1, upsample=False, rowbias=None,
               residual: Optional[torch.Tensor] = None, out_f32=False) -> Act:
+        """``tgt``: None (allocate) or ``(out view, colstats view or None)``."""
         VH, VW = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
         OH, OW = (VH - 1) // stride + 1, (VW - 1) // stride + 1
-        if out is None:
-            out = self._new(x.N * OH * OW, w["cout"], torch.float32 if out_f32 else None)
+        if tgt is None:
+            if out_f32:
+                out, cs = self._new(x.N * OH * OW, w["cout"], torch.float32), None
+            else:
+                out, cs = self._new_target(x.N * OH * OW, w["cout"], OH * OW)
+        else:
+            out, cs = tgt
         assert x.C == w["cinp"], (x.C, w["cinp"])
         hip.conv3x3(x.t, w["w"], out, nimg=x.N, H=x.H, W=x.W, cin=w["cinp"], cout=w["cout"], ldx=x.ld,
                     ldy=out.stride(0), stride=stride, upsample=upsample, bias=w["b"], rowbias=rowbias,
                     residual=residual, ldr=residual.stride(0) if residual is not None else 0,
-                    flags=hip.EPI_OUT_F32 if out_f32 else 0)
-        return Act(out, x.N, OH, OW)
+                    flags=hip.EPI_OUT_F32 if out_f32 else 0, colstats=cs)
+        return Act(out, x.N, OH, OW, cs)
 
-    def _res(self, x: Act, p: dict, emb_all: torch.Tensor, out: Optional[torch.Tensor]) -> Act:
+    def _res(self, x: Act, p: dict, emb_all: torch.Tensor, out) -> Act:
         """ResBlock._forward (openaimodel.py:255-275), non-updown, no scale-shift."""
         h = self._gn(x, p["in_gn"], 1e-5, True)
         a, b = p["emb_slice"]
@@ -416,7 +436,7 @@ class UNetEngine:
                  rows_per_sample=n, residual=resid, ldr=resid.stride(0))
         return out
 
-    def _st(self, x: Act, p: dict, mod, a2_all: torch.Tensor, out: Optional[torch.Tensor]) -> Act:
+    def _st(self, x: Act, p: dict, mod, a2_all: torch.Tensor, tgt) -> Act:
         """SpatialTransformer.forward + BasicTransformerBlock._forward (attention.py:278-289, 239-243)."""
         N, n, c = x.N, x.hw, p["c"]
         g = self._gn(x, p["gn"], 1e-6, False)
@@ -437,10 +457,9 @@ class UNetEngine:
         hip.gemm(ln, p["ff1"]["w"], ff, M=x.M, N=8 * c, K=c, lda=c, ldc=4 * c, bias=p["ff1"]["b"], flags=hip.EPI_GEGLU)
         t2 = self._new(x.M, c)
         self._gemm(ff, p["ff2"], t2, residual=t1, ldr=c)
-        if out is None:
-            out = self._new(x.M, c)
-        self._gemm(t2, p["proj_out"], out, residual=x.t, ldr=x.ld)
-        return Act(out, x.N, x.H, x.W)
+        out, cs = self._new_target(x.M, c, x.hw) if tgt is None else tgt
+        self._gemm(t2, p["proj_out"], out, residual=x.t, ldr=x.ld, colstats=cs)
+        return Act(out, x.N, x.H, x.W, cs)
 
     # ------------------------------------------------------------------ the forward
     def embeddings(self, timesteps: torch.Tensor, context: torch.Tensor):
@@ -506,19 +525,26 @@ class UNetEngine:
             shapes.append((H, W, u.block_out_channels(block)))
         nb = len(blocks_in)
         h_ch = [u.block_out_channels(mid)] + [u.block_out_channels(b) for b in blocks_out[:-1]]
-        cats = []
+        cats, cats_cs = [], []
         for j in range(nb):  # output block j consumes cat([h_{j}, skip_{nb-1-j}])
             sh, sw, sc = shapes[nb - 1 - j]
-            cats.append(self._new(x.N * sh * sw, h_ch[j] + sc))
+            buf, cs = self._new_target(x.N * sh * sw, h_ch[j] + sc, sh * sw)
+            cats.append(buf)
+            cats_cs.append(cs)
+
+        def part(j, a, b):  # columns [a, b) of concat buffer j and of its statistics
+            cs = cats_cs[j]
+            return cats[j][:, a:b], (cs[:, a:b] if cs is not None else None)
+
         h = x
         for i, block in enumerate(blocks_in):
             j = nb - 1 - i
-            h = run(block, h, cats[j][:, h_ch[j]:])
-        h = run(mid, h, cats[0][:, :h_ch[0]])
+            h = run(block, h, part(j, h_ch[j], cats[j].shape[1]))
+        h = run(mid, h, part(0, 0, h_ch[0]))
         for j, block in enumerate(blocks_out):
             sh, sw, _ = shapes[nb - 1 - j]
-            inp = Act(cats[j], x.N, sh, sw)
-            tgt = cats[j + 1][:, :h_ch[j + 1]] if j + 1 < nb else None
+            inp = Act(cats[j], x.N, sh, sw, cats_cs[j])
+            tgt = part(j + 1, 0, h_ch[j + 1]) if j + 1 < nb else None
             h = run(block, inp, tgt)
         h = self._gn(h, P["out.gn"], 1e-5, True)
         return self._conv(h, P["out.conv"], None, out_f32=True).t

@@ -26,9 +26,10 @@ SIGNATURES = {
     "vface_abi_version": (C.c_int, []),
     "vface_error_string": (C.c_char_p, [_i32]),
     "vface_gemm": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp,
-                             _i64, _vp, _i64, _vp, _i32, _i32, _vp]),
+                             _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp]),
     "vface_conv3x3": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp,
-                                _i64, _vp, _i64, _vp, _i32, _i32, _vp]),
+                                _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp]),
+    "vface_groupnorm_finalize_cols": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vface_attention": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32,
                                   _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
     "vface_layernorm": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _vp]),
@@ -122,23 +123,24 @@ def zeros_page(device) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------- wrappers
 def gemm(a: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldc: int,
          ldw: Optional[int] = None, bias=None, rowbias=None, rows_per_sample: int = 1, residual=None, ldr: int = 0,
-         a2=None, lda2: int = 0, k1: int = 0, a2_row_mod: int = 0, flags: int = 0):
+         a2=None, lda2: int = 0, k1: int = 0, a2_row_mod: int = 0, flags: int = 0, colstats=None):
     """out[M, :N] = a[M, :K] @ wt[:N, :K]^T (+ epilogue).  Tensors are device buffers; M/N/K/ld* describe the view."""
     lib = load()
     rc = lib.vface_gemm(_p(a), lda, _p(a2), lda2, k1, a2_row_mod, _p(wt), ldw if ldw is not None else K, M, N, K,
                         _p(bias), _p(rowbias), rows_per_sample, rowbias.stride(0) if rowbias is not None else 0,
                         _p(residual), ldr, _p(out), ldc, _p(zeros_page(a.device)), flags, dtype_code(a.dtype),
-                        _stream())
+                        _p(colstats), colstats.stride(0) // 2 if colstats is not None else 0, _stream())
     _check(rc, "vface_gemm")
 
 
 def conv3x3(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, H: int, W: int, cin: int, cout: int,
             ldx: int, ldy: int, stride: int = 1, upsample: bool = False, bias=None, rowbias=None, residual=None,
-            ldr: int = 0, flags: int = 0):
+            ldr: int = 0, flags: int = 0, colstats=None):
     lib = load()
     rc = lib.vface_conv3x3(_p(x), ldx, nimg, H, W, cin, _p(wt), 9 * cin, cout, stride, int(upsample), _p(bias),
                            _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, _p(residual), ldr, _p(out),
-                           ldy, _p(zeros_page(x.device)), flags, dtype_code(x.dtype), _stream())
+                           ldy, _p(zeros_page(x.device)), flags, dtype_code(x.dtype), _p(colstats),
+                           colstats.stride(0) // 2 if colstats is not None else 0, _stream())
     _check(rc, "vface_conv3x3")
 
 
@@ -166,6 +168,15 @@ def groupnorm_stats(x: torch.Tensor, *, nimg: int, hw: int, C_: int, ldx: int, g
     rc = lib.vface_groupnorm_stats(_p(x), ldx, nimg, hw, C_, groups, eps, _p(partial), _p(stats),
                                    dtype_code(x.dtype), _stream())
     _check(rc, "vface_groupnorm_stats")
+    return stats
+
+
+def groupnorm_stats_from_cols(colstats: torch.Tensor, *, nimg: int, hw: int, C_: int, groups: int = 32, eps: float = 1e-5):
+    """colstats: [nimg*hw/64, C(view), 2] fp32 view (row stride = 2 * ld)."""
+    stats = torch.empty(nimg, groups, 2, dtype=torch.float32, device=colstats.device)
+    rc = load().vface_groupnorm_finalize_cols(_p(colstats), colstats.stride(0) // 2, nimg, hw, C_, groups, eps, _p(stats),
+                                              _stream())
+    _check(rc, "vface_groupnorm_finalize_cols")
     return stats
 
 
