@@ -1,0 +1,88 @@
+"""Frame sharding on the MI355X box: two ranks (both on the one visible GPU, gloo for the boundary exchange through
+host staging) run the flow_fix UNet on 2 + 2 frames; every rank's eps must equal the unsharded 4-frame run bit for
+bit (same kernels, same arithmetic, only the halo frame arrives over the wire).  The production backend is "nccl"
+(RCCL over xGMI), one process per GPU -- see bench.py --gpus N --fusion flow_fix."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _cfg():
+    return dict(image_size=32, in_channels=9, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1],
+                num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                transformer_depth=1, context_dim=768, legacy=False)
+
+
+def _run(rank, world, port, outdir):
+    import torch.distributed as dist
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler
+    from vface_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from vface_amd.ldm.models.pnp_utils import register_spa_attn_injection as reg
+    from vface_amd.parallel import FrameShard
+    from vface_amd.utils import synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = "cuda:0"
+    total, h, w = 4, 32, 32
+    ldm = LatentDiffusion(_cfg())
+    synth.fill_module_(ldm.unet, seed=0)
+    ldm = ldm.to(dev)
+    sampler = DDIMSampler(ldm)
+    shard = FrameShard(rank, world, total, dist if world > 1 else None)
+    f0, fc = shard.first, shard.count
+    gflow = synth.synth_flow(total - 1, h, w)
+    xs = [synth.synth_normal(f"shard.x.{c}", (total, 9, h, w)) for c in range(3)]      # per chunk, per global frame
+    cs = [synth.synth_normal(f"shard.c.{c}", (total, 1, 768)) for c in range(3)]
+    x = torch.cat([t[f0:f0 + fc] for t in xs]).to(dev)
+    ctx = torch.cat([t[f0:f0 + fc] for t in cs]).to(dev)
+    tt = torch.full((3 * fc,), 481, dtype=torch.long, device=dev)
+    shard.install(ldm.unet.engine, gflow, dev)
+    flow = shard.local_flow(gflow)
+    reg(sampler, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True)
+    reg(sampler, 1, switch_on=True, input_blocks=True, middle_block=False, output_blocks=False, chunks=3,
+        flow=[f[None] for f in flow], block_indices=list(range(9)), fusion="flow_fix", split_ratio_fft=0.8, alpha=0.8)
+    out = ldm.apply_model(x, tt, ctx).float().cpu()
+    torch.save({"rank": rank, "f0": f0, "fc": fc, "out": out}, os.path.join(outdir, f"w{world}_r{rank}.pt"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_two_rank_flow_fix_equals_unsharded(tmp_path):
+    ctx = mp.get_context("spawn")
+    outdir = str(tmp_path)
+    p = ctx.Process(target=_run, args=(0, 1, _free_port(), outdir))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    full = torch.load(os.path.join(outdir, "w1_r0.pt"))["out"]
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, outdir)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    for pr in procs:
+        pr.join(600)
+        assert pr.exitcode == 0
+    total = 4
+    res = [torch.load(os.path.join(outdir, f"w2_r{r}.pt")) for r in range(2)]
+    for d in res:
+        rank, f0, fc, out = d["rank"], d["f0"], d["fc"], d["out"]
+        ref = torch.cat([full[c * total + f0:c * total + f0 + fc] for c in range(3)])
+        diff = (out - ref).abs()
+        per = diff.reshape(3, fc, -1).amax(-1)
+        print(f"rank {rank}: max diff {diff.max():.3e}; per (chunk, frame): {per.tolist()}")
+        assert torch.equal(out, ref), f"rank {rank}: max diff {diff.max()}"

@@ -252,3 +252,24 @@ def test_flow_resolution_mismatch_raises_like_reference(small):
                        inverse_results_dir={}, verbose=False, unconditional_guidance_scale=3.0,
                        unconditional_conditioning=cc, x_T=z, flow=[torch.zeros(1, 2, 8 * h, 8 * w)],
                        test_model_kwargs={"inpaint_image": z, "inpaint_mask": z[:, :1]})
+
+
+def test_bitwise_reproducible_and_batch_invariant(small):
+    """No atomics anywhere on the path: the same inputs give the same bits, and a frame's result does not depend on
+    which other frames share its batch (what makes frame sharding exact)."""
+    ldm, sampler, _ = small
+    h = w = 32
+    xs = [synth.synth_normal(f"shard.x.{c}", (4, 9, h, w)) for c in range(3)]
+    cs = [synth.synth_normal(f"shard.c.{c}", (4, 1, 768)) for c in range(3)]
+    _register(sampler, "in_fft", None)
+
+    def run(f0, fc):
+        x = torch.cat([t[f0:f0 + fc] for t in xs]).to(DEV)
+        ctx = torch.cat([t[f0:f0 + fc] for t in cs]).to(DEV)
+        tt = torch.full((3 * fc,), 481, dtype=torch.long, device=DEV)
+        return ldm.apply_model(x, tt, ctx).float().cpu()
+
+    a, b = run(0, 4), run(0, 4)
+    assert torch.equal(a, b)
+    c = run(1, 2)
+    assert torch.equal(c, torch.cat([a[k * 4 + 1:k * 4 + 3] for k in range(3)]))

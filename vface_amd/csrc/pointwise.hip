@@ -66,45 +66,58 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const typename TT::elem*
 // folds the partials in double precision into (mean, rstd).
 constexpr int GN_PIX = 128;  // pixels per workgroup
 
-// Thread t owns one 16-B channel chunk (t % CPB) and one pixel lane (t / CPB): its 8 channels' (sum, sumsq)
-// stay in registers across the pixel loop; one LDS atomic per channel per thread folds the pixel lanes.
+// Thread t owns one 16-B channel chunk (t % CPB) and one pixel lane (t / CPB): its 8 channels' (sum, sumsq) stay in
+// registers across the pixel loop; the pixel lanes are then folded through LDS in a FIXED order (no atomics), so the
+// statistics -- and everything downstream -- are bitwise reproducible.
 template <class TT>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const typename TT::elem* __restrict__ x, long ldx, int hw,
                                                          int C, int groups, float* __restrict__ partial) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
-    extern __shared__ float gn_acc[];  // [C][2]
+    extern __shared__ float gn_lds[];  // [PP][CPB*8][2] lane partials, then [C][2] channel sums
     const int img = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
     const int cpg = C / groups, c8 = C / 8;
-    for (int i = t; i < 2 * C; i += 256) gn_acc[i] = 0.f;
-    __syncthreads();
     const int p0 = chunk * GN_PIX, p1 = min(hw, p0 + GN_PIX);
     const E* base = x + (long)img * hw * ldx;
     const int CPB = min(c8, 256), PP = 256 / CPB;
     const int lanep = t / CPB, cl = t - lanep * CPB;
+    float* lane_part = gn_lds;                      // PP * CPB * 16 floats
+    float* chan = gn_lds + PP * CPB * 16;           // C * 2 floats
     for (int cb = 0; cb < c8; cb += CPB) {
         const int ch = cb + cl;
-        if (lanep < PP && ch < c8) {
-            float s[8], q[8];
+        float s[8], q[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+        for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+        if (lanep < PP && ch < c8) {
             for (int p = p0 + lanep; p < p1; p += PP) {
                 const V8 v = *reinterpret_cast<const V8*>(base + (long)p * ldx + ch * 8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { const float f = to_f32(v[j]); s[j] += f; q[j] += f * f; }
             }
+        }
+        if (lanep < PP) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                atomicAdd(&gn_acc[2 * (ch * 8 + j)], s[j]);
-                atomicAdd(&gn_acc[2 * (ch * 8 + j) + 1], q[j]);
+                lane_part[((lanep * CPB + cl) * 8 + j) * 2] = s[j];
+                lane_part[((lanep * CPB + cl) * 8 + j) * 2 + 1] = q[j];
             }
         }
+        __syncthreads();
+        // channel totals of this pass: one thread per channel, pixel lanes in ascending order
+        for (int i = t; i < CPB * 8; i += 256) {
+            const int c = cb * 8 + i;
+            if (c < C) {
+                float ss = 0.f, qq = 0.f;
+                for (int l = 0; l < PP; ++l) { ss += lane_part[(l * CPB * 8 + i) * 2]; qq += lane_part[(l * CPB * 8 + i) * 2 + 1]; }
+                chan[2 * c] = ss; chan[2 * c + 1] = qq;
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     float* out = partial + ((long)img * gridDim.x + chunk) * 2 * groups;
     for (int g = t; g < groups; g += 256) {
         float s = 0.f, q = 0.f;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += gn_acc[2 * c]; q += gn_acc[2 * c + 1]; }
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += chan[2 * c]; q += chan[2 * c + 1]; }
         out[2 * g] = s; out[2 * g + 1] = q;
     }
 }
@@ -594,7 +607,7 @@ int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int gro
     dim3 grid(nchunks, nimg);
     DISPATCH_DTYPE(dtype, {
         using E = typename TT::elem;
-        hipLaunchKernelGGL((gn_partial_kernel<TT>), grid, dim3(256), (size_t)2 * C * sizeof(float), stream, (const E*)x, ldx, hw, C, groups, partial);
+        hipLaunchKernelGGL((gn_partial_kernel<TT>), grid, dim3(256), (size_t)(2 * C + 256 * 16) * sizeof(float), stream, (const E*)x, ldx, hw, C, groups, partial);
     });
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg), dim3(64), 0, stream, (const float*)partial, nchunks, groups,
                        (double)hw * (C / groups), eps, stats);

@@ -49,6 +49,18 @@ class FrameShard:
         if self.world == 1:
             return None
         d = self.dist
+        if tail.is_cuda and d.get_backend() == "gloo":
+            # rehearsal on a box without one GPU per rank (gloo cannot move device memory peer to peer): the same
+            # protocol through host staging.  Production runs use backend "nccl" (RCCL over xGMI) below.
+            host = tail.detach().to("cpu").contiguous()
+            ops, halo = [], None
+            if self.rank + 1 < self.world:
+                ops.append(d.P2POp(d.isend, host, self.rank + 1))
+            if self.rank > 0:
+                halo = torch.empty_like(host)
+                ops.append(d.P2POp(d.irecv, halo, self.rank - 1))
+            works = d.batch_isend_irecv(ops) if ops else []
+            return ("host", works, (halo, tail.device))
         if self.mode == "allgather":
             t = tail.contiguous()
             bufs = torch.empty((self.world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -68,6 +80,11 @@ class FrameShard:
         if handle is None:
             return None
         kind, work, buf = handle
+        if kind == "host":
+            for w in work:
+                w.wait()
+            halo, dev = buf
+            return halo.to(dev) if halo is not None else None
         if kind == "ag":
             work.wait()
             return buf[self.rank - 1] if self.rank > 0 else None
