@@ -46,6 +46,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0;
+    if (p.flags & 0x4000) dbg_t0 = __builtin_amdgcn_s_memtime();
     // XCD-aware tile order (guide T1).  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2.
     // Every XCD gets a contiguous run of the tile sequence L (bijective for any grid size: q = nwg/8, r = nwg%8),
     // and L walks the tile grid in column groups of GN = 8 n-tiles, m-major inside a group: the ~64 tiles an XCD
@@ -247,6 +249,34 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     if (DB) {
         // two LDS stages: tile kt+1 is in flight while tile kt feeds the MFMAs; one barrier per K tile
         stage(0, 0);
+        if (p.flags & 0x4000) {
+            // DIAGNOSTIC build path (never used by the engine): s_memtime stamps around the three parts of a K tile;
+            // the sums go to the colstats pointer as [workgroup][wave][4] floats and feed no output value.
+            auto stamp = [&]() {
+                unsigned long long t;
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+                __builtin_amdgcn_sched_barrier(0);
+                return t;
+            };
+            unsigned long long tw = 0, ts = 0, tc = 0;
+            const unsigned long long t_begin = stamp();
+            for (int kt = 0; kt < nt; ++kt) {
+                const int cur = kt & 1;
+                const unsigned long long t0 = stamp();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const unsigned long long t1 = stamp();
+                if (kt + 1 < nt) stage(kt + 1, cur ^ 1);
+                const unsigned long long t2 = stamp();
+                compute(cur);
+                const unsigned long long t3 = stamp();
+                tw += t1 - t0; ts += t2 - t1; tc += t3 - t2;
+            }
+            const unsigned long long t_end = stamp();
+            dbg_t1 = t_begin; dbg_t2 = t_end;
+            (void)tw; (void)ts; (void)tc;
+        } else
         for (int kt = 0; kt < nt; ++kt) {
             const int cur = kt & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -265,6 +295,127 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         }
     }
 
+    // ---- wide epilogue (16-bit outputs, N % 8 == 0).  Measured: storing the accumulator layout directly -- 8 bytes per
+    // lane, 32-byte row fragments -- costs ~800 cycles per store instruction (16 k cycles per workgroup, more than three
+    // K tiles).  Instead each wave transposes its 64 x WN tile through LDS in two 32-row halves (fp32, so bias / row
+    // bias / residual are still summed before the single rounding) and writes whole 16-byte chunks of consecutive
+    // channels per lane: 8-10x fewer, fully coalesced stores; the residual is read the same way.
+    if (DB && !(p.flags & GEMM_OUT_F32) && !(p.N & 7) && !(p.flags & GEMM_NARROW_EPILOGUE)) {
+        constexpr int WN = NT * 16;
+        constexpr int SP = WN + 4;   // fp32 scratch row pitch (floats); +16 B keeps rows off the same banks
+        const bool gg = p.flags & GEMM_GEGLU;
+        const float* bias = p.bias;
+        const float* rowbias = p.rowbias;
+        const E* res = reinterpret_cast<const E*>(p.residual);
+        E* Cout = reinterpret_cast<E*>(p.C);
+        float* colstats = p.colstats;
+        const bool want_stats = colstats && !(p.flags & 0x4000);
+        __syncthreads();             // all waves are done with the last K tile: the stage buffers become scratch
+        float* scr = reinterpret_cast<float*>(smem_raw) + wave * (32 * SP);
+        const int OW = gg ? WN / 2 : WN;              // output columns of this wave
+        const int CH = OW >> 3;                       // 16-byte chunks per output row
+        const int LPR = 64 / CH;                      // rows covered per pass
+        const bool act = lane < LPR * CH;
+        const int rch = lane % CH, rrow = lane / CH;
+        const int ncol = (gg ? ((n0 + wn * WN) >> 1) : (n0 + wn * WN)) + rch * 8;   // first output channel of this lane
+        const int nout = gg ? (p.N >> 1) : p.N;
+        float s8[8], q8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = hh * 2 + ii;
+                const int m = m0 + wm * 64 + i * 16 + fr;
+                const float* rb = (rowbias && m < p.M) ? rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+                float* srow = scr + (ii * 16 + fr) * SP + fq * 4;
+                if (!gg) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int nb = n0 + wn * WN + j * 16 + fq * 4;
+                        float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+                        if (nb < p.N) {
+                            if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                            if (rb) { const float4 b = *reinterpret_cast<const float4*>(rb + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                        }
+                        *reinterpret_cast<float4*>(srow + j * 16) = v;
+                    }
+                } else if constexpr ((NT & 1) == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < NT / 2; ++jj) {
+                        const int nb = n0 + wn * WN + jj * 32 + fq * 4;   // packed index of the value rows; gates at +16
+                        float a[4], g[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { a[r] = acc[2 * jj][i][r]; g[r] = acc[2 * jj + 1][i][r]; }
+                        if (bias && nb < p.N) {
+                            const float4 ba = *reinterpret_cast<const float4*>(bias + nb);
+                            const float4 bg = *reinterpret_cast<const float4*>(bias + nb + 16);
+                            a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
+                            g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
+                        }
+                        *reinterpret_cast<float4*>(srow + jj * 16) =
+                            make_float4(a[0] * gelu_erf_f(g[0]), a[1] * gelu_erf_f(g[1]), a[2] * gelu_erf_f(g[2]), a[3] * gelu_erf_f(g[3]));
+                    }
+                }
+            }
+            // LDS operations of one wave execute in order: the reads below see the writes above, and the next
+            // half's writes cannot overtake these reads
+            if (act) {
+                for (int r = rrow; r < 32; r += LPR) {
+                    const int m = m0 + wm * 64 + hh * 32 + r;
+                    if (m < p.M && ncol < nout) {
+                        const float4 x0 = *reinterpret_cast<const float4*>(scr + r * SP + rch * 8);
+                        const float4 x1 = *reinterpret_cast<const float4*>(scr + r * SP + rch * 8 + 4);
+                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        if (res) {
+                            const V8 r8 = *reinterpret_cast<const V8*>(res + (long)m * p.ldr + ncol);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += to_f32(r8[e]);
+                        }
+                        V8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
+                        *reinterpret_cast<V8*>(Cout + (long)m * p.ldc + ncol) = o;
+                        if (want_stats) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] += f * f; }
+                        }
+                    }
+                }
+            }
+        }
+        if (want_stats) {
+            // fold the LPR row-lanes of every channel through the scratch (fixed order: reproducible)
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    scr[(rrow * OW + rch * 8 + e) * 2] = s8[e];
+                    scr[(rrow * OW + rch * 8 + e) * 2 + 1] = q8[e];
+                }
+            }
+            const long slice = (m0 + wm * 64) >> 6;
+            if (m0 + wm * 64 < p.M) {
+                for (int c = lane; c < OW; c += 64) {
+                    float ss = 0.f, qq = 0.f;
+                    for (int l = 0; l < LPR; ++l) { ss += scr[(l * OW + c) * 2]; qq += scr[(l * OW + c) * 2 + 1]; }
+                    const int n = n0 + wn * WN + c;
+                    if (n < p.N) *reinterpret_cast<float2*>(colstats + (slice * p.ld_colstats + n) * 2) = make_float2(ss, qq);
+                }
+            }
+        }
+        if (p.flags & 0x4000) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && colstats) {
+                float* d = colstats + ((long)blockIdx.x * 4 + wave) * 4;
+                d[0] = (float)(dbg_t1 - dbg_t0); d[1] = (float)(dbg_t2 - dbg_t1); d[2] = (float)(t3 - dbg_t2); d[3] = 1.f;
+            }
+        }
+        return;
+    }
+
     // ---- epilogue: lane holds rows n = nb + 0..3 (consecutive output channels) of column m
     const float* bias = p.bias;
     const float* rowbias = p.rowbias;
@@ -274,6 +425,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     // optional per-channel (sum, sum of squares) of the STORED values over this wave's 64 rows: the GroupNorm that
     // consumes this tensor gets its statistics from the producer instead of re-reading the tensor (util.py:214-216)
     float* colstats = p.colstats;
+    const bool want_stats = colstats && !(p.flags & 0x4000);
     float cs[NT][4], cq[NT][4];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
@@ -313,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = from_f32<E>(v[r]);
                     *reinterpret_cast<typename TT::v4*>(reinterpret_cast<E*>(p.C) + (long)m * p.ldc + nb) = o;
-                    if (colstats) {
+                    if (want_stats) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { const float f = to_f32(o[r]); cs[j][r] += f; cq[j][r] += f * f; }
                     }
@@ -351,6 +503,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                 *reinterpret_cast<typename TT::v4*>(reinterpret_cast<E*>(p.C) + (long)m * p.ldc + oc) = o;
             }
         }
+    }
+    if (p.flags & 0x4000) {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && colstats) {
+            float* d = colstats + ((long)blockIdx.x * 4 + wave) * 4;
+            d[0] = (float)(dbg_t1 - dbg_t0); d[1] = (float)(dbg_t2 - dbg_t1); d[2] = (float)(t3 - dbg_t2); d[3] = 0.f;
+        }
+        return;
     }
     if (colstats && !geglu && !out32) {
         // fold the 16 rows-lanes of each column with DPP adds (quad_perm xor 1, xor 2, then row_ror 4, 8): no LDS
