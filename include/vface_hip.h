@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VFACE_ABI_VERSION 1
+#define VFACE_ABI_VERSION 2
 
 #define VFACE_OK 0
 #define VFACE_ERR_ARG (-1)
@@ -66,7 +66,13 @@ const char* vface_error_string(int code);
 int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1, int a2_row_mod, const void* Wt,
                int64_t ldw, int M, int N, int K, const float* bias, const float* rowbias, int rows_per_sample,
                int ld_rowbias, const void* residual, int64_t ldr, void* C, int64_t ldc, const void* zeros, int flags,
-               int dtype, float* colstats, int64_t ld_colstats, void* stream);
+               int dtype, float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Bytes of device scratch a vface_gemm / vface_conv3x3 launch of this shape (M rows = nimg*OH*OW for a convolution,
+ * K = 9*Cin) can use to split its K loop over more workgroups when M x N alone would leave most of the 256 CUs idle
+ * (fp32 partial tiles summed in a fixed order: results stay reproducible).  0 = this shape is never split.
+ * `workspace` may be NULL or smaller: the launch then runs unsplit. */
+int64_t vface_splitk_workspace_bytes(int M, int N, int K, int flags);
 
 /* Y = conv3x3(X) over NHWC, padding 1, stride 1|2, optional nearest x2 upsampling of X first, as an
  * implicit GEMM (nothing materialised).  Wt is packed [Cout][K = 9*Cin]: K order (64-channel chunk, tap, channel)
@@ -76,7 +82,7 @@ int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1,
 int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw, int Cout,
                   int stride, int upsample, const float* bias, const float* rowbias, int ld_rowbias,
                   const void* residual, int64_t ldr, void* Y, int64_t ldy, const void* zeros, int flags, int dtype,
-                  float* colstats, int64_t ld_colstats, void* stream);
+                  float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* O = softmax(Q K^T * scale) V per (sample, head), streaming softmax, no [n x n] matrix.
  * Replaces attention.py:206-220 / pnp_utils.py:270-285.  Output sample b uses q,k of sample qk_map[b] and

@@ -20,7 +20,7 @@ def _declared():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(vface_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int64_t|int|size_t|const char\*)\s+(vface_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         decls[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
     return decls
@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     for name in decls:
         assert hasattr(lib, name), f"{name} declared in include/vface_hip.h but not exported"
     lib.vface_abi_version.restype = ctypes.c_int
-    assert lib.vface_abi_version() == 1
+    assert lib.vface_abi_version() == 2
 
 
 def test_ctypes_table_matches_header():

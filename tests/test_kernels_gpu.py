@@ -334,3 +334,55 @@ def test_conv_colstats_feed_groupnorm(N_, cout):
     mean = yf.mean(dim=(1, 3))
     assert torch.allclose(st_cols[..., 0].cpu(), mean, atol=2e-4)
     assert cs[:, :32].abs().max() == 0 and cs[:, 32 + cout:].abs().max() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cin,cout,H,nimg", [(1280, 1280, 8, 6), (640, 320, 8, 5), (2560, 1280, 8, 3)])
+def test_conv3x3_split_k(cin, cout, H, nimg):
+    """Shapes whose tile grid underfills the chip run split-K (fp32 partials + reduce pass with the epilogue): same
+    result as the one-pass launch up to the fp32 summation order, same column statistics contract."""
+    h = hip()
+    from vface_amd.packing import pack_conv3x3
+    dt = torch.float16
+    M = nimg * H * H
+    assert h.load().vface_splitk_workspace_bytes(M, cout, 9 * cin, 0) > 0
+    x = rnd((nimg, cin, H, H), 1, dt)
+    w = rnd((cout, cin, 3, 3), 2, dt, 1 / math.sqrt(9 * cin))
+    b = rnd((cout,), 3, torch.float32, 0.1)
+    rb = rnd((nimg, cout), 4, torch.float32)
+    res = rnd((nimg, H, H, cout), 5, dt)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1) + rb[:, :, None, None] + res.float().permute(0, 3, 1, 2)
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp = pack_conv3x3(w).to(DEV)
+    outs, stats = [], []
+    for split in (True, False):
+        out = torch.empty(nimg, H, H, cout, dtype=dt, device=DEV)
+        cs = torch.zeros(M // 64, cout, 2, dtype=torch.float32, device=DEV)
+        h.conv3x3(xn, wp, out, nimg=nimg, H=H, W=H, cin=cin, cout=cout, ldx=cin, ldy=cout, bias=b.to(DEV),
+                  rowbias=rb.to(DEV), residual=res.to(DEV), ldr=cout, colstats=cs, split_k=split)
+        assert rel_l2(out.cpu().float().permute(0, 3, 1, 2), ref) < TOL[dt]
+        outs.append(out); stats.append(cs)
+        yf = out.float().reshape(M // 64, 64, cout)
+        assert torch.allclose(cs[..., 0], yf.sum(1), rtol=1e-4, atol=1e-2)
+        assert torch.allclose(cs[..., 1], (yf * yf).sum(1), rtol=1e-4, atol=1e-2)
+    assert rel_l2(outs[0].float().cpu(), outs[1].float().cpu()) < 5e-4
+    again = torch.empty_like(outs[0])
+    h.conv3x3(xn, wp, again, nimg=nimg, H=H, W=H, cin=cin, cout=cout, ldx=cin, ldy=cout, bias=b.to(DEV),
+              rowbias=rb.to(DEV), residual=res.to(DEV), ldr=cout)
+    assert torch.equal(again, outs[0])        # fixed summation order: reproducible
+
+
+@pytest.mark.gpu
+def test_gemm_split_k_plain():
+    h = hip()
+    dt = torch.float16
+    M, N, K = 1536, 1280, 2560
+    assert h.load().vface_splitk_workspace_bytes(M, N, K, 0) > 0
+    a = rnd((M, K), 1, dt)
+    w = rnd((N, K), 2, dt, 1 / math.sqrt(K))
+    b = rnd((N,), 3, torch.float32, 0.1)
+    res = rnd((M, N), 4, dt)
+    ref = a.float() @ w.float().t() + b + res.float()
+    out = torch.empty(M, N, dtype=dt, device=DEV)
+    h.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), residual=res.to(DEV), ldr=N)
+    assert rel_l2(out.cpu().float(), ref) < TOL[dt]

@@ -39,9 +39,10 @@ const char* vface_error_string(int code) {
 int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1, int a2_row_mod, const void* Wt,
                int64_t ldw, int M, int N, int K, const float* bias, const float* rowbias, int rows_per_sample,
                int ld_rowbias, const void* residual, int64_t ldr, void* C, int64_t ldc, const void* zeros, int flags,
-               int dtype, float* colstats, int64_t ld_colstats, void* stream) {
+               int dtype, float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream) {
     GemmParams p = plain_gemm(A, lda, Wt, ldw, M, N, K, bias, C, ldc, zeros);
     p.colstats = colstats; p.ld_colstats = ld_colstats;
+    p.workspace = static_cast<float*>(workspace); p.workspace_bytes = workspace ? workspace_bytes : 0;
     p.A2 = A2; p.lda2 = lda2; p.K1 = K1; p.a2_row_mod = a2_row_mod;
     p.rowbias = rowbias; p.rows_per_sample = rows_per_sample; p.ld_rowbias = ld_rowbias;
     p.residual = residual; p.ldr = ldr; p.flags = flags;
@@ -51,7 +52,7 @@ int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1,
 int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw, int Cout,
                   int stride, int upsample, const float* bias, const float* rowbias, int ld_rowbias,
                   const void* residual, int64_t ldr, void* Y, int64_t ldy, const void* zeros, int flags, int dtype,
-                  float* colstats, int64_t ld_colstats, void* stream) {
+                  float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream) {
     if (nimg <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return VFACE_ERR_ARG;
     if (stride != 1 && stride != 2) return VFACE_ERR_SHAPE;
     if (flags & VFACE_EPI_GEGLU) return VFACE_ERR_SHAPE;
@@ -64,7 +65,13 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
     p.bias = bias; p.rowbias = rowbias; p.rows_per_sample = p.OH * p.OW; p.ld_rowbias = ld_rowbias;
     p.residual = residual; p.ldr = ldr; p.C = Y; p.ldc = ldy; p.zeros = zeros; p.flags = flags;
     p.colstats = colstats; p.ld_colstats = ld_colstats;
+    p.workspace = static_cast<float*>(workspace); p.workspace_bytes = workspace ? workspace_bytes : 0;
     return vf_launch_gemm(p, dtype, S(stream));
+}
+
+int64_t vface_splitk_workspace_bytes(int M, int N, int K, int flags) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return vf_splitk_workspace_bytes(M, N, K, flags);
 }
 
 int vface_attention(const void* Q, const void* K, const void* V, int64_t ldq, int64_t ldk, int64_t ldv, int64_t bsq,

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     int m0, n0;
     {
         const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
-        const int nwg = gridDim.x, id = blockIdx.x;
+        const int nwg = gridDim.x / p.split_k, id = blockIdx.x % nwg;   // split s of every tile = blocks [s*nwg, (s+1)*nwg)
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
         int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
         // implicit-conv K tiles already re-use their activation lines inside one workgroup (chunk-major K), and measured
@@ -200,7 +200,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nt = (p.K + BK - 1) / BK;
+    int kt_begin = 0, nt = (p.K + BK - 1) / BK;   // this workgroup's K tiles [kt_begin, nt)
+    if (p.split_k > 1) {
+        const int sk = blockIdx.x / (gridDim.x / p.split_k);
+        kt_begin = sk * p.kt_per_split;
+        nt = min(nt, kt_begin + p.kt_per_split);
+    }
     const int fr = lane & 15, fq = lane >> 4;
 
     // Fragment reads are software-pipelined by hand (hipcc otherwise sinks every ds_read next to its MFMA and waits
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 
     if (DB) {
         // two LDS stages: tile kt+1 is in flight while tile kt feeds the MFMAs; one barrier per K tile
-        stage(0, 0);
+        stage(kt_begin, 0);
         if (p.flags & 0x4000) {
             // DIAGNOSTIC build path (never used by the engine): s_memtime stamps around the three parts of a K tile;
             // the sums go to the colstats pointer as [workgroup][wave][4] floats and feed no output value.
@@ -261,8 +266,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             };
             unsigned long long tw = 0, ts = 0, tc = 0;
             const unsigned long long t_begin = stamp();
-            for (int kt = 0; kt < nt; ++kt) {
-                const int cur = kt & 1;
+            for (int kt = kt_begin; kt < nt; ++kt) {
+                const int cur = (kt - kt_begin) & 1;
                 const unsigned long long t0 = stamp();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
@@ -277,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             dbg_t1 = t_begin; dbg_t2 = t_end;
             (void)tw; (void)ts; (void)tc;
         } else
-        for (int kt = 0; kt < nt; ++kt) {
-            const int cur = kt & 1;
+        for (int kt = kt_begin; kt < nt; ++kt) {
+            const int cur = (kt - kt_begin) & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (kt + 1 < nt) stage(kt + 1, cur ^ 1);
@@ -286,13 +291,31 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         }
     } else {
         // one LDS stage, two barriers per K tile; latency is hidden by the other workgroups on the CU
-        for (int kt = 0; kt < nt; ++kt) {
+        for (int kt = kt_begin; kt < nt; ++kt) {
             stage(kt, 0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             compute(0);
             __syncthreads();
         }
+    }
+
+    // ---- split-K: raw fp32 partial tile; bias / row bias / residual / rounding / statistics run in splitk_reduce_kernel
+    if (p.split_k > 1) {
+        const int sk = blockIdx.x / (gridDim.x / p.split_k);
+        float* part = p.workspace + (long)sk * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int nb = n0 + wn * (BN / 2) + j * 16 + fq * 4;
+                if (nb < p.N)
+                    *reinterpret_cast<float4*>(part + (long)m * p.N + nb) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+            }
+        }
+        return;
     }
 
     // ---- wide epilogue (16-bit outputs, N % 8 == 0).  Measured: storing the accumulator layout directly -- 8 bytes per
@@ -539,10 +562,76 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     }
 }
 
+
+// Second pass of a split-K launch: C = round(sum_s partial[s] + bias + rowbias + residual), 8 channels per lane, the
+// same order of fp32 additions as the one-pass epilogue after the (split-ordered) K sum; per-64-row-slice column
+// statistics of the stored values in a fixed order (reproducible).  Grid (ceil(M/64), ceil(N/256)), 256 threads:
+// thread = (row group t>>5, 8-channel chunk t&31), rows rg + 8*it of the slice.
+template <class TT>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
+    using E = typename TT::elem;
+    using V8 = typename TT::v8;
+    __shared__ float red[8][256][2];
+    const int t = threadIdx.x, c8 = t & 31, rg = t >> 5;
+    const int n = blockIdx.y * 256 + c8 * 8;
+    const int mbase = blockIdx.x * 64;
+    const bool ncol_ok = n < p.N;
+    const E* res = reinterpret_cast<const E*>(p.residual);
+    E* Cout = reinterpret_cast<E*>(p.C);
+    float s8[8], q8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+    float b8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b8[e] = (p.bias && ncol_ok) ? p.bias[n + e] : 0.f;
+    for (int it = 0; it < 8; ++it) {
+        const int m = mbase + rg + it * 8;
+        if (m >= p.M || !ncol_ok) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        for (int s = 0; s < p.split_k; ++s) {
+            const float* src = p.workspace + ((long)s * p.M + m) * p.N + n;
+            const float4 x0 = *reinterpret_cast<const float4*>(src), x1 = *reinterpret_cast<const float4*>(src + 4);
+            v[0] += x0.x; v[1] += x0.y; v[2] += x0.z; v[3] += x0.w; v[4] += x1.x; v[5] += x1.y; v[6] += x1.z; v[7] += x1.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += b8[e];
+        if (p.rowbias) {
+            const float* rb = p.rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += rb[e];
+        }
+        if (res) {
+            const V8 r8 = *reinterpret_cast<const V8*>(res + (long)m * p.ldr + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += to_f32(r8[e]);
+        }
+        V8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
+        *reinterpret_cast<V8*>(Cout + (long)m * p.ldc + n) = o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] += f * f; }
+    }
+    if (p.colstats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[rg][c8 * 8 + e][0] = s8[e]; red[rg][c8 * 8 + e][1] = q8[e]; }
+        __syncthreads();
+        const int nn = blockIdx.y * 256 + t;
+        if (nn < p.N) {
+            float ss = 0.f, qq = 0.f;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) { ss += red[l][t][0]; qq += red[l][t][1]; }
+            *reinterpret_cast<float2*>(p.colstats + ((long)blockIdx.x * p.ld_colstats + nn) * 2) = make_float2(ss, qq);
+        }
+    }
+}
+
 template <class TT, int MODE, int NT, bool DB>
 int launch_one(const GemmParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT;
-    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN));
+    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.split_k);
     const size_t lds = (size_t)(DB ? 2 : 1) * (BM + BN) * BK * sizeof(typename TT::elem);
     auto kern = gemm_kernel<TT, MODE, NT, DB>;
     static bool attr_set = false;
@@ -553,6 +642,8 @@ int launch_one(const GemmParams& p, hipStream_t stream) {
         attr_set = true;
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    if (p.split_k > 1)
+        hipLaunchKernelGGL(splitk_reduce_kernel<TT>, dim3((p.M + 63) / 64, (p.N + 255) / 256), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
 }
 
@@ -582,10 +673,32 @@ int pick_variant(const GemmParams& p) {
     return n160 ? 6 : 5;
 }
 
+// Split-K factor for a launch whose tile grid would leave most of the 256 CUs (2 workgroups each) idle while every
+// workgroup walks a long K loop (the 8x8-level convolutions: 120 tiles x 180..360 K tiles).  Depends on the shape only.
+int split_for(int M, int N, int K, int flags) {
+    if (flags & (GEMM_GEGLU | GEMM_OUT_F32)) return 1;
+    if ((N & 7) || ((flags >> 8) & 0xF) == 0xF) return 1;
+    const bool n160 = (N % 160 == 0) && (N % 128 != 0);
+    const int bn = n160 ? 160 : 128;
+    const int tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
+    const int nt = (K + BK - 1) / BK;
+    if (tiles > 192 || nt < 16) return 1;
+    int s = 512 / tiles;
+    if (s > 8) s = 8;
+    if (s > nt / 8) s = nt / 8;
+    return s < 2 ? 1 : s;
+}
+
 }  // namespace
+
+long vf_splitk_workspace_bytes(int M, int N, int K, int flags) {
+    const int s = split_for(M, N, K, flags);
+    return s > 1 ? (long)s * M * N * 4 : 0;
+}
 
 int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     GemmParams p = p_in;
+    p.split_k = 1; p.kt_per_split = 0;
     if (!p.A || !p.Wt || !p.C || !p.zeros) return VF_ERR_ARG;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VF_ERR_ARG;
     if ((p.K & 7) || (p.Kw & 7) || (p.lda & 7) || (p.ldw & 7) || (p.N & 3) || (p.ldc & 3)) return VF_ERR_ALIGN;
@@ -612,6 +725,16 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb; p.a2_bytes = (unsigned)a2b;
     }
     const int variant = pick_variant(p);
+    if (p.workspace && (variant == 5 || variant == 6) && !((p.flags >> 8) & 0xF) && !(p.flags & 0x4000)) {
+        const int s = split_for(p.M, p.N, p.K, p.flags);
+        if (s > 1 && p.workspace_bytes >= (long)s * p.M * p.N * 4 && !((uintptr_t)p.workspace & 15) &&
+            !(p.residual && (((uintptr_t)p.residual & 15) || (p.ldr & 7))) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) {
+            const int nt = (p.K + BK - 1) / BK;
+            p.split_k = s;
+            p.kt_per_split = (nt + s - 1) / s;
+            if ((long)(s - 1) * p.kt_per_split >= nt) p.split_k = (nt + p.kt_per_split - 1) / p.kt_per_split;  // no empty split
+        }
+    }
     if ((p.flags & GEMM_GEGLU) && (variant == 2 || variant == 4 || variant == 6 || variant == 8 || variant == 10)) return VF_ERR_SHAPE;
     if (p.colstats && (variant < 5 || variant > 8)) return VF_ERR_SHAPE;
     if (variant >= 1 && variant <= 4) return vf_launch_gemm_pipe(p, dtype, variant, stream);

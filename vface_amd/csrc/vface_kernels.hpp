@@ -31,7 +31,13 @@ struct GemmParams {
     unsigned a_bytes, a2_bytes, w_bytes;  // filled by the launcher: extents of the operand views
     float* colstats;     // optional [ceil(M/64)][ld_colstats][2] per-64-row-slice column (sum, sumsq) of the stored values
     long ld_colstats;
+    // split-K (launcher-chosen when a workspace is supplied and the tile grid underfills the chip): fp32 partial tiles
+    // [split_k][M][N] in `workspace`, summed in split order by a second kernel that also runs the epilogue
+    float* workspace;
+    long workspace_bytes;
+    int split_k, kt_per_split;  // filled by the launcher
 };
+long vf_splitk_workspace_bytes(int M, int N, int K, int flags);
 int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream);
 int vf_launch_gemm_pp(const GemmParams& p, int dtype, int variant, hipStream_t stream);
