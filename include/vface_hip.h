@@ -89,7 +89,13 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
  * v of sample v_map[b] (NULL = identity): the zero-copy form of the hook's q/k/v row assignments. */
 int vface_attention(const void* Q, const void* K, const void* V, int64_t ldq, int64_t ldk, int64_t ldv, int64_t bsq,
                     int64_t bsk, int64_t bsv, const int32_t* qk_map, const int32_t* v_map, void* O, int64_t ldo,
-                    int64_t bso, int B, int heads, int n, int nk, int dh, float scale, int dtype, void* stream);
+                    int64_t bso, int B, int heads, int n, int nk, int dh, float scale, int dtype, int v_sets,
+                    int set_stride, void* stream);
+/* v_sets > 1 ("shared scores", the "replace" injection pnp_utils.py:133-143 / :259-262 where every chunk takes q,k of
+ * chunk 0): B counts the q/k samples; for g < v_sets output sample b + g*set_stride = softmax(q_b k_b^T * scale) v_s,
+ * s = v_map[b + g*set_stride] (or b + g*set_stride), the probabilities computed once per (b, head).  Supported for
+ * v_sets 2|3 and dh 8|16|32|40 (vface_attention_shared_scores_supported); other shapes: use qk_map. */
+int vface_attention_shared_scores_supported(int dh, int v_sets);
 
 /* y = LayerNorm(x) * gamma + beta, fp32 statistics (attention.py:231-233). */
 int vface_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy, int M,

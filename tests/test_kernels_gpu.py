@@ -165,6 +165,50 @@ def test_attention_sample_maps_and_spike():
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("dh,sets,n", [(40, 3, 500), (40, 2, 256), (8, 3, 100), (16, 2, 64), (32, 3, 320)])
+def test_attention_shared_scores(dt, dh, sets, n):
+    """"replace" injection: every chunk attends with q,k of chunk 0 -> one softmax per frame, `sets` value blocks.
+    Must equal the qk_map form of the same kernel family (and the torch reference), ragged n included."""
+    h = hip()
+    Fr, heads = 2, 8
+    B = sets * Fr
+    d = heads * dh
+    assert h.load().vface_attention_shared_scores_supported(dh, sets) == 1
+    qkv = rnd((B, n, 3 * d), 11, dt)
+    qkv[:, n // 2, d:2 * d] *= 4.0
+    qd = qkv.to(DEV)
+    scale = dh ** -0.5
+    kw = dict(heads=heads, n=n, nk=n, dh=dh, ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d,
+              bsv=n * 3 * d, ldo=d, bso=n * d, scale=scale)
+    out = torch.zeros(B, n, d, dtype=dt, device=DEV)
+    h.attention(qd, qd[:, :, d:], qd[:, :, 2 * d:], out, B=Fr, v_sets=sets, set_stride=Fr, **kw)
+    qk_map = (torch.arange(B) % Fr).to(torch.int32)
+    ref = _attn_ref(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], heads, scale, qk_map.long(), None)
+    assert rel_l2(out.cpu().float(), ref) < TOL[dt]
+    out2 = torch.zeros(B, n, d, dtype=dt, device=DEV)
+    h.attention(qd, qd[:, :, d:], qd[:, :, 2 * d:], out2, B=B, qk_map=qk_map.to(DEV), **kw)
+    assert rel_l2(out.cpu().float(), out2.cpu().float()) < 3e-4 * (8 if dt == torch.bfloat16 else 1)
+    # value remap composes with the shared scores
+    v_map = torch.arange(B, dtype=torch.int32).flip(0)
+    out3 = torch.zeros(B, n, d, dtype=dt, device=DEV)
+    h.attention(qd, qd[:, :, d:], qd[:, :, 2 * d:], out3, B=Fr, v_sets=sets, set_stride=Fr, v_map=v_map.to(DEV), **kw)
+    ref3 = _attn_ref(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], heads, scale, qk_map.long(), v_map.long())
+    assert rel_l2(out3.cpu().float(), ref3) < TOL[dt]
+
+
+def test_attention_shared_scores_rejects_unsupported():
+    h = hip()
+    dh, heads, n, B = 80, 8, 64, 3
+    d = heads * dh
+    q = torch.zeros(B, n, 3 * d, dtype=torch.float16, device=DEV)
+    out = torch.zeros(B, n, d, dtype=torch.float16, device=DEV)
+    with pytest.raises(h.VFaceHipError):
+        h.attention(q, q[:, :, d:], q[:, :, 2 * d:], out, B=1, v_sets=3, set_stride=1, heads=heads, n=n, nk=n, dh=dh,
+                    ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d, ldo=d, bso=n * d,
+                    scale=1.0)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("C", [64, 320, 640, 1280])
 def test_layernorm(dt, C):
     h = hip()

@@ -86,6 +86,11 @@ def main():
                                                          ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d,
                                                          ldo=d, bso=n * d, scale=dh ** -0.5, variant=var))
                 row += f"v{var} {fl / med / 1e9:6.0f}|{fl / best / 1e9:6.0f} ({med * 1e3:.0f} us)  "
+            if dh == 40:
+                med, best = timeit(lambda: hip.attention(qkv, qkv[:, :, d:], qkv[:, :, 2 * d:], out, B=N // 3, heads=8, n=n, nk=n, dh=dh,
+                                                         ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d,
+                                                         ldo=d, bso=n * d, scale=dh ** -0.5, v_sets=3, set_stride=N // 3))
+                row += f"shared3 ({med * 1e3:.0f} us)"
             print(row, flush=True)
     if "norm" in a.what:
         print("== GroupNorm / LayerNorm (GB/s of algorithmic bytes)")

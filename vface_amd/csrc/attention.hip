@@ -35,7 +35,11 @@ constexpr int v_pitch_bytes(int dvp) {
     return ((b / 32) & 1) ? b : b + 32;
 }
 
-template <class TT, int DH, int QT>
+// G > 1: "shared score" form for the hook's "replace" injection (pnp_utils.py:133-143, :259-262).  There every chunk
+// uses q,k of chunk 0, so softmax(q k^T) is the SAME matrix for the G chunks of a frame and only V differs: one
+// workgroup computes the probabilities once and multiplies them with the G value blocks side by side (a G*DH-wide
+// V tile), writing G output samples.  1/G of the QK^T MFMAs and of the exponentials.
+template <class TT, int DH, int QT, int G>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
@@ -45,16 +49,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     constexpr int NKS = DH / 32, TAIL = (DH % 32) ? 1 : 0;
     static_assert(DH % 32 == 0 || DH % 32 == 8 || DH % 32 == 16, "head dim");
     constexpr int DKP = NKS * 32 + TAIL * 16;
-    constexpr int DVP = round_up(DH, 16), NC = DVP / 16;
-    // spare V column (DVP > DH): filled with ones, so the MFMA that builds O also builds the softmax denominator
-    constexpr bool ONES = DVP > DH;
+    constexpr int DV = G * DH;                       // value columns side by side (G sets)
+    constexpr int DVP = round_up(DV, 16), NC = DVP / 16;
+    // spare V column (DVP > DV): filled with ones, so the MFMA that builds O also builds the softmax denominator
+    constexpr bool ONES = DVP > DV;
     // K block rows: 128 B (DKP <= 64) or 256 B (DKP <= 128), 16-B slots XOR-swizzled by the row so a ds_read_b128 of
     // 16 keys x one k-chunk is bank-conflict free (same rule as the GEMM tiles); larger head dims keep padded rows.
     constexpr int KROW = k_row_elems(DKP);           // elements
     constexpr int VROW = v_pitch_bytes(DVP) / 2;     // elements
-    constexpr int CPR = DH / 8;                      // 16-B chunks per row
-    constexpr int NCH = KVB * CPR;                   // chunks per K (or V) block
+    constexpr int CPR = DH / 8;                      // 16-B chunks per K row (and per V row of one set)
+    constexpr int NCH = KVB * CPR;                   // chunks per K block
     constexpr int SR = (NCH + 255) / 256;            // staging rounds
+    constexpr int CPRV = G * CPR, NCHV = KVB * CPRV, SRV = (NCHV + 255) / 256;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     E* sK = reinterpret_cast<E*>(smem_raw);          // [2][KVB][KROW]
@@ -65,10 +71,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     const int b = blockIdx.z, h = blockIdx.y;
     const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
     const int bqk = p.qk_map ? p.qk_map[b] : b;
-    const int bv = p.v_map ? p.v_map[b] : b;
+    const int gs = p.set_stride;                     // output / value sample of set g: b + g*gs
     const E* Qg = reinterpret_cast<const E*>(p.Q) + (long)bqk * p.bsq + h * DH;
     const E* Kg = reinterpret_cast<const E*>(p.K) + (long)bqk * p.bsk + h * DH;
-    const E* Vg = reinterpret_cast<const E*>(p.V) + (long)bv * p.bsv + h * DH;
     const int nk = p.nk;
 
     // zero LDS once: pad columns (DH..DKP of K, DH..DVP of V) are never written again
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     }
     if (ONES) {
         __syncthreads();
-        if (t < 2 * KVB) sV[t * VROW + DH] = (E)1.0f;
+        if (t < 2 * KVB) sV[t * VROW + DV] = (E)1.0f;
     }
 
     // Q fragments (B operand of S^T = K Q^T): lane (query fr, group fg) holds dh 32*ks + 8*fg .. +7
@@ -106,47 +111,56 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 
     // staging map, fixed for the whole walk: thread t moves 16-B chunk min(r*256 + t, NCH-1) of the K and V blocks
     // (the clamp makes the last round's surplus threads repeat chunk NCH-1: same bytes to the same place, no branch)
-    uint4 kreg[SR], vreg[SR];
+    uint4 kreg[SR], vreg[SRV];
     const E* kptr[SR];
-    const E* vptr[SR];
-    int srow[SR], lds_k[SR], lds_v[SR];
+    const E* vptr[SRV];
+    int srow[SR], lds_k[SR], srow_v[SRV], lds_v[SRV];
 #pragma unroll
     for (int r = 0; r < SR; ++r) {
         const int id = min(r * 256 + t, NCH - 1);
         const int row = id / CPR, c = id - row * CPR;
         srow[r] = row;
         kptr[r] = Kg + (long)row * p.ldk + c * 8;
-        vptr[r] = Vg + (long)row * p.ldv + c * 8;
         lds_k[r] = row * KROW + k_slot<KROW>(row, c) * 8;
-        lds_v[r] = row * VROW + c * 8;
+    }
+#pragma unroll
+    for (int r = 0; r < SRV; ++r) {
+        const int id = min(r * 256 + t, NCHV - 1);
+        const int row = id / CPRV, cc = id - row * CPRV;
+        const int g = cc / CPR, c = cc - g * CPR;
+        const int bo = b + g * gs;
+        const int bv = p.v_map ? p.v_map[bo] : bo;
+        srow_v[r] = row;
+        vptr[r] = reinterpret_cast<const E*>(p.V) + (long)bv * p.bsv + h * DH + (long)row * p.ldv + c * 8;
+        lds_v[r] = row * VROW + g * DH + c * 8;
     }
     const long kstep = (long)KVB * p.ldk, vstep = (long)KVB * p.ldv;
     auto load_block = [&](int kb) {
         if ((kb + 1) * KVB <= nk) {  // full block (wave-uniform): no per-key guard
 #pragma unroll
-            for (int r = 0; r < SR; ++r) {
-                kreg[r] = *reinterpret_cast<const uint4*>(kptr[r]);
-                vreg[r] = *reinterpret_cast<const uint4*>(vptr[r]);
-            }
+            for (int r = 0; r < SR; ++r) kreg[r] = *reinterpret_cast<const uint4*>(kptr[r]);
+#pragma unroll
+            for (int r = 0; r < SRV; ++r) vreg[r] = *reinterpret_cast<const uint4*>(vptr[r]);
         } else {
 #pragma unroll
-            for (int r = 0; r < SR; ++r) {
-                const bool ok = kb * KVB + srow[r] < nk;
-                kreg[r] = ok ? *reinterpret_cast<const uint4*>(kptr[r]) : make_uint4(0, 0, 0, 0);
-                vreg[r] = ok ? *reinterpret_cast<const uint4*>(vptr[r]) : make_uint4(0, 0, 0, 0);
-            }
+            for (int r = 0; r < SR; ++r)
+                kreg[r] = (kb * KVB + srow[r] < nk) ? *reinterpret_cast<const uint4*>(kptr[r]) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < SRV; ++r)
+                vreg[r] = (kb * KVB + srow_v[r] < nk) ? *reinterpret_cast<const uint4*>(vptr[r]) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < SR; ++r) { kptr[r] += kstep; vptr[r] += vstep; }
+        for (int r = 0; r < SR; ++r) kptr[r] += kstep;
+#pragma unroll
+        for (int r = 0; r < SRV; ++r) vptr[r] += vstep;
     };
     auto store_block = [&](int buf) {
         E* dK = sK + buf * KVB * KROW;
         E* dV = sV + buf * KVB * VROW;
 #pragma unroll
-        for (int r = 0; r < SR; ++r) {
-            *reinterpret_cast<uint4*>(dK + lds_k[r]) = kreg[r];
-            *reinterpret_cast<uint4*>(dV + lds_v[r]) = vreg[r];
-        }
+        for (int r = 0; r < SR; ++r) *reinterpret_cast<uint4*>(dK + lds_k[r]) = kreg[r];
+#pragma unroll
+        for (int r = 0; r < SRV; ++r) *reinterpret_cast<uint4*>(dV + lds_v[r]) = vreg[r];
     };
 
     f4_t o[NC][QT];
@@ -166,9 +180,28 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     store_block(0);
     __syncthreads();
 
+    // DIAGNOSTIC (compiled only with -DVFACE_ATTN_STAMPS; variant bit 8, never set by the engine): s_memtime stamps around the phases of a key block; the sums
+    // replace the first bytes of O as [workgroup][wave][8] floats.
+#ifdef VFACE_ATTN_STAMPS
+    const bool dbg = p.variant & 0x100;
+#else
+    constexpr bool dbg = false;
+#endif
+    unsigned long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+    auto stamp = [&](int ph) {
+        if (!dbg) return;
+        unsigned long long tn;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tn)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        if (ph >= 0) tph[ph] += tn - tlast;
+        tlast = tn;
+    };
+    stamp(-1);
     for (int kb = 0; kb < nblocks; ++kb) {
         const int cur = kb & 1;
         if (kb + 1 < nblocks) load_block(kb + 1);
+        stamp(0);
         const E* cK = sK + cur * KVB * KROW;
         const E* cV = sV + cur * KVB * VROW;
 
@@ -190,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
                 for (int qt = 0; qt < QT; ++qt) s[tl][qt] = TT::mfma16(kf, qt4[qt], s[tl][qt]);
             }
         }
+        stamp(1);
         // ---- online softmax (fp32)
         const bool tail = (kb + 1) * KVB > nk;
         V8 pf[QT][2];
@@ -242,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
                 pf[qt][st] = v;
             }
         }
+        stamp(2);
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -257,18 +292,29 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
                 for (int qt = 0; qt < QT; ++qt) o[c][qt] = TT::mfma32(vf, pf[qt][st], o[c][qt]);
             }
         }
+        stamp(3);
         if (kb + 1 < nblocks) store_block(cur ^ 1);
+        stamp(4);
         __syncthreads();
+        stamp(5);
+    }
+    if (dbg) {
+        if (lane == 0) {
+            float* d = reinterpret_cast<float*>(p.O) + (((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i] = (float)tph[i];
+        }
+        return;
     }
 
-    // ---- normalise and store: lane holds dh 16c + 4fg + r of query fr
+    // ---- normalise and store: lane holds value columns 16c + 4fg + r of query fr (set = column / DH)
     E* Og = reinterpret_cast<E*>(p.O) + (long)b * p.bso + h * DH;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         float l;
         if (ONES) {
-            // the denominator is row DH of O^T: held by lane group (DH % 16) / 4 in register 0 of tile DH / 16
-            l = __shfl(o[DH / 16][qt][0], fr + 16 * ((DH % 16) / 4), 64);
+            // the denominator is row DV of O^T: held by lane group (DV % 16) / 4 in register 0 of tile DV / 16
+            l = __shfl(o[DV / 16][qt][0], fr + 16 * ((DV % 16) / 4), 64);
         } else {
             l = quad_row_sum(l_run[qt]);
         }
@@ -277,22 +323,23 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         if (q >= p.n) continue;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int d = c * 16 + fg * 4;
-            if (d >= DH) continue;
+            const int d0 = c * 16 + fg * 4;
+            if (d0 >= DV) continue;
+            const int g = d0 / DH, d = d0 - g * DH;   // DH % 4 == 0: a lane's 4 columns stay inside one set
             V4 ov;
 #pragma unroll
             for (int r = 0; r < 4; ++r) ov[r] = from_f32<E>(o[c][qt][r] * inv);
-            *reinterpret_cast<V4*>(Og + (long)q * p.ldo + d) = ov;
+            *reinterpret_cast<V4*>(Og + (long)g * gs * p.bso + (long)q * p.ldo + d) = ov;
         }
     }
 }
 
-template <class TT, int DH, int QT>
+template <class TT, int DH, int QT, int G = 1>
 int launch(const AttnParams& p, hipStream_t stream) {
-    constexpr int DKP = (DH / 32) * 32 + ((DH % 32) ? 16 : 0), DVP = round_up(DH, 16);
+    constexpr int DKP = (DH / 32) * 32 + ((DH % 32) ? 16 : 0), DVP = round_up(G * DH, 16);
     constexpr int KROW = k_row_elems(DKP), VROW = v_pitch_bytes(DVP) / 2;
     constexpr size_t lds = (size_t)(2 * KVB * KROW + 2 * KVB * VROW) * 2;
-    auto kern = attn_kernel<TT, DH, QT>;
+    auto kern = attn_kernel<TT, DH, QT, G>;
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -307,6 +354,24 @@ int launch(const AttnParams& p, hipStream_t stream) {
 
 template <class TT>
 int dispatch(const AttnParams& p, hipStream_t stream) {
+    if (p.v_sets == 2) {
+        switch (p.dh) {
+            case 8: return launch<TT, 8, 2, 2>(p, stream);
+            case 16: return launch<TT, 16, 2, 2>(p, stream);
+            case 32: return launch<TT, 32, 2, 2>(p, stream);
+            case 40: return launch<TT, 40, 2, 2>(p, stream);
+            default: return VF_ERR_SHAPE;
+        }
+    }
+    if (p.v_sets == 3) {
+        switch (p.dh) {
+            case 8: return launch<TT, 8, 2, 3>(p, stream);
+            case 16: return launch<TT, 16, 2, 3>(p, stream);
+            case 32: return launch<TT, 32, 2, 3>(p, stream);
+            case 40: return launch<TT, 40, 2, 3>(p, stream);
+            default: return VF_ERR_SHAPE;
+        }
+    }
     switch (p.dh) {
         case 8: return launch<TT, 8, 2>(p, stream);
         case 16: return launch<TT, 16, 2>(p, stream);
@@ -320,7 +385,14 @@ int dispatch(const AttnParams& p, hipStream_t stream) {
 
 }  // namespace
 
-int vf_launch_attention(const AttnParams& p, int dtype, hipStream_t stream) {
+bool vf_attention_shared_scores_supported(int dh, int v_sets) {
+    return (v_sets == 2 || v_sets == 3) && (dh == 8 || dh == 16 || dh == 32 || dh == 40);
+}
+
+int vf_launch_attention(const AttnParams& p_in, int dtype, hipStream_t stream) {
+    AttnParams p = p_in;
+    if (p.v_sets <= 1) { p.v_sets = 1; p.set_stride = 0; }
+    else if (p.set_stride <= 0 || !vf_attention_shared_scores_supported(p.dh, p.v_sets)) return VF_ERR_SHAPE;
     if (!p.Q || !p.K || !p.V || !p.O) return VF_ERR_ARG;
     if (p.B <= 0 || p.heads <= 0 || p.n <= 0 || p.nk <= 0) return VF_ERR_ARG;
     if (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) return VF_ERR_ALIGN;

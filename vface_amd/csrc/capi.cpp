@@ -76,13 +76,19 @@ int64_t vface_splitk_workspace_bytes(int M, int N, int K, int flags) {
 
 int vface_attention(const void* Q, const void* K, const void* V, int64_t ldq, int64_t ldk, int64_t ldv, int64_t bsq,
                     int64_t bsk, int64_t bsv, const int32_t* qk_map, const int32_t* v_map, void* O, int64_t ldo,
-                    int64_t bso, int B, int heads, int n, int nk, int dh, float scale, int dtype, void* stream) {
+                    int64_t bso, int B, int heads, int n, int nk, int dh, float scale, int dtype, int v_sets,
+                    int set_stride, void* stream) {
     AttnParams p{};
+    p.v_sets = v_sets; p.set_stride = set_stride;
     p.Q = Q; p.K = K; p.V = V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.bsq = bsq; p.bsk = bsk; p.bsv = bsv;
     p.qk_map = qk_map; p.v_map = v_map; p.O = O; p.ldo = ldo; p.bso = bso;
     p.B = B; p.heads = heads; p.n = n; p.nk = nk; p.dh = dh; p.scale = scale;
     p.variant = dtype >> 8;  // bits 8+ of dtype: schedule variant (benchmarking); 0 = automatic
     return vf_launch_attention(p, dtype & 0xFF, S(stream));
+}
+
+int vface_attention_shared_scores_supported(int dh, int v_sets) {
+    return vf_attention_shared_scores_supported(dh, v_sets) ? 1 : 0;
 }
 
 int vface_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy, int M,
@@ -194,6 +200,10 @@ int vface_attn1_forward(const void* x, int64_t ldx, const void* Wqkv, const void
     a.v_map = v_fixed ? v_map : nullptr;
     a.O = att; a.ldo = d; a.bso = (long)n * d;
     a.B = B; a.heads = heads; a.n = n; a.nk = n; a.dh = d / heads;
+    if (fusion == VFACE_FUSION_REPLACE && vf_attention_shared_scores_supported(d / heads, chunks)) {
+        // every chunk attends with q,k of chunk 0 (pnp_utils.py:136-142): softmax once per frame, `chunks` value sets
+        a.qk_map = nullptr; a.B = (int)F; a.v_sets = chunks; a.set_stride = (int)F;
+    }
     a.scale = 1.0f / sqrtf((float)(d / heads));
     if ((rc = vf_launch_attention(a, dtype, st))) return rc;
     GemmParams po = plain_gemm(att, d, Wo, d, B * n, d, d, bo, out, ldo, zeros);

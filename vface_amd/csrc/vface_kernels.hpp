@@ -39,6 +39,7 @@ struct GemmParams {
 };
 long vf_splitk_workspace_bytes(int M, int N, int K, int flags);
 int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
+bool vf_attention_shared_scores_supported(int dh, int v_sets);
 int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream);
 int vf_launch_gemm_pp(const GemmParams& p, int dtype, int variant, hipStream_t stream);
 
@@ -52,6 +53,7 @@ struct AttnParams {
     int B, heads, n, nk, dh;      // nk = number of keys (== n for self-attention)
     float scale;
     int variant;  // 0 = automatic; queries-per-wave variants for A/B benchmarking
+    int v_sets, set_stride;  // > 1: B q/k samples; output (and value) sample of set g is b + g*set_stride, scores shared
 };
 int vf_launch_attention(const AttnParams& p, int dtype, hipStream_t stream);
 

@@ -32,7 +32,8 @@ SIGNATURES = {
     "vface_splitk_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
     "vface_groupnorm_finalize_cols": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vface_attention": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32,
-                                  _i32, _i32, _i32, _i32, _f32, _i32, _vp]),
+                                  _i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
+    "vface_attention_shared_scores_supported": (C.c_int, [_i32, _i32]),
     "vface_layernorm": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _vp]),
     "vface_groupnorm_partial_floats": (C.c_int, [_i32, _i32, _i32, _i32]),
     "vface_groupnorm_stats": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _vp]),
@@ -168,10 +169,13 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, B: int, heads: int, n: int,
               nk: int, dh: int, ldq: int, ldk: int, ldv: int, bsq: int, bsk: int, bsv: int, ldo: int, bso: int,
-              scale: float, qk_map=None, v_map=None, variant: int = 0):
+              scale: float, qk_map=None, v_map=None, variant: int = 0, v_sets: int = 1, set_stride: int = 0):
+    """``v_sets > 1``: B q/k samples, output sample ``b + g*set_stride`` uses v of that sample (through ``v_map``)
+    with the probabilities of q/k sample b, computed once (the "replace" injection)."""
     lib = load()
     rc = lib.vface_attention(_p(q), _p(k), _p(v), ldq, ldk, ldv, bsq, bsk, bsv, _p(qk_map), _p(v_map), _p(out), ldo,
-                             bso, B, heads, n, nk, dh, scale, dtype_code(out.dtype) | (variant << 8), _stream())
+                             bso, B, heads, n, nk, dh, scale, dtype_code(out.dtype) | (variant << 8), v_sets,
+                             set_stride, _stream())
     _check(rc, "vface_attention")
 
 

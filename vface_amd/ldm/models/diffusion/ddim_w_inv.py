@@ -190,7 +190,13 @@ class DDIMSampler(object):
         F_, C, H, W = x.shape
         unet = self.model.model.diffusion_model
         eng = unet.engine
-        inv_t = self._inv_latent(int(t[0].item()) if torch.is_tensor(t) else int(t), inverse_results_dir, device)
+        # t[0] == ddim_timesteps[index] by construction of the loop (ddim_w_inv.py:299-300); reading it from the host
+        # schedule avoids a device->host sync every step (the reference's t[0].item() stalls the launch queue)
+        if hasattr(self, "ddim_timesteps") and 0 <= index < len(self.ddim_timesteps):
+            t_host = int(self.ddim_timesteps[index])
+        else:
+            t_host = int(t[0].item()) if torch.is_tensor(t) else int(t)
+        inv_t = self._inv_latent(t_host, inverse_results_dir, device)
         f32 = lambda v: v.to(device=device, dtype=torch.float32).contiguous()
         x_in = torch.empty(3 * F_ * H * W, 16, dtype=eng.dtype, device=device)
         hip.pack_unet_input(f32(x), inv_t, f32(inpaint), f32(mask), x_in, F=F_, h=H, w=W, cpad=16)
