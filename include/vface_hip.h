@@ -46,6 +46,8 @@ extern "C" {
 #define VFACE_EPI_GEGLU 1   /* out[m][c] = (acc_val + b) * gelu(acc_gate + b); Wt rows packed by vface layout */
 #define VFACE_EPI_OUT_F32 2 /* store fp32 instead of the 16-bit type */
 #define VFACE_TUNE_VARIANT(v) ((v) << 8) /* bits 8..11: force GEMM schedule variant v (1..8); 0 = automatic */
+#define VFACE_TUNE_NO_PERSISTENT 0x10000 /* one workgroup per output tile even where the persistent form would run */
+#define VFACE_TUNE_PERSISTENT 0x20000    /* persistent form for a plain GEMM too (default: implicit convolutions only) */
 
 /* fusion modes of the attn1 hook (pnp_utils.py:133-262) understood by vface_attn1_forward */
 #define VFACE_FUSION_NONE 0       /* switch_on == False, or unpatched CrossAttention.forward */

@@ -430,3 +430,54 @@ def test_gemm_split_k_plain():
     out = torch.empty(M, N, dtype=dt, device=DEV)
     h.gemm(a.to(DEV), w.to(DEV), out, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), residual=res.to(DEV), ldr=N)
     assert rel_l2(out.cpu().float(), ref) < TOL[dt]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,geglu", [(70000, 320, 320, False), (66000, 1280, 320, True), (40000, 640, 192, False)])
+def test_gemm_persistent_matches_one_tile_per_workgroup(M, N, K, geglu):
+    """More tiles than resident workgroups -> the persistent kernel (K pipeline running across tiles).  Same arithmetic in
+    the same order as the one-tile-per-workgroup launch: bit-identical outputs and column statistics."""
+    h = hip()
+    from vface_amd.packing import pack_geglu
+    dt = torch.float16
+    a = rnd((M, K), 1, dt).to(DEV)
+    w = rnd((N, K), 2, dt, 1 / math.sqrt(K))
+    b = rnd((N,), 3, torch.float32, 0.1)
+    nout = N // 2 if geglu else N
+    res = None if geglu else rnd((M, nout), 4, dt).to(DEV)
+    rb = None if geglu else rnd(((M + 4095) // 4096, nout), 5, torch.float32).to(DEV)
+    if geglu:
+        w, b = pack_geglu(w, b)
+    outs = []
+    for flags in (h.TUNE_PERSISTENT, h.TUNE_NO_PERSISTENT):
+        out = torch.zeros(M, nout, dtype=dt, device=DEV)
+        cs = None if geglu else torch.zeros((M + 63) // 64, nout, 2, dtype=torch.float32, device=DEV)
+        h.gemm(a, w.to(DEV), out, M=M, N=N, K=K, lda=K, ldc=nout, bias=b.to(DEV), residual=res, ldr=nout,
+               rowbias=rb, rows_per_sample=4096, flags=flags | (h.EPI_GEGLU if geglu else 0), colstats=cs)
+        outs.append((out, cs))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if not geglu:
+        assert torch.equal(outs[0][1], outs[1][1])
+        ref = a[:4096].float().cpu() @ w.float().t() + b + rb[0].cpu() + res[:4096].float().cpu()
+        assert rel_l2(outs[0][0][:4096].float().cpu(), ref) < TOL[dt]
+
+
+@pytest.mark.gpu
+def test_conv_persistent_matches_one_tile_per_workgroup():
+    h = hip()
+    from vface_amd.packing import pack_conv3x3
+    dt = torch.float16
+    nimg, H, cin, cout = 20, 64, 64, 160          # 640 m-tiles x 1 n-tile
+    x = rnd((nimg, H, H, cin), 1, dt).to(DEV)
+    w = pack_conv3x3(rnd((cout, cin, 3, 3), 2, dt, 1 / math.sqrt(9 * cin))).to(DEV)
+    b = rnd((cout,), 3, torch.float32, 0.1).to(DEV)
+    outs = []
+    for flags in (0, h.TUNE_NO_PERSISTENT):
+        out = torch.zeros(nimg, H, H, cout, dtype=dt, device=DEV)
+        cs = torch.zeros(nimg * H * H // 64, cout, 2, dtype=torch.float32, device=DEV)
+        h.conv3x3(x, w, out, nimg=nimg, H=H, W=H, cin=cin, cout=cout, ldx=cin, ldy=cout, bias=b, colstats=cs, flags=flags)
+        outs.append((out, cs))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = F.conv2d(x[:1].float().cpu().permute(0, 3, 1, 2), rnd((cout, cin, 3, 3), 2, dt, 1 / math.sqrt(9 * cin)).float(),
+                   b.cpu(), padding=1)
+    assert rel_l2(outs[0][0][:1].float().cpu().permute(0, 3, 1, 2), ref) < TOL[dt]

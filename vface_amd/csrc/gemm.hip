@@ -32,7 +32,7 @@ namespace {
 constexpr int BM = 128, BK = 64;
 enum { MODE_PLAIN = 0, MODE_CONV_FAST = 1, MODE_CONV_GENERIC = 2 };
 
-template <class TT, int MODE, int NT, bool DB>
+template <class TT, int MODE, int NT, bool DB, bool PERSIST>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
@@ -53,10 +53,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     // and L walks the tile grid in column groups of GN = 8 n-tiles, m-major inside a group: the ~64 tiles an XCD
     // has in flight then cover ~8 m-tiles x 8 n-tiles, so both the activation panels (and the neighbouring
     // m-tiles whose 3x3 windows overlap them) and the weight panels are re-used out of that XCD's L2.
-    int m0, n0;
-    {
-        const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
-        const int nwg = gridDim.x / p.split_k, id = blockIdx.x % nwg;   // split s of every tile = blocks [s*nwg, (s+1)*nwg)
+    // A persistent workgroup w walks the virtual block ids w, w + G, w + 2G, ... (G = grid size, a multiple of 8, so all
+    // of them map to w's own XCD exactly as the blocks of a one-tile-per-workgroup launch would).
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    const int ntiles = ntn * ntm;
+    int m0 = 0, n0 = 0;
+    auto tile_origin = [&](int id) {
+        const int nwg = ntiles;
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
         int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
         // implicit-conv K tiles already re-use their activation lines inside one workgroup (chunk-major K), and measured
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         const int tm = rem / gw;
         m0 = tm * BM;
         n0 = (g * GN + (rem - tm * gw)) * BN;
-    }
+    };
 
     // Operands are read through buffer descriptors (guide T8): `buffer_load_dwordx4 ... offen lds` takes a 32-bit
     // per-lane byte offset and returns zeros for any offset >= num_records, so a padding tap / tile tail is one
@@ -90,6 +93,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     unsigned a_mask[4];      // conv-fast: bit tap = tap in bounds; else: row valid
     int g_oy[4], g_ox[4];    // conv: top-left tap coordinates (generic / upsample paths)
     unsigned g_img[4];       // conv: first pixel index of the row's image
+    unsigned b_off[BROUNDS];
+    // per-tile operand addresses (after tile_origin)
+    auto tile_addresses = [&]() {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
         const int m = m0 + rr * 32 + srow;
@@ -124,12 +130,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             }
         }
     }
-    unsigned b_off[BROUNDS];
 #pragma unroll
     for (int rr = 0; rr < BROUNDS; ++rr) {
         const int n = n0 + rr * 32 + srow;
         b_off[rr] = n < p.N ? (unsigned)(((long)n * p.ldw + schunk * 8) * ES) : OOB;
     }
+    };
+
+    tile_origin(PERSIST ? (int)blockIdx.x : (int)(blockIdx.x % ntiles));
+    tile_addresses();
 
     auto stage = [&](int kt, int buf) {
         E* sA = smem + buf * STAGE;
@@ -251,6 +260,171 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         if (!(p.flags & GEMM_NO_SETPRIO)) __builtin_amdgcn_s_setprio(0);
     };
 
+    // ---- wide epilogue (16-bit outputs, N % 8 == 0).  Measured: storing the accumulator layout directly -- 8 bytes per
+    // lane, 32-byte row fragments -- costs ~800 cycles per store instruction (16 k cycles per workgroup, more than three
+    // K tiles).  Instead each wave transposes its 64 x WN tile through LDS, 16 rows (one MFMA tile row) at a time, in
+    // fp32 -- so bias / row bias / residual are still summed before the single rounding -- and writes whole 16-byte
+    // chunks of consecutive channels per lane: 8-10x fewer, fully coalesced stores; the residual is read the same way.
+    // Scratch: 4 waves x 16 rows x (WN + 4) floats (17-21 KB) at `scr_base` (a free stage buffer).
+    auto wide_epilogue = [&](int em0, int en0, float* scr_base) {
+        constexpr int WN = NT * 16;
+        constexpr int SP = WN + 4;   // fp32 scratch row pitch (floats); +16 B keeps rows off the same banks
+        const bool gg = p.flags & GEMM_GEGLU;
+        const float* bias = p.bias;
+        const float* rowbias = p.rowbias;
+        const E* res = reinterpret_cast<const E*>(p.residual);
+        E* Cout = reinterpret_cast<E*>(p.C);
+        float* colstats = p.colstats;
+        const bool want_stats = colstats && !(p.flags & 0x4000);
+        float* scr = scr_base + wave * (16 * SP);
+        const int OW = gg ? WN / 2 : WN;              // output columns of this wave
+        const int CH = OW >> 3;                       // 16-byte chunks per output row
+        const int LPR = 64 / CH;                      // rows covered per read pass
+        const bool act = lane < LPR * CH;
+        const int rch = lane % CH, rrow = lane / CH;
+        const int ncol = (gg ? ((en0 + wn * WN) >> 1) : (en0 + wn * WN)) + rch * 8;   // first output channel of this lane
+        const int nout = gg ? (p.N >> 1) : p.N;
+        float s8[8], q8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+        // the residual rows of the whole tile are requested up front (never with GEGLU, so the chunk geometry is static):
+        // their HBM latency then runs under the LDS transposes instead of once per 16-row pass
+        constexpr int LPRC = 64 / (NT * 2), RI = (16 + LPRC - 1) / LPRC;
+        V8 rres[4][RI];
+        if (res) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int it = 0; it < RI; ++it) {
+                    const int r = rrow + it * LPRC;
+                    const int m = em0 + wm * 64 + i * 16 + r;
+                    if (act && r < 16 && m < p.M && ncol < nout) rres[i][it] = *reinterpret_cast<const V8*>(res + (long)m * p.ldr + ncol);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            {
+                const int m = em0 + wm * 64 + i * 16 + fr;
+                const float* rb = (rowbias && m < p.M) ? rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+                float* srow = scr + fr * SP + fq * 4;
+                if (!gg) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int nb = en0 + wn * WN + j * 16 + fq * 4;
+                        float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+                        if (nb < p.N) {
+                            if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                            if (rb) { const float4 b = *reinterpret_cast<const float4*>(rb + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                        }
+                        *reinterpret_cast<float4*>(srow + j * 16) = v;
+                    }
+                } else if constexpr ((NT & 1) == 0) {
+#pragma unroll
+                    for (int jj = 0; jj < NT / 2; ++jj) {
+                        const int nb = en0 + wn * WN + jj * 32 + fq * 4;   // packed index of the value rows; gates at +16
+                        float a[4], g[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { a[r] = acc[2 * jj][i][r]; g[r] = acc[2 * jj + 1][i][r]; }
+                        if (bias && nb < p.N) {
+                            const float4 ba = *reinterpret_cast<const float4*>(bias + nb);
+                            const float4 bg = *reinterpret_cast<const float4*>(bias + nb + 16);
+                            a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
+                            g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
+                        }
+                        *reinterpret_cast<float4*>(srow + jj * 16) =
+                            make_float4(a[0] * gelu_erf_f(g[0]), a[1] * gelu_erf_f(g[1]), a[2] * gelu_erf_f(g[2]), a[3] * gelu_erf_f(g[3]));
+                    }
+                }
+            }
+            // LDS operations of one wave execute in order: the reads below see the writes above, and the next
+            // tile row's writes cannot overtake these reads
+            if (act) {
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int r = rrow + it * LPR;
+                    if (r >= 16) break;
+                    const int m = em0 + wm * 64 + i * 16 + r;
+                    if (m < p.M && ncol < nout) {
+                        const float4 x0 = *reinterpret_cast<const float4*>(scr + r * SP + rch * 8);
+                        const float4 x1 = *reinterpret_cast<const float4*>(scr + r * SP + rch * 8 + 4);
+                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        if (res) {
+                            const V8 r8 = rres[i][it < RI ? it : 0];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += to_f32(r8[e]);
+                        }
+                        V8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
+                        *reinterpret_cast<V8*>(Cout + (long)m * p.ldc + ncol) = o;
+                        if (want_stats) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] += f * f; }
+                        }
+                    }
+                }
+            }
+        }
+        if (want_stats) {
+            // fold the LPR row-lanes of every channel through the scratch (fixed order: reproducible)
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    scr[(rrow * OW + rch * 8 + e) * 2] = s8[e];
+                    scr[(rrow * OW + rch * 8 + e) * 2 + 1] = q8[e];
+                }
+            }
+            const long slice = (em0 + wm * 64) >> 6;
+            if (em0 + wm * 64 < p.M) {
+                for (int c = lane; c < OW; c += 64) {
+                    float ss = 0.f, qq = 0.f;
+                    for (int l = 0; l < LPR; ++l) { ss += scr[(l * OW + c) * 2]; qq += scr[(l * OW + c) * 2 + 1]; }
+                    const int n = en0 + wn * WN + c;
+                    if (n < p.N) *reinterpret_cast<float2*>(colstats + (slice * p.ld_colstats + n) * 2) = make_float2(ss, qq);
+                }
+            }
+        }
+    };
+
+    if constexpr (PERSIST) {
+        // Persistent form (grid = 2 workgroups per CU): the two-stage K pipeline keeps running ACROSS output tiles.  While
+        // the last K tile of tile T feeds the MFMAs, the first K tile of tile T+1 is already in flight into the other
+        // stage, and the epilogue of T (scratch = the stage it just finished with) overlaps that load's latency; a
+        // workgroup pays the launch, descriptor and first-load latencies once instead of once per tile.
+        const int ntk = (p.K + BK - 1) / BK;
+        int tile = blockIdx.x, g = 0;
+        stage(0, 0);
+        while (true) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][i] = f4_t{0.f, 0.f, 0.f, 0.f};
+            int em0 = m0, en0 = n0;
+            for (int kt = 0; kt < ntk; ++kt) {
+                const int cur = g & 1;
+                ++g;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (kt + 1 < ntk) {
+                    stage(kt + 1, cur ^ 1);
+                } else {
+                    em0 = m0; en0 = n0;
+                    tile += gridDim.x;
+                    if (tile < ntiles) {   // wave-uniform
+                        tile_origin(tile);
+                        tile_addresses();
+                        stage(0, cur ^ 1);
+                    }
+                }
+                compute(cur);
+            }
+            __syncthreads();   // every wave is done reading the last stage: it becomes the epilogue scratch
+            wide_epilogue(em0, en0, reinterpret_cast<float*>(smem + ((g - 1) & 1) * STAGE));
+            if (tile >= ntiles) break;
+        }
+        return;
+    }
+
     if (DB) {
         // two LDS stages: tile kt+1 is in flight while tile kt feeds the MFMAs; one barrier per K tile
         stage(kt_begin, 0);
@@ -318,121 +492,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         return;
     }
 
-    // ---- wide epilogue (16-bit outputs, N % 8 == 0).  Measured: storing the accumulator layout directly -- 8 bytes per
-    // lane, 32-byte row fragments -- costs ~800 cycles per store instruction (16 k cycles per workgroup, more than three
-    // K tiles).  Instead each wave transposes its 64 x WN tile through LDS in two 32-row halves (fp32, so bias / row
-    // bias / residual are still summed before the single rounding) and writes whole 16-byte chunks of consecutive
-    // channels per lane: 8-10x fewer, fully coalesced stores; the residual is read the same way.
     if (DB && !(p.flags & GEMM_OUT_F32) && !(p.N & 7) && !(p.flags & GEMM_NARROW_EPILOGUE)) {
-        constexpr int WN = NT * 16;
-        constexpr int SP = WN + 4;   // fp32 scratch row pitch (floats); +16 B keeps rows off the same banks
-        const bool gg = p.flags & GEMM_GEGLU;
-        const float* bias = p.bias;
-        const float* rowbias = p.rowbias;
-        const E* res = reinterpret_cast<const E*>(p.residual);
-        E* Cout = reinterpret_cast<E*>(p.C);
-        float* colstats = p.colstats;
-        const bool want_stats = colstats && !(p.flags & 0x4000);
         __syncthreads();             // all waves are done with the last K tile: the stage buffers become scratch
-        float* scr = reinterpret_cast<float*>(smem_raw) + wave * (32 * SP);
-        const int OW = gg ? WN / 2 : WN;              // output columns of this wave
-        const int CH = OW >> 3;                       // 16-byte chunks per output row
-        const int LPR = 64 / CH;                      // rows covered per pass
-        const bool act = lane < LPR * CH;
-        const int rch = lane % CH, rrow = lane / CH;
-        const int ncol = (gg ? ((n0 + wn * WN) >> 1) : (n0 + wn * WN)) + rch * 8;   // first output channel of this lane
-        const int nout = gg ? (p.N >> 1) : p.N;
-        float s8[8], q8[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int i = hh * 2 + ii;
-                const int m = m0 + wm * 64 + i * 16 + fr;
-                const float* rb = (rowbias && m < p.M) ? rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
-                float* srow = scr + (ii * 16 + fr) * SP + fq * 4;
-                if (!gg) {
-#pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int nb = n0 + wn * WN + j * 16 + fq * 4;
-                        float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-                        if (nb < p.N) {
-                            if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                            if (rb) { const float4 b = *reinterpret_cast<const float4*>(rb + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                        }
-                        *reinterpret_cast<float4*>(srow + j * 16) = v;
-                    }
-                } else if constexpr ((NT & 1) == 0) {
-#pragma unroll
-                    for (int jj = 0; jj < NT / 2; ++jj) {
-                        const int nb = n0 + wn * WN + jj * 32 + fq * 4;   // packed index of the value rows; gates at +16
-                        float a[4], g[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { a[r] = acc[2 * jj][i][r]; g[r] = acc[2 * jj + 1][i][r]; }
-                        if (bias && nb < p.N) {
-                            const float4 ba = *reinterpret_cast<const float4*>(bias + nb);
-                            const float4 bg = *reinterpret_cast<const float4*>(bias + nb + 16);
-                            a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
-                            g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
-                        }
-                        *reinterpret_cast<float4*>(srow + jj * 16) =
-                            make_float4(a[0] * gelu_erf_f(g[0]), a[1] * gelu_erf_f(g[1]), a[2] * gelu_erf_f(g[2]), a[3] * gelu_erf_f(g[3]));
-                    }
-                }
-            }
-            // LDS operations of one wave execute in order: the reads below see the writes above, and the next
-            // half's writes cannot overtake these reads
-            if (act) {
-                for (int r = rrow; r < 32; r += LPR) {
-                    const int m = m0 + wm * 64 + hh * 32 + r;
-                    if (m < p.M && ncol < nout) {
-                        const float4 x0 = *reinterpret_cast<const float4*>(scr + r * SP + rch * 8);
-                        const float4 x1 = *reinterpret_cast<const float4*>(scr + r * SP + rch * 8 + 4);
-                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                        if (res) {
-                            const V8 r8 = *reinterpret_cast<const V8*>(res + (long)m * p.ldr + ncol);
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += to_f32(r8[e]);
-                        }
-                        V8 o;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
-                        *reinterpret_cast<V8*>(Cout + (long)m * p.ldc + ncol) = o;
-                        if (want_stats) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] += f * f; }
-                        }
-                    }
-                }
-            }
-        }
-        if (want_stats) {
-            // fold the LPR row-lanes of every channel through the scratch (fixed order: reproducible)
-            if (act) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    scr[(rrow * OW + rch * 8 + e) * 2] = s8[e];
-                    scr[(rrow * OW + rch * 8 + e) * 2 + 1] = q8[e];
-                }
-            }
-            const long slice = (m0 + wm * 64) >> 6;
-            if (m0 + wm * 64 < p.M) {
-                for (int c = lane; c < OW; c += 64) {
-                    float ss = 0.f, qq = 0.f;
-                    for (int l = 0; l < LPR; ++l) { ss += scr[(l * OW + c) * 2]; qq += scr[(l * OW + c) * 2 + 1]; }
-                    const int n = n0 + wn * WN + c;
-                    if (n < p.N) *reinterpret_cast<float2*>(colstats + (slice * p.ld_colstats + n) * 2) = make_float2(ss, qq);
-                }
-            }
-        }
+        wide_epilogue(m0, n0, reinterpret_cast<float*>(smem_raw));
         if (p.flags & 0x4000) {
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-            if (lane == 0 && colstats) {
-                float* d = colstats + ((long)blockIdx.x * 4 + wave) * 4;
+            if (lane == 0 && p.colstats) {
+                float* d = p.colstats + ((long)blockIdx.x * 4 + wave) * 4;
                 d[0] = (float)(dbg_t1 - dbg_t0); d[1] = (float)(dbg_t2 - dbg_t1); d[2] = (float)(t3 - dbg_t2); d[3] = 1.f;
             }
         }
@@ -628,19 +696,38 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
     }
 }
 
+// workgroups a persistent launch keeps resident: 2 per CU (LDS 64-74 KB and <= 256 VGPRs each)
+int persistent_grid() {
+    static int g = 0;
+    if (!g) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        g = 2 * cus;
+        g -= g % 8;   // whole rounds of the 8 XCDs
+    }
+    return g;
+}
+
 template <class TT, int MODE, int NT, bool DB>
 int launch_one(const GemmParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT;
-    dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.split_k);
+    const int ntiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     const size_t lds = (size_t)(DB ? 2 : 1) * (BM + BN) * BK * sizeof(typename TT::elem);
-    auto kern = gemm_kernel<TT, MODE, NT, DB>;
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
+    // persistent form: only where a workgroup would get more than one tile and the wide epilogue applies
+    // (measured on the UNet's shapes: +1..3 % for the implicit convolutions, +-2 % noise for plain GEMMs, which keep the
+    // one-tile-per-workgroup launch unless GEMM_PERSIST asks otherwise)
+    const bool persist = DB && p.split_k == 1 && !(p.flags & (GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE | GEMM_NO_PERSIST | 0x4000)) &&
+                         !(p.N & 7) && ntiles > persistent_grid() && (MODE != MODE_PLAIN || (p.flags & GEMM_PERSIST));
+    auto kern = persist ? gemm_kernel<TT, MODE, NT, DB, DB> : gemm_kernel<TT, MODE, NT, DB, false>;
+    static bool attr_set[2] = {false, false};
+    if (lds > 64 * 1024 && !attr_set[persist]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return VF_ERR_LAUNCH;
-        attr_set = true;
+        attr_set[persist] = true;
     }
+    dim3 grid(persist ? persistent_grid() : ntiles * p.split_k);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     if (p.split_k > 1)
         hipLaunchKernelGGL(splitk_reduce_kernel<TT>, dim3((p.M + 63) / 64, (p.N + 255) / 256), dim3(256), 0, stream, p);

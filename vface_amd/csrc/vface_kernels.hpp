@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-enum { GEMM_GEGLU = 1, GEMM_OUT_F32 = 2, GEMM_NO_XCD_REMAP = 0x1000, GEMM_NO_SETPRIO = 0x2000, GEMM_NARROW_EPILOGUE = 0x8000 };  // bits 8..11 of flags: forced schedule variant (0 = automatic)
+enum { GEMM_GEGLU = 1, GEMM_OUT_F32 = 2, GEMM_NO_XCD_REMAP = 0x1000, GEMM_NO_SETPRIO = 0x2000, GEMM_NARROW_EPILOGUE = 0x8000, GEMM_NO_PERSIST = 0x10000, GEMM_PERSIST = 0x20000 };  // bits 8..11 of flags: forced schedule variant (0 = automatic)
 
 struct GemmParams {
     int mode;  // 0: plain A[M][K]; 1: implicit 3x3 conv over NHWC

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvface_hip.so")
 
 F16, BF16 = 0, 1
 EPI_GEGLU, EPI_OUT_F32 = 1, 2
+TUNE_NO_PERSISTENT, TUNE_PERSISTENT = 0x10000, 0x20000  # flags of gemm / conv3x3: force one workgroup per tile / the persistent form
 FUSION_NONE, FUSION_REPLACE, FUSION_LINEAR = 0, 1, 2
 
 _i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
