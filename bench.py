@@ -207,6 +207,14 @@ def main():
     if rank == 0:
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         unet_tflops = 3 * F_ * 796.94e9 / (ms_step * 1e-3) / 1e12 if h == 64 else None
+        # HBM-side bytes per conv launch come from separate rocprofv3 --pmc passes of this same command (tools/traffic.sh:
+        # 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md "HBM"); the committed summary is quoted
+        # only for the workload it was collected on, otherwise null.
+        traffic, traffic_src = None, None
+        tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_b_hbm_traffic.json")
+        if os.path.exists(tf) and F_ == 8 and h == 64 and a.fusion == "replace" and a.dtype == "fp16":
+            traffic = json.load(open(tf))["_conv_all"]["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r01_b_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
         out = {
             "metric": "swapped frames/sec at 512x512, 50-step DDIM", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -219,7 +227,7 @@ def main():
                        "unet_algorithmic_tflops_per_gpu": unet_tflops},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<MODE_CONV> (implicit-GEMM 3x3 conv)",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": n_launch, "mean_launch_us": conv_ms * 1e3 / max(n_launch, 1),
                          "share_of_step_time": conv_ms / (el * 1e3)},
         }

@@ -36,7 +36,7 @@ def main():
     dt = torch.float16
     g = torch.Generator(device="cpu").manual_seed(0)
     rnd = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dt).to(DEV)
-    variants = {"auto": 0, "db128": 0x500, "db160": 0x600}
+    variants = {"auto": 0, "db128": 0x500, "db160": 0x600, "pp128": 0x900, "pp160": 0xA00}
     if "conv" in a.what:
         print("== conv3x3 implicit GEMM (TFLOP/s median | best), variants:", list(variants))
         for (H, cin, cout, stride) in [(64, 320, 320, 1), (64, 640, 320, 1), (64, 960, 320, 1), (32, 640, 640, 1),

@@ -68,8 +68,22 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    // XCD-aware order (guide T1): workgroups are dealt round-robin to the 8 XCDs; give each XCD a CONTIGUOUS run of the
+    // (sample, head, query tile) sequence, so the query tiles of one (sample, head) -- which all walk the same K / V --
+    // share one XCD's 4 MiB L2 instead of spreading every head's K / V over all eight (measured: 1.04 GB of fabric
+    // reads per launch at n = 4096, dh = 40 against 0.19 GB of q, k, v).
+    int b, h, qtile;
+    {
+        const int gx = (p.n + 64 * QT - 1) / (64 * QT);
+        const int nwg = gridDim.x, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        qtile = L % gx;
+        const int bh = L / gx;
+        h = bh % p.heads;
+        b = bh / p.heads;
+    }
+    const int q0 = qtile * (64 * QT) + wave * (16 * QT);
     const int bqk = p.qk_map ? p.qk_map[b] : b;
     const int gs = p.set_stride;                     // output / value sample of set g: b + g*gs
     const E* Qg = reinterpret_cast<const E*>(p.Q) + (long)bqk * p.bsq + h * DH;
@@ -300,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     }
     if (dbg) {
         if (lane == 0) {
-            float* d = reinterpret_cast<float*>(p.O) + (((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+            float* d = reinterpret_cast<float*>(p.O) + ((long)blockIdx.x * 4 + wave) * 8;
 #pragma unroll
             for (int i = 0; i < 6; ++i) d[i] = (float)tph[i];
         }
@@ -347,7 +361,7 @@ int launch(const AttnParams& p, hipStream_t stream) {
             return VF_ERR_LAUNCH;
         attr_set = true;
     }
-    dim3 grid((p.n + 64 * QT - 1) / (64 * QT), p.heads, p.B);
+    dim3 grid(((p.n + 64 * QT - 1) / (64 * QT)) * p.heads * p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
 }
