@@ -756,7 +756,11 @@ int pick_variant(const GemmParams& p) {
     const int forced = (p.flags >> 8) & 0xF;
     if (forced) return forced;
     const bool geglu = p.flags & GEMM_GEGLU;
-    const bool n160 = !geglu && (p.N % 160 == 0) && (p.N % 128 != 0);
+    // BN = 160 moves 10 % fewer L2->LDS bytes per FLOP.  Where N is a multiple of 128 as well (640, 1280, 1920) it only
+    // pays once the grid is several rounds deep (measured: +5..10 % at >= 1536 tiles, -3..5 % below: 160-wide tiles
+    // quantise a 1-2 round grid worse)
+    const long tiles160 = (long)((p.M + BM - 1) / BM) * (p.N / 160);
+    const bool n160 = !geglu && (p.N % 160 == 0) && ((p.N % 128 != 0) || tiles160 >= 1536);
     return n160 ? 6 : 5;
 }
 
