@@ -73,8 +73,10 @@ int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1,
 /* Bytes of device scratch a vface_gemm / vface_conv3x3 launch of this shape (M rows = nimg*OH*OW for a convolution,
  * K = 9*Cin) can use to split its K loop over more workgroups when M x N alone would leave most of the 256 CUs idle
  * (fp32 partial tiles summed in a fixed order: results stay reproducible).  0 = this shape is never split.
- * `workspace` may be NULL or smaller: the launch then runs unsplit. */
-int64_t vface_splitk_workspace_bytes(int M, int N, int K, int flags);
+ * `workspace` may be NULL or smaller: the launch then runs unsplit.  rows_per_sample (OH*OW of a convolution, h*w of a
+ * token matrix; <= 1 = unknown) makes the decision a function of the per-sample geometry only, so the bits of a sample
+ * do not depend on the batch it is launched in; vface_gemm uses its own rows_per_sample argument the same way. */
+int64_t vface_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_sample);
 
 /* Y = conv3x3(X) over NHWC, padding 1, stride 1|2, optional nearest x2 upsampling of X first, as an
  * implicit GEMM (nothing materialised).  Wt is packed [Cout][K = 9*Cin]: K order (64-channel chunk, tap, channel)

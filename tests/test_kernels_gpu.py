@@ -389,7 +389,7 @@ def test_conv3x3_split_k(cin, cout, H, nimg):
     from vface_amd.packing import pack_conv3x3
     dt = torch.float16
     M = nimg * H * H
-    assert h.load().vface_splitk_workspace_bytes(M, cout, 9 * cin, 0) > 0
+    assert h.load().vface_splitk_workspace_bytes(M, cout, 9 * cin, 0, H * H) > 0
     x = rnd((nimg, cin, H, H), 1, dt)
     w = rnd((cout, cin, 3, 3), 2, dt, 1 / math.sqrt(9 * cin))
     b = rnd((cout,), 3, torch.float32, 0.1)
@@ -421,7 +421,7 @@ def test_gemm_split_k_plain():
     h = hip()
     dt = torch.float16
     M, N, K = 1536, 1280, 2560
-    assert h.load().vface_splitk_workspace_bytes(M, N, K, 0) > 0
+    assert h.load().vface_splitk_workspace_bytes(M, N, K, 0, 1) > 0
     a = rnd((M, K), 1, dt)
     w = rnd((N, K), 2, dt, 1 / math.sqrt(K))
     b = rnd((N,), 3, torch.float32, 0.1)

@@ -273,3 +273,53 @@ def test_bitwise_reproducible_and_batch_invariant(small):
     assert torch.equal(a, b)
     c = run(1, 2)
     assert torch.equal(c, torch.cat([a[k * 4 + 1:k * 4 + 3] for k in range(3)]))
+
+
+def _full_run(fusion, frames, f0, fc, h, flow_all=None):
+    """The 859.5 M-parameter UNet on frames [f0, f0+fc) of a synthetic `frames`-frame clip at h x h latents."""
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler
+    from vface_amd.ldm.models.pnp_utils import register_spa_attn_injection as reg
+    ldm = _full_model()
+    sampler = DDIMSampler(ldm)
+    pick = lambda name, shape: torch.stack([synth.synth_normal(f"cfg.{name}.{c}.{f}", shape)
+                                            for c in range(3) for f in range(f0, f0 + fc)])
+    x, ctx = pick("x", (9, h, h)).to(DEV), pick("c", (1, 768)).to(DEV)
+    t = torch.full((3 * fc,), 481, dtype=torch.long, device=DEV)
+    reg(sampler, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True, chunks=3)
+    flow = None
+    if fusion == "flow_fix":
+        flow = [flow_all[i][None] for i in range(f0, f0 + fc - 1)]
+    reg(sampler, 1, switch_on=True, input_blocks=True, middle_block=False, output_blocks=False, chunks=3, flow=flow,
+        block_indices=list(range(9)), fusion=fusion, split_ratio_fft=0.8, alpha=0.8)
+    out = ldm.apply_model(x, t, ctx).float()
+    assert torch.isfinite(out).all()
+    return out.reshape(3, fc, *out.shape[1:]).cpu()
+
+
+@pytest.mark.parametrize("fusion,frames,h", [("fft", 32, 64), ("replace", 16, 64)])
+def test_full_size_clip_is_batch_invariant(fusion, frames, h):
+    """BASELINE configs 3 (32-frame clip, FSAI) at full size, and `replace` at 16 frames: FSAI / injection couple a frame
+    only with its own chunk 0, so the clip computed in one batch must equal -- bit for bit -- the same frames computed
+    8 at a time (the property frame sharding relies on; no oracle finishes at this size)."""
+    whole = _full_run(fusion, frames, 0, frames, h)
+    for f0 in (0, frames - 8):
+        part = _full_run(fusion, frames, f0, 8, h)
+        assert torch.equal(part, whole[:, f0:f0 + 8]), (fusion, f0)
+
+
+def test_full_size_768_latent_flow_fix_dependency_window():
+    """BASELINE config 5's geometry (768x768 -> 96x96 latents, n = 9216 / 2304 / 576 / 144) with all three modules; the
+    flow gate is generalised to n == h*w of the flow field.  Smoothing is not recurrent inside a layer (frame f blends
+    its own FSAI'd map with frame f-1's, temporal_flow.py:229-236), and two level-0 layers are hooked, so a frame depends
+    on exactly two predecessors: in a run that starts at frame 1, frame 3 must come out bit for bit as in the whole
+    clip, frame 2 must not (its second layer sees a frame 1 that lost its predecessor), and frame 0 equals an
+    unsmoothed FSAI-only run."""
+    h, frames = 96, 4
+    flow_all = synth.synth_flow(frames - 1, h, h)
+    whole = _full_run("flow_fix", frames, 0, frames, h, flow_all)
+    tail = _full_run("flow_fix", frames, 1, 3, h, flow_all)
+    assert torch.equal(tail[:, 2], whole[:, 3])
+    assert not torch.equal(tail[:, 1], whole[:, 2])
+    assert not torch.equal(tail[:, 0], whole[:, 1])
+    single = _full_run("fft", frames, 0, 1, h)
+    assert torch.equal(single[:, 0], whole[:, 0])        # frame 0 is never smoothed (temporal_flow.py:229)

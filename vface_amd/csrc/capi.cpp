@@ -69,9 +69,9 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
     return vf_launch_gemm(p, dtype, S(stream));
 }
 
-int64_t vface_splitk_workspace_bytes(int M, int N, int K, int flags) {
+int64_t vface_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_sample) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return vf_splitk_workspace_bytes(M, N, K, flags);
+    return vf_splitk_workspace_bytes(M, N, K, flags, rows_per_sample);
 }
 
 int vface_attention(const void* Q, const void* K, const void* V, int64_t ldq, int64_t ldk, int64_t ldv, int64_t bsq,

@@ -759,19 +759,26 @@ int pick_variant(const GemmParams& p) {
     // BN = 160 moves 10 % fewer L2->LDS bytes per FLOP.  Where N is a multiple of 128 as well (640, 1280, 1920) it only
     // pays once the grid is several rounds deep (measured: +5..10 % at >= 1536 tiles, -3..5 % below: 160-wide tiles
     // quantise a 1-2 round grid worse)
-    const long tiles160 = (long)((p.M + BM - 1) / BM) * (p.N / 160);
+    // (grid depth taken at the nominal 24-sample batch when the per-sample geometry is known, like split_for: the column
+    // statistics are folded in a tile-shape-dependent order, so the choice must not depend on the batch)
+    const long mref = p.rows_per_sample > 1 ? 24L * p.rows_per_sample : p.M;
+    const long tiles160 = ((mref + BM - 1) / BM) * (p.N / 160);
     const bool n160 = !geglu && (p.N % 160 == 0) && ((p.N % 128 != 0) || tiles160 >= 1536);
     return n160 ? 6 : 5;
 }
 
 // Split-K factor for a launch whose tile grid would leave most of the 256 CUs (2 workgroups each) idle while every
 // workgroup walks a long K loop (the 8x8-level convolutions: 120 tiles x 180..360 K tiles).  Depends on the shape only.
-int split_for(int M, int N, int K, int flags) {
+// The factor is a function of the PER-SAMPLE geometry when the caller states it (rows_per_sample = OH*OW of a conv, h*w
+// of a token matrix): the tile count is taken at a nominal batch of 24 samples, so a frame's bits do not depend on how
+// many other frames share its launch (the fp32 summation order changes with the split) -- what frame sharding relies on.
+int split_for(int M, int N, int K, int flags, int rows_per_sample) {
     if (flags & (GEMM_GEGLU | GEMM_OUT_F32)) return 1;
     if ((N & 7) || ((flags >> 8) & 0xF) == 0xF) return 1;
     const bool n160 = (N % 160 == 0) && (N % 128 != 0);
     const int bn = n160 ? 160 : 128;
-    const int tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
+    const long mref = rows_per_sample > 1 ? 24L * rows_per_sample : M;
+    const int tiles = (int)((mref + BM - 1) / BM) * ((N + bn - 1) / bn);
     const int nt = (K + BK - 1) / BK;
     if (tiles > 192 || nt < 16) return 1;
     int s = 512 / tiles;
@@ -782,8 +789,8 @@ int split_for(int M, int N, int K, int flags) {
 
 }  // namespace
 
-long vf_splitk_workspace_bytes(int M, int N, int K, int flags) {
-    const int s = split_for(M, N, K, flags);
+long vf_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_sample) {
+    const int s = split_for(M, N, K, flags, rows_per_sample);
     return s > 1 ? (long)s * M * N * 4 : 0;
 }
 
@@ -817,7 +824,7 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     }
     const int variant = pick_variant(p);
     if (p.workspace && (variant == 5 || variant == 6) && !((p.flags >> 8) & 0xF) && !(p.flags & 0x4000)) {
-        const int s = split_for(p.M, p.N, p.K, p.flags);
+        const int s = split_for(p.M, p.N, p.K, p.flags, p.rows_per_sample);
         if (s > 1 && p.workspace_bytes >= (long)s * p.M * p.N * 4 && !((uintptr_t)p.workspace & 15) &&
             !(p.residual && (((uintptr_t)p.residual & 15) || (p.ldr & 7))) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) {
             const int nt = (p.K + BK - 1) / BK;

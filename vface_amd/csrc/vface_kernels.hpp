@@ -37,7 +37,7 @@ struct GemmParams {
     long workspace_bytes;
     int split_k, kt_per_split;  // filled by the launcher
 };
-long vf_splitk_workspace_bytes(int M, int N, int K, int flags);
+long vf_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_sample);
 int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 bool vf_attention_shared_scores_supported(int dh, int v_sets);
 int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream);

@@ -333,8 +333,10 @@ class UNetEngine:
             return None
         return torch.empty(rows // 64, cols, 2, dtype=torch.float32, device=self.device)
 
-    def _gemm(self, a: torch.Tensor, w: dict, out: torch.Tensor, **kw):
+    def _gemm(self, a: torch.Tensor, w: dict, out: torch.Tensor, hw: int = 0, **kw):
         K = a.shape[1]
+        if hw > 1 and "rowbias" not in kw:
+            kw["rows_per_sample"] = hw   # split-K decided per sample: a frame's bits do not depend on its batch
         hip.gemm(a, w["w"], out, M=a.shape[0], N=w["w"].shape[0], K=K, lda=a.stride(0), ldc=out.stride(0),
                  ldw=w["w"].shape[1], bias=w.get("b"), **kw)
 
@@ -374,7 +376,7 @@ class UNetEngine:
         h = self._gn(h, p["out_gn"], 1e-5, True)
         if "skip" in p:
             skip = self._new(x.M, p["conv2"]["cout"])
-            self._gemm(x.t, p["skip"], skip)
+            self._gemm(x.t, p["skip"], skip, hw=x.H * x.W)
         else:
             skip = x.t
         return self._conv(h, p["conv2"], out, residual=skip)
@@ -441,7 +443,7 @@ class UNetEngine:
         N, n, c = x.N, x.hw, p["c"]
         g = self._gn(x, p["gn"], 1e-6, False)
         t0 = self._new(x.M, c)
-        self._gemm(g.t, p["proj_in"], t0)
+        self._gemm(g.t, p["proj_in"], t0, hw=x.H * x.W)
         ln = self._new(x.M, c)
         hip.layernorm(t0, p["ln1"][0], p["ln1"][1], ln, M=x.M, C_=c, ldx=c, ldy=c)
         a, b = p["a2_slice"]
@@ -456,9 +458,9 @@ class UNetEngine:
         ff = self._new(x.M, 4 * c)
         hip.gemm(ln, p["ff1"]["w"], ff, M=x.M, N=8 * c, K=c, lda=c, ldc=4 * c, bias=p["ff1"]["b"], flags=hip.EPI_GEGLU)
         t2 = self._new(x.M, c)
-        self._gemm(ff, p["ff2"], t2, residual=t1, ldr=c)
+        self._gemm(ff, p["ff2"], t2, residual=t1, ldr=c, hw=x.H * x.W)
         out, cs = self._new_target(x.M, c, x.hw) if tgt is None else tgt
-        self._gemm(t2, p["proj_out"], out, residual=x.t, ldr=x.ld, colstats=cs)
+        self._gemm(t2, p["proj_out"], out, residual=x.t, ldr=x.ld, colstats=cs, hw=x.H * x.W)
         return Act(out, x.N, x.H, x.W, cs)
 
     # ------------------------------------------------------------------ the forward

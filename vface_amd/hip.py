@@ -30,7 +30,7 @@ SIGNATURES = {
                              _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "vface_conv3x3": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp,
                                 _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
-    "vface_splitk_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "vface_splitk_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "vface_groupnorm_finalize_cols": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vface_attention": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32,
                                   _i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
@@ -126,10 +126,10 @@ def zeros_page(device) -> torch.Tensor:
 _splitk_ws = {}
 
 
-def splitk_workspace(device, M: int, N: int, K: int, flags: int = 0):
+def splitk_workspace(device, M: int, N: int, K: int, flags: int = 0, rows_per_sample: int = 1):
     """Device scratch for a split-K launch of this shape (grown on demand, one per device; launches on one stream
     use it in order).  Returns (tensor | None, bytes)."""
-    need = load().vface_splitk_workspace_bytes(M, N, K, flags)
+    need = load().vface_splitk_workspace_bytes(M, N, K, flags, rows_per_sample)
     if need <= 0:
         return None, 0
     key = str(device)
@@ -146,7 +146,7 @@ def gemm(a: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, M: int, N: int
          a2=None, lda2: int = 0, k1: int = 0, a2_row_mod: int = 0, flags: int = 0, colstats=None, split_k: bool = True):
     """out[M, :N] = a[M, :K] @ wt[:N, :K]^T (+ epilogue).  Tensors are device buffers; M/N/K/ld* describe the view."""
     lib = load()
-    ws, ws_bytes = splitk_workspace(a.device, M, N, K, flags) if split_k else (None, 0)
+    ws, ws_bytes = splitk_workspace(a.device, M, N, K, flags, rows_per_sample) if split_k else (None, 0)
     rc = lib.vface_gemm(_p(a), lda, _p(a2), lda2, k1, a2_row_mod, _p(wt), ldw if ldw is not None else K, M, N, K,
                         _p(bias), _p(rowbias), rows_per_sample, rowbias.stride(0) if rowbias is not None else 0,
                         _p(residual), ldr, _p(out), ldc, _p(zeros_page(a.device)), flags, dtype_code(a.dtype),
@@ -160,7 +160,7 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, 
     lib = load()
     vh, vw = (2 * H, 2 * W) if upsample else (H, W)
     M = nimg * ((vh - 1) // stride + 1) * ((vw - 1) // stride + 1)
-    ws, ws_bytes = splitk_workspace(x.device, M, cout, 9 * cin, flags) if split_k else (None, 0)
+    ws, ws_bytes = splitk_workspace(x.device, M, cout, 9 * cin, flags, M // nimg) if split_k else (None, 0)
     rc = lib.vface_conv3x3(_p(x), ldx, nimg, H, W, cin, _p(wt), 9 * cin, cout, stride, int(upsample), _p(bias),
                            _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, _p(residual), ldr, _p(out),
                            ldy, _p(zeros_page(x.device)), flags, dtype_code(x.dtype), _p(colstats),
