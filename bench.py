@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="frames per GPU")
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--fusion", default="replace", help="replace | fft | flow_fix | none")
+    ap.add_argument("--inv-steps", type=int, default=3, help="DDIM-inversion steps timed after the run (0 = skip)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -121,12 +122,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback on the product path)"
+    # VFACE_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend -- to rehearse the N > 1 control flow on a
+    # one-GPU box (the numbers of such a run mean nothing).  The driver's multi-GPU runs never set it.
+    rehearse = os.environ.get("VFACE_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     from vface_amd import hip
@@ -195,8 +204,27 @@ def main():
         el = time.perf_counter() - t0
         timer.on = False
     assert torch.isfinite(img).all(), "non-finite latents"
+    # DDIM inversion (ddim_w_inv.py:360-490; SURVEY 8d asks for it separately): hooks off, batch 2F = [target ; source],
+    # no guidance -- 50 such steps per clip precede sampling unless the latents are cached.  Timed outside the step loop.
+    inv_ms = None
+    if a.inv_steps > 0:
+        with torch.no_grad():
+            x2 = torch.cat([x_T, stack("xsrc", (4, h, h))])
+            c2 = torch.cat([c, tc])
+            kw2 = {"inpaint_image": torch.cat([inp, inp]), "inpaint_mask": torch.cat([mask, mask])}
+            store = {}
+            sampler.ddim_invert(x2, c2, a.ddim_steps, (4, h, h), inverse_dir=store, batch_size=F_, max_steps=1,
+                                test_model_kwargs=kw2)
+            fence()
+            t1 = time.perf_counter()
+            sampler.ddim_invert(x2, c2, a.ddim_steps, (4, h, h), inverse_dir=store, batch_size=F_, max_steps=a.inv_steps,
+                                test_model_kwargs=kw2)
+            fence()
+            inv_ms = (time.perf_counter() - t1) / a.inv_steps * 1e3
+        sampler.make_schedule(a.ddim_steps, ddim_eta=0.0, verbose=False)
+        log(f"inversion: {inv_ms:.2f} ms/step (2F = {2 * F_} unhooked sample-forwards)")
     if dist is not None:
-        tt = torch.tensor([el], device=dev, dtype=torch.float64)
+        tt = torch.tensor([el], device="cpu" if rehearse else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     ms_step = el / a.steps * 1e3
@@ -225,6 +253,11 @@ def main():
                                    f"batch [uncond;cond;recon] = {3 * F_} samples per step",
                        "frames_per_gpu": F_, "latent": [h, h], "fusion": a.fusion,
                        "unet_algorithmic_tflops_per_gpu": unet_tflops},
+            "inversion": None if inv_ms is None else {
+                "ms_per_step": inv_ms, "steps_timed": a.inv_steps,
+                "note": "DDIM inversion step (hooks off, batch 2F, no guidance), outside the timed region; `value` is "
+                        "sampling only, as BASELINE's metric",
+                "frames_per_s_sampling_plus_inversion": (F_ * world) / (a.ddim_steps * (ms_step + inv_ms) / 1e3)},
             "roofline": {"bound": "mfma", "kernel": "gemm_kernel<MODE_CONV> (implicit-GEMM 3x3 conv)",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,

@@ -75,6 +75,7 @@ class DDIMSampler(object):
         assert ac.shape[0] == self.ddpm_num_timesteps, 'alphas have to be defined for each timestep'
         self.register_buffer('betas', self.model.betas.clone().detach().float())
         self.register_buffer('alphas_cumprod', ac.clone().detach().float())
+        self._alphas_cumprod_host = ac.detach().float().cpu().numpy()   # scalars for the update kernels: no per-step sync
         self.register_buffer('alphas_cumprod_prev', self.model.alphas_cumprod_prev.clone().detach().float())
         sig, a, ap = make_ddim_sampling_parameters(alphacums=ac.detach().float().cpu().numpy(),
                                                    ddim_timesteps=self.ddim_timesteps, eta=ddim_eta, verbose=verbose)
@@ -248,7 +249,7 @@ class DDIMSampler(object):
         unet = self.model.model.diffusion_model
         eng = unet.engine
         _, C, H, W = x.shape
-        ac = self.alphas_cumprod
+        ac = self._alphas_cumprod_host
         x = f32(x)
         for i, step in enumerate(timesteps):
             if max_steps is not None and i >= max_steps:
