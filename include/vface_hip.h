@@ -46,6 +46,7 @@ extern "C" {
 #define VFACE_EPI_GEGLU 1   /* out[m][c] = (acc_val + b) * gelu(acc_gate + b); Wt rows packed by vface layout */
 #define VFACE_EPI_OUT_F32 2 /* store fp32 instead of the 16-bit type */
 #define VFACE_TUNE_VARIANT(v) ((v) << 8) /* bits 8..11: force GEMM schedule variant v (1..8); 0 = automatic */
+#define VFACE_CONV_PAD_TRAILING 0x40000 /* vface_conv3x3: zero padding (left 0, right 1, top 0, bottom 1) instead of 1 all round */
 #define VFACE_TUNE_NO_PERSISTENT 0x10000 /* one workgroup per output tile even where the persistent form would run */
 #define VFACE_TUNE_PERSISTENT 0x20000    /* persistent form for a plain GEMM too (default: implicit convolutions only) */
 
@@ -163,6 +164,19 @@ int vface_adain_fusion(const void* a, int64_t lda, const void* b, int64_t ldb, v
 int vface_timestep_embedding(const int64_t* t, void* out, int N, int dim, int dtype, void* stream);
 /* nn.SiLU on a flat buffer (time_embed / emb_layers, openaimodel.py:218-224,631-636); in_f32: x is fp32 */
 int vface_silu(const void* x, void* y, int64_t count, int in_f32, int dtype, void* stream);
+
+/* ---- first-stage KL-VAE (ldm/models/autoencoder.py:285-335, diffusionmodules/model.py:368-570) ----
+ * The encoder / decoder are sequences of vface_conv3x3 (VFACE_CONV_PAD_TRAILING for Downsample :72-77, `upsample` for
+ * Upsample :55-58), vface_groupnorm_* (eps 1e-6, swish) and vface_gemm; two more entry points cover what is new. */
+/* P[m][:] = softmax(scores[m][:] * scale), fp32 in, 16-bit out, N <= 16384 (AttnBlock :183-186: one head of 512 channels;
+ * its scores come from vface_gemm with VFACE_EPI_OUT_F32). */
+int vface_softmax_rows(const float* scores, int64_t ld_s, void* P, int64_t ld_p, int M, int N, float scale, int dtype,
+                       void* stream);
+/* z[F][zc][hw] (fp32 NCHW) = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale from moments [F*hw][ld >= 2*zc] (fp32
+ * NHWC: mean | logvar); noise NULL = mode.  DiagonalGaussianDistribution.sample (distributions.py:24-37) followed by
+ * get_first_stage_encoding's scale_factor. */
+int vface_vae_sample(const float* moments, int64_t ld_moments, const float* noise, float* z, int F, int hw, int zc,
+                     float scale, void* stream);
 int vface_cast_f32(const float* src, void* dst, int64_t count, int dtype, void* stream);
 /* ddim_w_inv.py:633,654-655: x_in = cat[cat[x,inp,mask], cat[x,inp,mask], cat[inv_t,inp,mask]] -> NHWC [3F][hw][cpad] */
 int vface_pack_unet_input(const float* x, const float* inv, const float* inpaint, const float* mask, void* out, int F,

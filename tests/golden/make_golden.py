@@ -343,6 +343,42 @@ def gen_full_unet():
     save("full_unet", **out)
 
 
+def gen_vae():
+    """First-stage KL-VAE: the reference's own Encoder / Decoder (diffusionmodules/model.py:368-568) and
+    DiagonalGaussianDistribution, wired as AutoencoderKL.encode / decode wires them (autoencoder.py:301-302,323-333 --
+    the class itself derives from pytorch_lightning, absent here): a small configuration with every block type, and
+    the shipped configuration (project_ffhq.yaml:57-78) on a 64x64 image."""
+    from ldm.modules.diffusionmodules.model import Decoder, Encoder
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    import builtins
+    out = {}
+    for tag, dd, res, nb in (("small", dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32,
+                                            ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0), 32, 2),
+                             ("ffhq", dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                                           ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0), 64, 1)):
+        class KL(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                pr, builtins.print = builtins.print, (lambda *a, **k: None)   # the constructors print
+                self.encoder, self.decoder = Encoder(**dd), Decoder(**dd)
+                builtins.print = pr
+                self.quant_conv = torch.nn.Conv2d(2 * dd["z_channels"], 2 * 4, 1)
+                self.post_quant_conv = torch.nn.Conv2d(4, dd["z_channels"], 1)
+        m = KL().eval()
+        synth.fill_module_(m, seed=0, prefix="vae.")
+        x = synth.synth_normal(f"vae.{tag}.x", (nb, 3, res, res)).clamp(-1, 1)
+        noise = synth.synth_normal(f"vae.{tag}.noise", (nb, 4, res // 8, res // 8))
+        with torch.no_grad():
+            moments = m.quant_conv(m.encoder(x))
+            post = DiagonalGaussianDistribution(moments)
+            z_mode = post.mode() * 0.18215
+            z_samp = (post.mean + post.std * noise) * 0.18215      # sample() with the noise drawn outside
+            dec = m.decoder(m.post_quant_conv(z_samp / 0.18215))
+        out[f"{tag}.moments"], out[f"{tag}.z_mode"], out[f"{tag}.z_sample"], out[f"{tag}.dec"] = moments, z_mode, z_samp, dec
+        out[f"{tag}.n_params"] = float(sum(p.numel() for p in m.parameters()))
+    save("vae", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also the 860 M-parameter UNet fixture")
@@ -351,7 +387,8 @@ if __name__ == "__main__":
     install_stubs()
     import builtins
     _print = builtins.print
-    gens = {"fsai": gen_fsai, "warp": gen_warp, "attn": gen_attn_module, "tiny": gen_tiny_unet, "ddim": gen_ddim}
+    gens = {"fsai": gen_fsai, "warp": gen_warp, "attn": gen_attn_module, "tiny": gen_tiny_unet, "ddim": gen_ddim,
+            "vae": gen_vae}
     if a.full:
         gens["full"] = gen_full_unet
     for name, fn in gens.items():

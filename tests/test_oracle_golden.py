@@ -209,3 +209,32 @@ def test_invert_two_steps():
     assert rel_l2(xn, g["invert2_final"]) < 2e-5
     assert rel_l2(saved[1], g["invert2_saved_1"]) < 2e-5
     assert rel_l2(saved[21], g["invert2_saved_21"]) < 2e-5
+
+
+# ------------------------------------------------------------------ first-stage KL-VAE
+from oracle import vae as ovae  # noqa: E402
+
+VAE_SPECS = {"small": ovae.VAESpec(ch=32, resolution=32), "ffhq": ovae.FFHQ_VAE}
+
+
+def vae_state_dict(spec):
+    shapes = ovae.param_shapes(spec)
+    return {k: synth.synth_tensor("vae." + k, tuple(s), 0) for k, s in shapes.items()}
+
+
+@pytest.mark.parametrize("tag,res,nb", [("small", 32, 2), ("ffhq", 64, 1)])
+def test_vae_encode_sample_decode_match_reference(tag, res, nb):
+    g = load_golden("vae")
+    spec = VAE_SPECS[tag]
+    sd = vae_state_dict(spec)
+    assert sum(int(np.prod(v.shape)) for v in sd.values()) == int(g[f"{tag}.n_params"])
+    x = synth.synth_normal(f"vae.{tag}.x", (nb, 3, res, res)).clamp(-1, 1)
+    noise = synth.synth_normal(f"vae.{tag}.noise", (nb, 4, res // 8, res // 8))
+    with torch.no_grad():
+        moments = ovae.encode_moments(sd, spec, x)
+        assert rel_l2(moments, g[f"{tag}.moments"]) < 1e-5
+        assert torch.allclose(ovae.sample(moments, None, 0.18215), g[f"{tag}.z_mode"], atol=1e-6)
+        z = ovae.sample(moments, noise, 0.18215)
+        assert rel_l2(z, g[f"{tag}.z_sample"]) < 1e-5
+        dec = ovae.decode(sd, spec, g[f"{tag}.z_sample"] / 0.18215)
+        assert rel_l2(dec, g[f"{tag}.dec"]) < 1e-5

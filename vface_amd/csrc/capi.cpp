@@ -60,7 +60,9 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
     p.mode = 1; p.A = X; p.lda = ldx; p.Wt = Wt; p.ldw = ldw; p.Kw = 9 * Cin;
     p.H = H; p.W = W; p.Cin = Cin; p.stride = stride; p.upsample = upsample ? 1 : 0;
     const int VH = upsample ? 2 * H : H, VW = upsample ? 2 * W : W;
-    p.OH = (VH + 2 - 3) / stride + 1; p.OW = (VW + 2 - 3) / stride + 1;
+    // VFACE_CONV_PAD_TRAILING: zero padding (0,1,0,1) -- F.pad then a padding-0 convolution (diffusionmodules/model.py:72-77)
+    p.pad = (flags & VFACE_CONV_PAD_TRAILING) ? 0 : 1;
+    p.OH = (VH + p.pad + 1 - 3) / stride + 1; p.OW = (VW + p.pad + 1 - 3) / stride + 1;
     p.M = nimg * p.OH * p.OW; p.N = Cout; p.K = 9 * Cin;
     p.bias = bias; p.rowbias = rowbias; p.rows_per_sample = p.OH * p.OW; p.ld_rowbias = ld_rowbias;
     p.residual = residual; p.ldr = ldr; p.C = Y; p.ldc = ldy; p.zeros = zeros; p.flags = flags;
@@ -226,6 +228,15 @@ int vface_adain_fusion(const void* a, int64_t lda, const void* b, int64_t ldb, v
 int vface_timestep_embedding(const int64_t* t, void* out, int N, int dim, int dtype, void* stream) {
     return vf_launch_timestep_embedding(reinterpret_cast<const long long*>(t), out, N, dim, dtype, S(stream));
 }
+int vface_softmax_rows(const float* scores, int64_t ld_s, void* P, int64_t ld_p, int M, int N, float scale, int dtype, void* stream) {
+    return vf_launch_softmax_rows(scores, ld_s, P, ld_p, M, N, scale, dtype, S(stream));
+}
+
+int vface_vae_sample(const float* moments, int64_t ld_moments, const float* noise, float* z, int F, int hw, int zc,
+                     float scale, void* stream) {
+    return vf_launch_vae_sample(moments, ld_moments, noise, z, F, hw, zc, scale, S(stream));
+}
+
 int vface_silu(const void* x, void* y, int64_t count, int in_f32, int dtype, void* stream) {
     return vf_launch_silu(x, y, count, in_f32, dtype, S(stream));
 }

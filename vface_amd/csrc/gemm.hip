@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             const int img = m / hw;
             const int rem = m - img * hw;
             const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
+            const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
             g_oy[rr] = y0; g_ox[rr] = x0; g_img[rr] = (unsigned)(img * p.H * p.W);
             if (MODE == MODE_CONV_FAST) {
                 const int VH = p.upsample ? 2 * p.H : p.H, VW = p.upsample ? 2 * p.W : p.W;

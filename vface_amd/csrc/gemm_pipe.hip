@@ -81,7 +81,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_pipe_kernel(GemmParams p) {
             const int img = m / hw;
             const int rem = m - img * hw;
             const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            const int y0 = oy * p.stride - 1, x0 = ox * p.stride - 1;
+            const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
             if (MODE == MODE_CONV_FAST) {
                 const int VH = p.upsample ? 2 * p.H : p.H, VW = p.upsample ? 2 * p.W : p.W;
                 unsigned mk = 0;

@@ -568,6 +568,84 @@ inline int ok() { return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH
 
 }  // namespace
 
+
+// P[m][:] = softmax(S[m][:] * scale) over N columns, fp32 in, 16-bit out: the VAE's single-head 512-channel AttnBlock
+// (diffusionmodules/model.py:183-186), whose head dim is far beyond what the streaming attention kernel keeps in LDS, so
+// its scores go through the GEMM kernel (fp32 out) and this pass.  One workgroup per row, row held in registers.
+template <class TT>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, long lds_, typename TT::elem* __restrict__ P,
+                                                           long ldp, int N, float scale) {
+    using E = typename TT::elem;
+    __shared__ float red[8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const float* row = S + (long)blockIdx.x * lds_;
+    E* out = P + (long)blockIdx.x * ldp;
+    constexpr int MAXV = 16;                      // up to 256 * 16 * 4 = 16384 columns
+    float4 v[MAXV];
+    const int nv = (N / 4 + 255) / 256;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (i < nv) {
+            const int c4 = i * 256 + t;
+            v[i] = c4 * 4 < N ? *reinterpret_cast<const float4*>(row + c4 * 4) : make_float4(-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f);
+            mx = fmaxf(mx, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float c = scale * 1.44269504088896340736f, mc = mx * c;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (i < nv) {
+            v[i].x = __builtin_amdgcn_exp2f(fmaf(v[i].x, c, -mc)); v[i].y = __builtin_amdgcn_exp2f(fmaf(v[i].y, c, -mc));
+            v[i].z = __builtin_amdgcn_exp2f(fmaf(v[i].z, c, -mc)); v[i].w = __builtin_amdgcn_exp2f(fmaf(v[i].w, c, -mc));
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((red[4] + red[5]) + (red[6] + red[7]));
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        if (i < nv) {
+            const int c4 = i * 256 + t;
+            if (c4 * 4 < N) {
+                typename TT::v4 o;
+                o[0] = from_f32<E>(v[i].x * inv); o[1] = from_f32<E>(v[i].y * inv);
+                o[2] = from_f32<E>(v[i].z * inv); o[3] = from_f32<E>(v[i].w * inv);
+                *reinterpret_cast<typename TT::v4*>(out + c4 * 4) = o;
+            }
+        }
+    }
+}
+
+// z = (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise) * scale from the quant_conv moments [rows][2*zc] (NHWC fp32):
+// DiagonalGaussianDistribution.sample (distributions.py:24-37) and get_first_stage_encoding's scale_factor; noise == null
+// gives the mode.  Output NCHW fp32 [F][zc][hw], the layout the sampler keeps latents in.
+__global__ void vae_sample_kernel(const float* __restrict__ moments, long ldm, const float* __restrict__ noise,
+                                  float* __restrict__ z, int F, int hw, int zc, float scale) {
+    const long total = (long)F * zc * hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(i % hw);
+        const int c = (int)((i / hw) % zc);
+        const long f = i / ((long)hw * zc);
+        const float* m = moments + (f * hw + p) * ldm;
+        const float mean = m[c];
+        float v = mean;
+        if (noise) {
+            const float lv = fminf(fmaxf(m[zc + c], -30.0f), 20.0f);
+            v = mean + expf(0.5f * lv) * noise[i];
+        }
+        z[i] = v * scale;
+    }
+}
+
 #define DISPATCH_DTYPE(dtype, CALL)            \
     if ((dtype) == VF_DTYPE_F16) { using TT = F16; CALL; } \
     else if ((dtype) == VF_DTYPE_BF16) { using TT = BF16; CALL; } \
@@ -670,6 +748,24 @@ int vf_launch_silu(const void* x, void* y, long count, int in_f32, int dtype, hi
         if (in_f32) hipLaunchKernelGGL((silu_kernel<TT, true>), dim3(grid_for(count)), dim3(256), 0, stream, x, (E*)y, count);
         else hipLaunchKernelGGL((silu_kernel<TT, false>), dim3(grid_for(count)), dim3(256), 0, stream, x, (E*)y, count);
     });
+    return ok();
+}
+
+int vf_launch_softmax_rows(const float* S, long lds_, void* P, long ldp, int M, int N, float scale, int dtype, hipStream_t stream) {
+    if (!S || !P || M <= 0 || N <= 0) return VF_ERR_ARG;
+    if ((N & 3) || (lds_ & 3) || (ldp & 3) || ((uintptr_t)S & 15) || ((uintptr_t)P & 7)) return VF_ERR_ALIGN;
+    if (N > 16384) return VF_ERR_SHAPE;
+    DISPATCH_DTYPE(dtype, {
+        using E = typename TT::elem;
+        hipLaunchKernelGGL((softmax_rows_kernel<TT>), dim3(M), dim3(256), 0, stream, S, lds_, (E*)P, ldp, N, scale);
+    });
+    return ok();
+}
+
+int vf_launch_vae_sample(const float* moments, long ldm, const float* noise, float* z, int F, int hw, int zc, float scale,
+                         hipStream_t stream) {
+    if (!moments || !z || F <= 0 || hw <= 0 || zc <= 0 || ldm < 2 * zc) return VF_ERR_ARG;
+    hipLaunchKernelGGL(vae_sample_kernel, dim3(grid_for((long)F * hw * zc)), dim3(256), 0, stream, moments, ldm, noise, z, F, hw, zc, scale);
     return ok();
 }
 

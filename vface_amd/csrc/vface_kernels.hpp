@@ -18,6 +18,7 @@ struct GemmParams {
     int M, N, K;
     // conv geometry (stored input H x W, output OH x OW)
     int H, W, Cin, OH, OW, stride, upsample;
+    int pad;  // leading (top / left) zero padding: 1, or 0 for the VAE encoder's (0,1,0,1) stride-2 convolution
     const float* bias;     // [N] or null
     const float* rowbias;  // [M / rows_per_sample][ld_rowbias] or null
     int rows_per_sample;
@@ -72,6 +73,9 @@ int vf_launch_flow_warp(const void* src, long ld_src, long fs_src, const void* p
                         hipStream_t stream);
 int vf_launch_timestep_embedding(const long long* t, void* out, int N, int dim, int dtype, hipStream_t stream);
 int vf_launch_silu(const void* x, void* y, long count, int in_f32, int dtype, hipStream_t stream);
+int vf_launch_softmax_rows(const float* S, long lds_, void* P, long ldp, int M, int N, float scale, int dtype, hipStream_t stream);
+int vf_launch_vae_sample(const float* moments, long ldm, const float* noise, float* z, int F, int hw, int zc, float scale,
+                         hipStream_t stream);
 int vf_launch_pack_input(const float* x, const float* inv, const float* inpaint, const float* mask, void* out,
                          int F, int h, int w, int cpad, int dtype, hipStream_t stream);
 int vf_launch_nchw_to_nhwc(const float* x, void* out, int N, int C, int hw, int cpad, int dtype, hipStream_t stream);

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvface_hip.so")
 
 F16, BF16 = 0, 1
 EPI_GEGLU, EPI_OUT_F32 = 1, 2
+CONV_PAD_TRAILING = 0x40000  # conv3x3: zero padding (0,1,0,1) (the VAE encoder's Downsample)
 TUNE_NO_PERSISTENT, TUNE_PERSISTENT = 0x10000, 0x20000  # flags of gemm / conv3x3: force one workgroup per tile / the persistent form
 FUSION_NONE, FUSION_REPLACE, FUSION_LINEAR = 0, 1, 2
 
@@ -50,6 +51,8 @@ SIGNATURES = {
     "vface_adain_fusion": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _sz, _i32, _vp]),
     "vface_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "vface_silu": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "vface_softmax_rows": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _f32, _i32, _vp]),
+    "vface_vae_sample": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "vface_cast_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "vface_pack_unet_input": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vface_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -298,3 +301,17 @@ def adain_fusion(a, b, dst, *, rows, C_, lda, ldb, ldd):
     rc = lib.vface_adain_fusion(_p(a), lda, _p(b), ldb, _p(dst), ldd, rows, C_, _p(ws), ws.numel(), dtype_code(a.dtype),
                                 _stream())
     _check(rc, "vface_adain_fusion")
+
+
+def softmax_rows(scores: torch.Tensor, out: torch.Tensor, *, M: int, N: int, scale: float, ld_s: Optional[int] = None,
+                 ld_p: Optional[int] = None):
+    """out[m, :N] = softmax(scores[m, :N] * scale); fp32 in, 16-bit out."""
+    rc = load().vface_softmax_rows(_p(scores), ld_s if ld_s is not None else scores.stride(0), _p(out),
+                                   ld_p if ld_p is not None else out.stride(0), M, N, scale, dtype_code(out.dtype), _stream())
+    _check(rc, "vface_softmax_rows")
+
+
+def vae_sample(moments: torch.Tensor, noise: Optional[torch.Tensor], z: torch.Tensor, *, F: int, hw: int, zc: int,
+               scale: float):
+    rc = load().vface_vae_sample(_p(moments), moments.stride(0), _p(noise), _p(z), F, hw, zc, scale, _stream())
+    _check(rc, "vface_vae_sample")

@@ -1,7 +1,9 @@
 """The thin slice of ``REFace/ldm/models/diffusion/ddpm.py`` that sits on the hot path:
 ``LatentDiffusion.apply_model`` (ddpm.py:1519-1617) and ``DiffusionWrapper.forward`` (:2231-2257) for
 ``conditioning_key: crossattn``, plus the schedule buffers of ``DDPM.register_schedule`` the sampler reads.
-Conditioning encoders, the VAE, losses and training (the other ~2270 lines) are out of scope.
+The first-stage VAE is optional: ``first_stage_config`` builds ``AutoencoderKL`` under ``first_stage_model``
+and ``encode_first_stage`` / ``get_first_stage_encoding`` / ``decode_first_stage`` (:1402, :850-857, :1277-1284) work as in
+the reference.  Conditioning encoders, losses and training (the other ~2200 lines) are out of scope.
 
 State-dict keys of the UNet are ``model.diffusion_model.*`` as in ``last.ckpt`` so
 ``load_state_dict(ckpt["state_dict"], strict=False)`` (VFace_inference_batch.py:118-135) fills it unchanged.
@@ -31,9 +33,12 @@ class DiffusionWrapper(nn.Module):
 
 class LatentDiffusion(nn.Module):
     def __init__(self, unet_config: dict, timesteps=1000, linear_start=0.00085, linear_end=0.012,
-                 beta_schedule="linear", scale_factor=0.18215, parameterization="eps"):
+                 beta_schedule="linear", scale_factor=0.18215, parameterization="eps", first_stage_config=None):
         super().__init__()
         self.model = DiffusionWrapper(UNetModel(**unet_config))
+        if first_stage_config is not None:
+            from ..autoencoder import AutoencoderKL
+            self.first_stage_model = AutoencoderKL(**first_stage_config)
         self.parameterization = parameterization
         self.scale_factor = scale_factor
         self.num_timesteps = int(timesteps)
@@ -51,6 +56,23 @@ class LatentDiffusion(nn.Module):
     @property
     def unet(self) -> UNetModel:
         return self.model.diffusion_model
+
+    # ---- first stage (ddpm.py:1402-1420, 850-857, 1277-1300; the patch-split branches are not configured) ----
+    def encode_first_stage(self, x):
+        return self.first_stage_model.encode(x)
+
+    def get_first_stage_encoding(self, encoder_posterior, noise=None):
+        from ...modules.distributions.distributions import DiagonalGaussianDistribution
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
+            return encoder_posterior.sample(noise, scale=self.scale_factor)   # scale_factor * sample(), one kernel
+        if isinstance(encoder_posterior, torch.Tensor):
+            return self.scale_factor * encoder_posterior
+        raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
+
+    def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):
+        if predict_cids:
+            raise NotImplementedError("predict_cids belongs to VQ first stages; the VFace configuration uses AutoencoderKL")
+        return self.first_stage_model.decode(1. / self.scale_factor * z)
 
     def apply_model(self, x_noisy, t, cond):
         if isinstance(cond, dict):
