@@ -140,6 +140,12 @@ def test_cli_synthetic_smoke(tmp_path):
                     "--max_steps", "2", "--Base_dir", str(tmp_path / "out"), "--ddim_steps", "50"])
     assert len(res["batches"]) == 2 and all(b["finite"] for b in res["batches"])
     assert (tmp_path / "out" / "samples_batch1.pt").exists()
+    # the same run with the first-stage VAE in the loop: synthetic images -> encode -> DDIM -> decode -> pixels in [0, 1]
+    res = cli.main(["--synthetic", "--with_vae", "--config", str(ypath), "--n_frames", "2", "--n_samples", "2", "--H", "256",
+                    "--W", "256", "--max_steps", "2", "--Base_dir", str(tmp_path / "out_vae"), "--ddim_steps", "50"])
+    assert res["batches"][0]["finite"] and res["batches"][0]["pixels"] == [2, 3, 256, 256]
+    px = torch.load(tmp_path / "out_vae" / "pixels_batch0.pt")
+    assert px.min() >= 0 and px.max() <= 1
 
 
 @pytest.mark.parametrize("mode", ["in_flow_fix"])

@@ -54,6 +54,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--precision", type=str, choices=["full", "autocast"], default="autocast")
     # additions of this build
     p.add_argument("--synthetic", action="store_true", help="synthetic latents/conditioning/flow instead of video I/O")
+    p.add_argument("--with_vae", action="store_true",
+                   help="synthetic run through the first-stage KL-VAE too: the inpaint latents come from encode_first_stage of "
+                        "synthetic images (:456-457) and the samples are decoded to pixels (:596-600)")
     p.add_argument("--fusion", type=str, default="flow_fix", help="hook mode on the input-block attn1 modules")
     p.add_argument("--no_inversion", action="store_true", help="use random recon latents instead of DDIM inversion")
     p.add_argument("--compute_dtype", choices=["fp16", "bf16"], default="fp16")
@@ -80,15 +83,21 @@ def run_synthetic(opt) -> dict:
     dt = torch.float16 if opt.compute_dtype == "fp16" else torch.bfloat16
     cfg = load_unet_config(opt.config)
     cfg["compute_dtype"] = dt
-    model = LatentDiffusion(cfg)
+    if opt.with_vae:
+        from ..ldm.models.autoencoder import FFHQ_VAE_CONFIG
+        model = LatentDiffusion(cfg, first_stage_config=dict(FFHQ_VAE_CONFIG, compute_dtype=dt))
+    else:
+        model = LatentDiffusion(cfg)
     if opt.ckpt:
         sd = torch.load(opt.ckpt, map_location="cpu")
         sd = sd.get("state_dict", sd)
         missing, unexpected = model.load_state_dict(
-            {k: v for k, v in sd.items() if k.startswith("model.diffusion_model.")}, strict=False)
+            {k: v for k, v in sd.items() if k.startswith(("model.diffusion_model.", "first_stage_model."))}, strict=False)
         print(f"loaded {opt.ckpt}: {len(missing)} missing, {len(unexpected)} unexpected keys")
     else:
         synth.fill_module_(model.unet, seed=0)
+        if opt.with_vae:
+            synth.fill_module_(model.first_stage_model, seed=0, prefix="vae.")
     model = model.to(dev).eval()
     sampler = DDIMSampler(model)
     sampler.hook_plan = HookPlan(fusion=opt.fusion, enabled=opt.fusion != "none")
@@ -100,7 +109,11 @@ def run_synthetic(opt) -> dict:
         tag = lambda s: f"cli.{s}.{batch_id}"
         d = lambda t: t.to(dev)
         c, uc, tc = (d(synth.synth_normal(tag(k), (F_, 1, 768))) for k in ("c", "uc", "tc"))
-        z_inp = d(synth.synth_normal(tag("inp"), (F_, opt.C, h, w)) * 0.18215)
+        if opt.with_vae:
+            img = d(torch.stack([synth.synth_normal(tag(f"img{f}"), (3, opt.H, opt.W)).clamp(-1, 1) for f in range(F_)]))
+            z_inp = model.get_first_stage_encoding(model.encode_first_stage(img)).detach()       # :456-457
+        else:
+            z_inp = d(synth.synth_normal(tag("inp"), (F_, opt.C, h, w)) * 0.18215)
         mask = d(synth.synth_mask(F_, h, w))
         flow = [f[None] for f in synth.synth_flow(F_ - 1, h, w, seed=opt.seed + batch_id)]
         kw = {"inpaint_image": z_inp, "inpaint_mask": mask}
@@ -132,10 +145,17 @@ def run_synthetic(opt) -> dict:
                                     test_model_kwargs=kw, max_steps=opt.max_steps)
         torch.cuda.synchronize()
         dt_s = time.time() - t0
+        pixels = None
+        if opt.with_vae:
+            x_samples = model.decode_first_stage(samples)                                          # :596
+            pixels = torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0)                       # :597
         if not opt.skip_save:
             torch.save(samples.cpu(), os.path.join(opt.Base_dir, f"samples_batch{batch_id}.pt"))
+            if pixels is not None:
+                torch.save(pixels.cpu(), os.path.join(opt.Base_dir, f"pixels_batch{batch_id}.pt"))
         results.append({"batch": batch_id, "frames": F_, "sample_seconds": dt_s,
-                        "finite": bool(torch.isfinite(samples).all())})
+                        "finite": bool(torch.isfinite(samples).all()) and (pixels is None or bool(torch.isfinite(pixels).all())),
+                        "pixels": None if pixels is None else list(pixels.shape)})
         print(f"batch {batch_id}: {F_} frames sampled in {dt_s:.2f} s")
     return {"batches": results, "total_seconds": time.time() - t_all}
 
@@ -147,7 +167,7 @@ def main(argv=None):
         raise NotImplementedError("--plms selects PLMSSampler, which is outside the VFace hot path (SURVEY §2)")
     if not opt.synthetic:
         sys.exit("Only the denoising hot path is built here.  Video decoding, dlib/BiSeNet pre-processing, CLIP/ArcFace "
-                 "conditioning, the KL-VAE and paste-back (VFace_inference_batch.py:193-528,596-670) need checkpoints "
+                 "conditioning and paste-back (VFace_inference_batch.py:193-528,603-670) need checkpoints "
                  "that are not available offline; run with --synthetic, or feed real latents through "
                  "vface_amd.ldm.models.diffusion.ddim_w_inv.DDIMSampler (see INTEGRATION.md).")
     if not torch.cuda.is_available():
