@@ -58,9 +58,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     constexpr int KROW = k_row_elems(DKP);           // elements
     constexpr int VROW = v_pitch_bytes(DVP) / 2;     // elements
     constexpr int CPR = DH / 8;                      // 16-B chunks per K row (and per V row of one set)
-    constexpr int NCH = KVB * CPR;                   // chunks per K block
-    constexpr int SR = (NCH + 255) / 256;            // staging rounds
-    constexpr int CPRV = G * CPR, NCHV = KVB * CPRV, SRV = (NCHV + 255) / 256;
+
+
+    constexpr int CPRV = G * CPR;
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     E* sK = reinterpret_cast<E*>(smem_raw);          // [2][KVB][KROW]
@@ -87,7 +87,6 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     const int bqk = p.qk_map ? p.qk_map[b] : b;
     const int gs = p.set_stride;                     // output / value sample of set g: b + g*gs
     const E* Qg = reinterpret_cast<const E*>(p.Q) + (long)bqk * p.bsq + h * DH;
-    const E* Kg = reinterpret_cast<const E*>(p.K) + (long)bqk * p.bsk + h * DH;
     const int nk = p.nk;
 
     // zero LDS once: pad columns (DH..DKP of K, DH..DVP of V) are never written again
@@ -123,58 +122,59 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         qt4[qt] = w;
     }
 
-    // staging map, fixed for the whole walk: thread t moves 16-B chunk min(r*256 + t, NCH-1) of the K and V blocks
-    // (the clamp makes the last round's surplus threads repeat chunk NCH-1: same bytes to the same place, no branch)
-    uint4 kreg[SR], vreg[SRV];
-    const E* kptr[SR];
-    const E* vptr[SRV];
-    int srow[SR], lds_k[SR], srow_v[SRV], lds_v[SRV];
+    // K / V blocks go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 16 B per lane, lane-linear destination): no
+    // staging registers, no ds_write pass, and a padding slot / a key row past nk is an out-of-range offset (zeros).
+    // One DMA instruction fills 64 consecutive 16-B slots of a block; slot id -> (row, slot in row); the K rows' XOR
+    // swizzle is applied on the SOURCE chunk index.  V slots past the value columns are masked out, so the ones column
+    // and the zero padding written once at kernel start survive.
+    constexpr int SK = KROW / 8, SV = VROW / 8;            // 16-B slots per K / V row
+    constexpr int RK = (KVB * SK + 255) / 256, RV = (KVB * SV + 255) / 256;
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.K), 0, (int)p.k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.V), 0, (int)p.v_bytes, 0x00020000);
+    unsigned koff[RK], voff[RV];       // byte offset of this lane's chunk in key block 0 (OOB: never loads)
+    int krow[RK], vrow[RV];
+    bool vact[RV];
 #pragma unroll
-    for (int r = 0; r < SR; ++r) {
-        const int id = min(r * 256 + t, NCH - 1);
-        const int row = id / CPR, c = id - row * CPR;
-        srow[r] = row;
-        kptr[r] = Kg + (long)row * p.ldk + c * 8;
-        lds_k[r] = row * KROW + k_slot<KROW>(row, c) * 8;
+    for (int r = 0; r < RK; ++r) {
+        const int id = r * 256 + t;
+        const int row = id / SK, sl = id - row * SK;
+        int c = sl;
+        if (KROW == 64) c = sl ^ ((row >> 1) & 7);
+        if (KROW == 128) c = sl ^ (row & 15);
+        krow[r] = row;
+        koff[r] = (row < KVB && c < CPR) ? (unsigned)((((long)bqk * p.bsk + h * DH + (long)row * p.ldk + c * 8)) * 2) : OOB;
     }
 #pragma unroll
-    for (int r = 0; r < SRV; ++r) {
-        const int id = min(r * 256 + t, NCHV - 1);
-        const int row = id / CPRV, cc = id - row * CPRV;
-        const int g = cc / CPR, c = cc - g * CPR;
-        const int bo = b + g * gs;
+    for (int r = 0; r < RV; ++r) {
+        const int id = r * 256 + t;
+        const int row = id / SV, sl = id - row * SV;
+        const int g = sl / CPR, c = sl - g * CPR;
+        vrow[r] = row;
+        vact[r] = row < KVB && sl < CPRV;
+        const int bo = b + (g < G ? g : 0) * gs;
         const int bv = p.v_map ? p.v_map[bo] : bo;
-        srow_v[r] = row;
-        vptr[r] = reinterpret_cast<const E*>(p.V) + (long)bv * p.bsv + h * DH + (long)row * p.ldv + c * 8;
-        lds_v[r] = row * VROW + g * DH + c * 8;
+        voff[r] = vact[r] ? (unsigned)((((long)bv * p.bsv + h * DH + (long)row * p.ldv + c * 8)) * 2) : OOB;
     }
-    const long kstep = (long)KVB * p.ldk, vstep = (long)KVB * p.ldv;
-    auto load_block = [&](int kb) {
-        if ((kb + 1) * KVB <= nk) {  // full block (wave-uniform): no per-key guard
-#pragma unroll
-            for (int r = 0; r < SR; ++r) kreg[r] = *reinterpret_cast<const uint4*>(kptr[r]);
-#pragma unroll
-            for (int r = 0; r < SRV; ++r) vreg[r] = *reinterpret_cast<const uint4*>(vptr[r]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < SR; ++r)
-                kreg[r] = (kb * KVB + srow[r] < nk) ? *reinterpret_cast<const uint4*>(kptr[r]) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < SRV; ++r)
-                vreg[r] = (kb * KVB + srow_v[r] < nk) ? *reinterpret_cast<const uint4*>(vptr[r]) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int r = 0; r < SR; ++r) kptr[r] += kstep;
-#pragma unroll
-        for (int r = 0; r < SRV; ++r) vptr[r] += vstep;
-    };
-    auto store_block = [&](int buf) {
+    const unsigned kstep = (unsigned)(KVB * p.ldk * 2), vstep = (unsigned)(KVB * p.ldv * 2);
+    auto stage_block = [&](int kb, int buf) {
         E* dK = sK + buf * KVB * KROW;
         E* dV = sV + buf * KVB * VROW;
+        const int r0 = kb * KVB;
 #pragma unroll
-        for (int r = 0; r < SR; ++r) *reinterpret_cast<uint4*>(dK + lds_k[r]) = kreg[r];
+        for (int r = 0; r < RK; ++r) {
+            if (r * 256 + wave * 64 < KVB * SK) {          // wave-uniform: this instruction has slots to fill
+                const unsigned off = (koff[r] != OOB && r0 + krow[r] < nk) ? koff[r] + (unsigned)kb * kstep : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, LDS_PTR(dK + (r * 256 + wave * 64) * 8), 16, off, 0, 0, 0);
+            }
+        }
 #pragma unroll
-        for (int r = 0; r < SRV; ++r) *reinterpret_cast<uint4*>(dV + lds_v[r]) = vreg[r];
+        for (int r = 0; r < RV; ++r) {
+            if (r * 256 + wave * 64 < KVB * SV) {
+                const unsigned off = (r0 + vrow[r] < nk) ? voff[r] + (unsigned)kb * vstep : OOB;
+                if (vact[r]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, LDS_PTR(dV + (r * 256 + wave * 64) * 8), 16, off, 0, 0, 0);
+            }
+        }
     };
 
     f4_t o[NC][QT];
@@ -189,9 +189,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     const float cexp = p.scale * 1.44269504088896340736f;
     const int nblocks = (nk + KVB - 1) / KVB;
 
-    load_block(0);
-    __syncthreads();  // zero fill done
-    store_block(0);
+    __syncthreads();  // zero fill (and the ones column) done before the first DMA lands
+    stage_block(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // DIAGNOSTIC (compiled only with -DVFACE_ATTN_STAMPS; variant bit 8, never set by the engine): s_memtime stamps around the phases of a key block; the sums
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     stamp(-1);
     for (int kb = 0; kb < nblocks; ++kb) {
         const int cur = kb & 1;
-        if (kb + 1 < nblocks) load_block(kb + 1);
+        if (kb + 1 < nblocks) stage_block(kb + 1, cur ^ 1);   // lands under this block's math; the other buffer is free
         stamp(0);
         const E* cK = sK + cur * KVB * KROW;
         const E* cV = sV + cur * KVB * VROW;
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
             }
         }
         stamp(3);
-        if (kb + 1 < nblocks) store_block(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(4);
         __syncthreads();
         stamp(5);
@@ -413,6 +413,14 @@ int vf_launch_attention(const AttnParams& p_in, int dtype, hipStream_t stream) {
     if ((uintptr_t)p.O & 7) return VF_ERR_ALIGN;
     if ((p.ldq | p.ldk | p.ldv | p.bsq | p.bsk | p.bsv) & 7) return VF_ERR_ALIGN;
     if ((p.ldo | p.bso) & 3) return VF_ERR_ALIGN;
+    // extents of the K / V views for the buffer descriptors (sources are bounds-checked: a map entry past the batch reads zeros)
+    {
+        const unsigned long nsamp = p.v_sets > 1 ? (unsigned long)(p.v_sets - 1) * p.set_stride + p.B : (unsigned long)p.B;
+        const unsigned long kb = ((nsamp - 1) * p.bsk + (unsigned long)(p.nk - 1) * p.ldk + (unsigned long)p.heads * p.dh) * 2;
+        const unsigned long vb = ((nsamp - 1) * p.bsv + (unsigned long)(p.nk - 1) * p.ldv + (unsigned long)p.heads * p.dh) * 2;
+        if (kb >= 0xFFFFFFF0ul || vb >= 0xFFFFFFF0ul) return VF_ERR_SHAPE;
+        p.k_bytes = (unsigned)kb; p.v_bytes = (unsigned)vb;
+    }
     if (dtype == VF_DTYPE_F16) return dispatch<F16>(p, stream);
     if (dtype == VF_DTYPE_BF16) return dispatch<BF16>(p, stream);
     return VF_ERR_DTYPE;

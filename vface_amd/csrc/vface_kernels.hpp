@@ -54,6 +54,7 @@ struct AttnParams {
     int B, heads, n, nk, dh;      // nk = number of keys (== n for self-attention)
     float scale;
     int variant;  // 0 = automatic; queries-per-wave variants for A/B benchmarking
+    unsigned k_bytes, v_bytes;    // filled by the launcher: extents of the K / V views (buffer descriptors, < 4 GiB)
     int v_sets, set_stride;  // > 1: B q/k samples; output (and value) sample of set g is b + g*set_stride, scores shared
 };
 int vf_launch_attention(const AttnParams& p, int dtype, hipStream_t stream);
