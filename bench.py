@@ -239,10 +239,10 @@ def main():
         # 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md "HBM"); the committed summary is quoted
         # only for the workload it was collected on, otherwise null.
         traffic, traffic_src = None, None
-        tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_b_hbm_traffic.json")
+        tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_c_hbm_traffic.json")
         if os.path.exists(tf) and F_ == 8 and h == 64 and a.fusion == "replace" and a.dtype == "fp16":
             traffic = json.load(open(tf))["_conv_all"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_b_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+            traffic_src = "profiles/r01_c_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
         out = {
             "metric": "swapped frames/sec at 512x512, 50-step DDIM", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
