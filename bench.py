@@ -200,6 +200,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(a.steps):
             img = one_step(img, i)
+        t_enq = time.perf_counter() - t0      # host time to enqueue the steps (the GPU runs behind)
         fence()
         el = time.perf_counter() - t0
         timer.on = False
@@ -228,7 +229,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     ms_step = el / a.steps * 1e3
-    log(f"timed {a.steps} steps: {ms_step:.2f} ms/step")
+    log(f"timed {a.steps} steps: {ms_step:.2f} ms/step (host enqueue {t_enq / a.steps * 1e3:.2f} ms/step)")
     fps = (F_ * world) / (a.ddim_steps * ms_step / 1e3)
     n_launch, conv_ms, conv_flops = timer.summary()
     out = None

@@ -3,8 +3,8 @@
 // pnp_utils.py:270-287).  8 heads, head dim 40 / 80 / 160 (8 / 16 / 32 for the test-size UNet).
 //
 // * One workgroup = 4 waves = 64*QT queries of one (sample, head); each wave owns 16*QT queries.
-// * Keys are walked in blocks of 64.  K and V blocks are staged global -> registers -> LDS (two LDS
-//   buffers, next block's loads issued before the current block's math, written after it).
+// * Keys are walked in blocks of 64.  K and V blocks go global -> LDS by LDS-DMA (two LDS buffers, the next
+//   block's loads are issued before the current block's math and waited for after it).
 // * Scores are computed TRANSPOSED, S^T = K Q^T, with mfma_f32_16x16x32: a lane then holds 16 keys of
 //   ONE query, so the row max / row sum are in-lane plus two cross-lane steps, and the fp32 accumulator
 //   registers, converted to 16 bit, are directly the B operand of O^T += V^T P^T (no LDS round trip).
