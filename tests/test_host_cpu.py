@@ -86,3 +86,27 @@ def test_pack_geglu_and_conv():
     cols = F.unfold(F.pad(xi, (0, 0, 0, 0, 0, 7)), 3, padding=1)  # [1, 16*9, 25], (c, ky, kx) order
     cols = cols.reshape(1, 16, 9, 25).permute(0, 2, 1, 3).reshape(1, 144, 25)  # -> (ky, kx, c)
     assert torch.allclose((pw @ cols[0]).reshape(1, 6, 5, 5), ref, atol=1e-5)
+
+
+def test_every_entry_point_rejects_null_arguments_without_a_gpu():
+    """Error behaviour of the C ABI: invalid arguments give a negative VFACE_ERR_* and nothing is launched
+    -- checked here with all-zero arguments, which every launcher refuses before its first HIP call."""
+    from vface_amd import hip
+    lib = hip.load()
+    import ctypes as C
+    checked = 0
+    for name, (restype, argtypes) in hip.SIGNATURES.items():
+        if restype is not C.c_int or not any(a is C.c_void_p for a in argtypes):
+            continue
+        if name in ("vface_attention_shared_scores_supported",):
+            continue
+        args = [None if a is C.c_void_p else (0.0 if a is C.c_float else 0) for a in argtypes]
+        rc = getattr(lib, name)(*args)
+        assert rc < 0, (name, rc)
+        msg = lib.vface_error_string(rc)
+        assert msg and b"unknown" not in msg.lower(), (name, rc, msg)
+        checked += 1
+    assert checked >= 15
+    assert lib.vface_splitk_workspace_bytes(0, 0, 0, 0, 0) == 0
+    assert lib.vface_attn1_workspace_bytes(0, 0, 0, 0) == 0
+    assert lib.vface_attention_shared_scores_supported(40, 3) == 1 and lib.vface_attention_shared_scores_supported(80, 3) == 0
