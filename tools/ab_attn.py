@@ -20,9 +20,19 @@ def timeit(var, iters=8):
         run(var); ev[i + 1].record()
     torch.cuda.synchronize()
     return statistics.median(ev[i].elapsed_time(ev[i + 1]) for i in range(iters)) * 1e3
-res = {0: [], 1: []}
+res = {0: [], 1: [], 2: []}
 for _ in range(6):
-    for v in (0, 1):
+    for v in (0, 1, 2):
         res[v].append(timeit(v))
-for v in (0, 1):
-    print(f"variant {v} (QT={'4' if v == 0 else '2'}): median {statistics.median(res[v]):7.1f} us  all {[round(x) for x in res[v]]}")
+for v in (0, 1, 2):
+    print(f"variant {v} (QT={'2' if v == 1 else '4'}{' exact-scale' if v == 2 else ' lazy'}): median {statistics.median(res[v]):7.1f} us  all {[round(x) for x in res[v]]}")
+
+ref = None
+def ref_attn():
+    sp = lambda t: t.reshape(2, n, 8, dh).permute(0, 2, 1, 3).double()
+    a = torch.softmax(sp(qkv[:2, :, :d]) @ sp(qkv[:2, :, d:2 * d]).transpose(-1, -2) * dh ** -0.5, -1) @ sp(qkv[:2, :, 2 * d:])
+    return a.permute(0, 2, 1, 3).reshape(2, n, d)
+r = ref_attn()
+for v in (0, 2):
+    run(v); e = ((out[:2].double() - r).norm() / r.norm()).item()
+    print(f"variant {v}: rel-L2 vs fp64 reference {e:.3e}")

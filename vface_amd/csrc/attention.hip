@@ -9,7 +9,9 @@
 //   ONE query, so the row max / row sum are in-lane plus two cross-lane steps, and the fp32 accumulator
 //   registers, converted to 16 bit, are directly the B operand of O^T += V^T P^T (no LDS round trip).
 //   V^T fragments come from the row-major V block with ds_read_b64_tr_b16.
-// * Softmax is fp32 (as autocast keeps it, SURVEY precision map): p = exp2((s - m) * scale*log2e).
+// * Softmax is fp32 (as autocast keeps it, SURVEY precision map).  Default form: scale*log2e is folded into q and the
+//   running reference enters the score MFMA as its C operand, p = exp2(s - m_ref) (see LAZY below); the exact-scale
+//   form p = exp2((s - m) * scale*log2e) is kept behind variant bit 1.
 // * Sample remapping: output sample b reads q,k of sample qk_map[b] and v of sample v_map[b].  This is
 //   how the hook's "replace" / chunks==2 injection (pnp_utils.py:136-142,259-262) and fft_vfixed's
 //   V broadcast (:255-256) run without copying anything.
@@ -39,7 +41,12 @@ constexpr int v_pitch_bytes(int dvp) {
 // uses q,k of chunk 0, so softmax(q k^T) is the SAME matrix for the G chunks of a frame and only V differs: one
 // workgroup computes the probabilities once and multiplies them with the G value blocks side by side (a G*DH-wide
 // V tile), writing G output samples.  1/G of the QK^T MFMAs and of the exponentials.
-template <class TT, int DH, int QT, int G>
+// LAZY: the softmax scale is folded into Q once (q <- fp16(q * scale * log2 e)) and the running reference m_ref enters
+// the score MFMA as its C operand, so a score leaves the matrix pipe as (s - m_ref) in base-2 units and needs only the
+// exponential: one VALU op per score less than the exact form.  m_ref follows the running max loosely -- it is raised
+// (with the usual rescale of O) only when a block's max exceeds it by more than 8, so P stays below 2^8 (exact in fp32
+// accumulation; fp16 keeps its relative precision).  Costs one extra fp16 rounding of q.
+template <class TT, int DH, int QT, int G, bool LAZY>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
@@ -121,6 +128,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         if (TAIL && q < p.n && NKS * 32 + fg * 4 < DH) w = *reinterpret_cast<const V4*>(Qg + (long)q * p.ldq + NKS * 32 + fg * 4);
         qt4[qt] = w;
     }
+    if constexpr (LAZY) {
+        const float cq = p.scale * 1.44269504088896340736f;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) qf[qt][ks][j] = from_f32<E>(to_f32(qf[qt][ks][j]) * cq);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qt4[qt][j] = from_f32<E>(to_f32(qt4[qt][j]) * cq);
+        }
+    }
 
     // K / V blocks go global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 16 B per lane, lane-linear destination): no
     // staging registers, no ds_write pass, and a padding slot / a key row past nk is an out-of-range offset (zeros).
@@ -185,6 +204,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     float m_run[QT], l_run[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -1e30f; l_run[qt] = 0.f; }
+    f4_t cneg[QT];   // LAZY: -m_ref of this lane's query, the C operand of the score MFMAs
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) cneg[qt] = f4_t{0.f, 0.f, 0.f, 0.f};
 
     const float cexp = p.scale * 1.44269504088896340736f;
     const int nblocks = (nk + KVB - 1) / KVB;
@@ -224,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 #pragma unroll
         for (int tl = 0; tl < 4; ++tl) {
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) s[tl][qt] = f4_t{0.f, 0.f, 0.f, 0.f};
+            for (int qt = 0; qt < QT; ++qt) s[tl][qt] = LAZY ? cneg[qt] : f4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 const V8 kf = *reinterpret_cast<const V8*>(cK + (tl * 16 + fr) * KROW + k_slot<KROW>(tl * 16 + fr, ks * 4 + fg) * 8);
@@ -256,6 +278,34 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[tl][qt][r]);
             mx = quad_row_max(mx);
+            float ls = 0.f;
+            if constexpr (LAZY) {
+                // scores are relative to m_ref already.  Raise m_ref (first block: set it) only where needed.
+                const bool shift = (kb == 0) || (mx > 8.0f);
+                if (__any(shift)) {
+                    const float delta = shift ? mx : 0.f;
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cneg[qt][r] -= delta;
+                    if (!ONES) l_run[qt] *= alpha;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[c][qt][r] *= alpha;
+#pragma unroll
+                    for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[tl][qt][r] -= delta;
+                }
+#pragma unroll
+                for (int tl = 0; tl < 4; ++tl)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(s[tl][qt][r]);
+                        s[tl][qt][r] = pv;
+                        if (!ONES) ls += pv;
+                    }
+            } else {
             const float m_new = fmaxf(m_run[qt], mx);
             // the running max rarely moves after the first key blocks: rescale only when some query's did
             // (alpha == 1 exactly otherwise, so skipping is exact, not an approximation)
@@ -269,7 +319,6 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
                     for (int r = 0; r < 4; ++r) o[c][qt][r] *= alpha;
             }
             const float mc = m_run[qt] * cexp;
-            float ls = 0.f;
 #pragma unroll
             for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
@@ -278,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
                     s[tl][qt][r] = pv;
                     if (!ONES) ls += pv;
                 }
+            }
             if (!ONES) l_run[qt] += ls;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
@@ -348,12 +398,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     }
 }
 
-template <class TT, int DH, int QT, int G = 1>
+template <class TT, int DH, int QT, int G = 1, bool LAZY = false>
 int launch(const AttnParams& p, hipStream_t stream) {
     constexpr int DKP = (DH / 32) * 32 + ((DH % 32) ? 16 : 0), DVP = round_up(G * DH, 16);
     constexpr int KROW = k_row_elems(DKP), VROW = v_pitch_bytes(DVP) / 2;
     constexpr size_t lds = (size_t)(2 * KVB * KROW + 2 * KVB * VROW) * 2;
-    auto kern = attn_kernel<TT, DH, QT, G>;
+    auto kern = attn_kernel<TT, DH, QT, G, LAZY>;
     static bool attr_set = false;
     if (lds > 64 * 1024 && !attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -366,35 +416,42 @@ int launch(const AttnParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
 }
 
-template <class TT>
-int dispatch(const AttnParams& p, hipStream_t stream) {
+template <class TT, bool LAZY>
+int dispatch_l(const AttnParams& p, hipStream_t stream) {
     if (p.v_sets == 2) {
         switch (p.dh) {
-            case 8: return launch<TT, 8, 2, 2>(p, stream);
-            case 16: return launch<TT, 16, 2, 2>(p, stream);
-            case 32: return launch<TT, 32, 2, 2>(p, stream);
-            case 40: return launch<TT, 40, 2, 2>(p, stream);
+            case 8: return launch<TT, 8, 2, 2, LAZY>(p, stream);
+            case 16: return launch<TT, 16, 2, 2, LAZY>(p, stream);
+            case 32: return launch<TT, 32, 2, 2, LAZY>(p, stream);
+            case 40: return launch<TT, 40, 2, 2, LAZY>(p, stream);
             default: return VF_ERR_SHAPE;
         }
     }
     if (p.v_sets == 3) {
         switch (p.dh) {
-            case 8: return launch<TT, 8, 2, 3>(p, stream);
-            case 16: return launch<TT, 16, 2, 3>(p, stream);
-            case 32: return launch<TT, 32, 2, 3>(p, stream);
-            case 40: return launch<TT, 40, 2, 3>(p, stream);
+            case 8: return launch<TT, 8, 2, 3, LAZY>(p, stream);
+            case 16: return launch<TT, 16, 2, 3, LAZY>(p, stream);
+            case 32: return launch<TT, 32, 2, 3, LAZY>(p, stream);
+            case 40: return launch<TT, 40, 2, 3, LAZY>(p, stream);
             default: return VF_ERR_SHAPE;
         }
     }
     switch (p.dh) {
-        case 8: return launch<TT, 8, 2>(p, stream);
-        case 16: return launch<TT, 16, 2>(p, stream);
-        case 32: return launch<TT, 32, 2>(p, stream);
-        case 40: return p.variant == 1 ? launch<TT, 40, 2>(p, stream) : launch<TT, 40, 4>(p, stream);
-        case 80: return launch<TT, 80, 2>(p, stream);
-        case 160: return launch<TT, 160, 1>(p, stream);
+        case 8: return launch<TT, 8, 2, 1, LAZY>(p, stream);
+        case 16: return launch<TT, 16, 2, 1, LAZY>(p, stream);
+        case 32: return launch<TT, 32, 2, 1, LAZY>(p, stream);
+        case 40: return (p.variant & 1) ? launch<TT, 40, 2, 1, LAZY>(p, stream) : launch<TT, 40, 4, 1, LAZY>(p, stream);
+        case 80: return launch<TT, 80, 2, 1, LAZY>(p, stream);
+        case 160: return launch<TT, 160, 1, 1, LAZY>(p, stream);
         default: return VF_ERR_SHAPE;
     }
+}
+
+// variant bit 0: 2 query tiles per wave at dh = 40 (A/B); bit 1: the exact-scale softmax (scale applied to the fp32 scores
+// instead of folded into q: one more VALU op per score, one fp16 rounding of q less)
+template <class TT>
+int dispatch(const AttnParams& p, hipStream_t stream) {
+    return (p.variant & 2) ? dispatch_l<TT, false>(p, stream) : dispatch_l<TT, true>(p, stream);
 }
 
 }  // namespace
