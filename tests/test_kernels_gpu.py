@@ -481,3 +481,34 @@ def test_conv_persistent_matches_one_tile_per_workgroup():
     ref = F.conv2d(x[:1].float().cpu().permute(0, 3, 1, 2), rnd((cout, cin, 3, 3), 2, dt, 1 / math.sqrt(9 * cin)).float(),
                    b.cpu(), padding=1)
     assert rel_l2(outs[0][0][:1].float().cpu().permute(0, 3, 1, 2), ref) < TOL[dt]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dh,n", [(40, 640), (80, 256)])
+def test_attention_wide_logit_range(dh, n):
+    """Peaked softmax rows (logit std > 10, row maxima that keep rising along the key walk): the lazily raised reference of
+    the default softmax form must track them -- compared with fp64 and with the exact-scale form of the kernel."""
+    h = hip()
+    dt = torch.float16
+    B, heads = 2, 8
+    d = heads * dh
+    qkv = rnd((B, n, 3 * d), 21, dt)
+    ramp = torch.linspace(0.5, 3.5, n).reshape(1, n, 1)          # later keys are larger: the running max keeps moving
+    qkv[..., :d] *= 6.0
+    qkv[..., d:2 * d] = (qkv[..., d:2 * d].float() * ramp).to(dt)
+    qd = qkv.to(DEV)
+    scale = dh ** -0.5
+    kw = dict(B=B, heads=heads, n=n, nk=n, dh=dh, ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d,
+              ldo=d, bso=n * d, scale=scale)
+    outs = []
+    for variant in (0, 2):
+        out = torch.zeros(B, n, d, dtype=dt, device=DEV)
+        h.attention(qd, qd[:, :, d:], qd[:, :, 2 * d:], out, variant=variant, **kw)
+        assert torch.isfinite(out).all()
+        outs.append(out.float().cpu())
+    sp = lambda t: t.reshape(B, n, heads, dh).permute(0, 2, 1, 3).double()
+    s = sp(qkv[..., :d]) @ sp(qkv[..., d:2 * d]).transpose(-1, -2) * scale
+    assert s.std() > 10
+    ref = (torch.softmax(s, -1) @ sp(qkv[..., 2 * d:])).permute(0, 2, 1, 3).reshape(B, n, d).float()
+    assert rel_l2(outs[0], ref) < 2e-3 and rel_l2(outs[1], ref) < 2e-3     # peaked rows amplify the fp16 rounding of q, k
+    assert rel_l2(outs[0], outs[1]) < 2e-3
