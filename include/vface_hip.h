@@ -89,6 +89,19 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
                   const void* residual, int64_t ldr, void* Y, int64_t ldy, const void* zeros, int flags, int dtype,
                   float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* One output-parity phase of conv3x3(nearest_upsample2x(X)) (Upsample: openaimodel.py:108-118, diffusionmodules/model.py:
+ * 55-58).  Every output pixel (2i+py, 2j+px) of the upsampled convolution sees only a 2x2 block of source pixels, so the
+ * nine taps collapse -- exactly -- into four with pre-summed weights (vface_amd/packing.py::pack_upsample_phases): 4/9 of
+ * the multiply-adds of running the 3x3 window over the upsampled image.  X: [nimg*H*W][ldx >= Cin]; Y: the FULL output
+ * [nimg*2H*2W][ldy]; this call writes its rows (2i+py, 2j+px) only; call it for the four (py, px).  Wt: that phase's
+ * [Cout][4*Cin] matrix.  No residual, 16-bit output, Cout % 8 == 0.  colstats (optional, H*W % 64 == 0): the
+ * [nimg*4*H*W/64][ld_colstats][2] buffer of the FULL output; each phase fills its own quarter of every sample's slices
+ * (sums over a sample are what vface_groupnorm_finalize_cols takes, so the slice order inside a sample is free). */
+int vface_upsample2x_conv3x3_phase(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw,
+                                   int Cout, int py, int px, const float* bias, const float* rowbias, int ld_rowbias, void* Y,
+                                   int64_t ldy, const void* zeros, int flags, int dtype, float* colstats,
+                                   int64_t ld_colstats, void* stream);
+
 /* O = softmax(Q K^T * scale) V per (sample, head), streaming softmax, no [n x n] matrix.
  * Replaces attention.py:206-220 / pnp_utils.py:270-285.  Output sample b uses q,k of sample qk_map[b] and
  * v of sample v_map[b] (NULL = identity): the zero-copy form of the hook's q/k/v row assignments. */

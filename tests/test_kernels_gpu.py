@@ -512,3 +512,40 @@ def test_attention_wide_logit_range(dh, n):
     ref = (torch.softmax(s, -1) @ sp(qkv[..., 2 * d:])).permute(0, 2, 1, 3).reshape(B, n, d).float()
     assert rel_l2(outs[0], ref) < 2e-3 and rel_l2(outs[1], ref) < 2e-3     # peaked rows amplify the fp16 rounding of q, k
     assert rel_l2(outs[0], outs[1]) < 2e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 8, 8), (128, 160, 12, 10), (640, 640, 16, 16), (24, 32, 6, 7)])
+def test_upsample_conv_as_parity_phases(dt, cin, cout, H, W):
+    """conv3x3(nearest x2 upsample) as four 2x2 parity-phase convolutions with pre-summed taps: equals the direct form
+    (the fused-upsample implicit GEMM and torch) -- 4/9 of the multiply-adds."""
+    h = hip()
+    from vface_amd.packing import pack_conv3x3, pack_upsample_phases
+    nimg = 3
+    x = rnd((nimg, cin, H, W), 1, dt)
+    w = rnd((cout, cin, 3, 3), 2, dt, 1 / math.sqrt(9 * cin))
+    b = rnd((cout,), 3, torch.float32, 0.1)
+    rb = rnd((nimg, cout), 4, torch.float32)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2, mode="nearest"), w.float(), b, padding=1) + rb[:, :, None, None]
+    cp = (cin + 7) // 8 * 8
+    xn = torch.zeros(nimg, H, W, cp, dtype=dt)
+    xn[..., :cin] = x.permute(0, 2, 3, 1)
+    xn = xn.to(DEV)
+    out = torch.zeros(nimg, 2 * H, 2 * W, cout, dtype=dt, device=DEV)
+    h.upsample2x_conv3x3(xn, pack_upsample_phases(w.float()).to(dt).to(DEV), out, nimg=nimg, H=H, W=W, cin=cp, cout=cout, ldx=cp,
+                         ldy=cout, bias=b.to(DEV), rowbias=rb.to(DEV))
+    assert rel_l2(out.cpu().float().permute(0, 3, 1, 2), ref) < TOL[dt]
+    direct = torch.zeros_like(out)
+    h.conv3x3(xn, pack_conv3x3(w).to(DEV), direct, nimg=nimg, H=H, W=W, cin=cp, cout=cout, ldx=cp, ldy=cout, upsample=True,
+              bias=b.to(DEV), rowbias=rb.to(DEV))
+    assert rel_l2(out.float().cpu(), direct.float().cpu()) < TOL[dt]
+    if (H * W) % 64 == 0:
+        # column statistics of the phase launches feed the same GroupNorm statistics as the stand-alone kernel
+        cs = torch.zeros(nimg * 4 * H * W // 64, cout, 2, dtype=torch.float32, device=DEV)
+        h.upsample2x_conv3x3(xn, pack_upsample_phases(w.float()).to(dt).to(DEV), out, nimg=nimg, H=H, W=W, cin=cp, cout=cout,
+                             ldx=cp, ldy=cout, bias=b.to(DEV), rowbias=rb.to(DEV), colstats=cs)
+        y = out.reshape(nimg * 4 * H * W, cout)
+        st_cols = h.groupnorm_stats_from_cols(cs, nimg=nimg, hw=4 * H * W, C_=cout)
+        st_ref = h.groupnorm_stats(y, nimg=nimg, hw=4 * H * W, C_=cout, ldx=cout)
+        assert torch.allclose(st_cols, st_ref, rtol=3e-4, atol=3e-5)

@@ -71,6 +71,25 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
     return vf_launch_gemm(p, dtype, S(stream));
 }
 
+int vface_upsample2x_conv3x3_phase(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw,
+                                   int Cout, int py, int px, const float* bias, const float* rowbias, int ld_rowbias, void* Y,
+                                   int64_t ldy, const void* zeros, int flags, int dtype, float* colstats,
+                                   int64_t ld_colstats, void* stream) {
+    if (nimg <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (py & ~1) || (px & ~1)) return VFACE_ERR_ARG;
+    if (flags & (VFACE_EPI_GEGLU | VFACE_EPI_OUT_F32 | VFACE_CONV_PAD_TRAILING)) return VFACE_ERR_SHAPE;
+    GemmParams p{};
+    p.mode = 1; p.A = X; p.lda = ldx; p.Wt = Wt; p.ldw = ldw; p.Kw = 4 * Cin;
+    p.H = H; p.W = W; p.Cin = Cin; p.stride = 1; p.upsample = 0;
+    // output parity py sees source rows {i-1, i} (py = 0) or {i, i+1} (py = 1): a 2-tap window with leading pad 1 - py
+    p.KH = p.KW = 2; p.ntaps = 4; p.pad = 1 - py; p.pad_x = 1 - px;
+    p.OH = H; p.OW = W; p.out_phase = 4 | (py << 1) | px;
+    p.M = nimg * H * W; p.N = Cout; p.K = 4 * Cin;
+    p.bias = bias; p.rowbias = rowbias; p.rows_per_sample = H * W; p.ld_rowbias = ld_rowbias;
+    p.C = Y; p.ldc = ldy; p.zeros = zeros; p.flags = flags;
+    p.colstats = colstats; p.ld_colstats = ld_colstats;
+    return vf_launch_gemm(p, dtype, S(stream));
+}
+
 int64_t vface_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_sample) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     return vf_splitk_workspace_bytes(M, N, K, flags, rows_per_sample);

@@ -111,14 +111,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             const int img = m / hw;
             const int rem = m - img * hw;
             const int oy = rem / p.OW, ox = rem - oy * p.OW;
-            const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
+            const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad_x;
             g_oy[rr] = y0; g_ox[rr] = x0; g_img[rr] = (unsigned)(img * p.H * p.W);
             if (MODE == MODE_CONV_FAST) {
                 const int VH = p.upsample ? 2 * p.H : p.H, VW = p.upsample ? 2 * p.W : p.W;
                 unsigned mk = 0;
 #pragma unroll
                 for (int tp = 0; tp < 9; ++tp) {
-                    const int vy = y0 + tp / 3, vx = x0 + tp % 3;
+                    if (tp >= p.ntaps) break;
+                    const int vy = y0 + tp / p.KW, vx = x0 + tp % p.KW;
                     if (ok && (unsigned)vy < (unsigned)VH && (unsigned)vx < (unsigned)VW) mk |= 1u << tp;
                 }
                 a_mask[rr] = mk;
@@ -160,8 +161,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             // K order for Cin % 64 == 0 is (64-channel chunk, tap, channel): the 9 taps of one chunk are
             // consecutive K tiles, so the 9 re-reads of a pixel's 128-B chunk happen within 9 tiles and hit L2
             // (tap-major order re-reads a line only after sweeping all Cin: L2 hit rate 76 %, 10x over-fetch).
-            const int cc = kt / 9, tap = kt - cc * 9;  // wave-uniform
-            const int ky = tap / 3, kx = tap - ky * 3;
+            const int cc = kt / p.ntaps, tap = kt - cc * p.ntaps;  // wave-uniform
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
             const int ci0 = cc * BK;
             if (!p.upsample) {
                 const unsigned toff = (unsigned)((((long)ky * p.W + kx) * p.lda + ci0) * ES);
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         } else {
             const int tap = k / p.Cin;
             const int ci = k - tap * p.Cin;
-            const int ky = tap / 3, kx = tap - ky * 3;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
             const int VH = p.upsample ? 2 * p.H : p.H, VW = p.upsample ? 2 * p.W : p.W;
             const bool kin = k < p.K;
 #pragma unroll
@@ -356,7 +357,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                         V8 o;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
-                        *reinterpret_cast<V8*>(Cout + (long)m * p.ldc + ncol) = o;
+                        long orow = m;
+                        if (MODE != MODE_PLAIN && p.out_phase) {
+                            // one output-parity phase of conv(nearest x2 upsample): pixel (oy, ox) of the phase grid is
+                            // pixel (2 oy + py, 2 ox + px) of the 2OH x 2OW output
+                            const int hw = p.OH * p.OW, img = m / hw, rem = m - img * hw, oy = rem / p.OW, ox = rem - oy * p.OW;
+                            orow = ((long)img * 2 * p.OH + 2 * oy + ((p.out_phase >> 1) & 1)) * (2 * p.OW) + 2 * ox + (p.out_phase & 1);
+                        }
+                        *reinterpret_cast<V8*>(Cout + orow * p.ldc + ncol) = o;
                         if (want_stats) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] += f * f; }
@@ -374,7 +382,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                     scr[(rrow * OW + rch * 8 + e) * 2 + 1] = q8[e];
                 }
             }
-            const long slice = (em0 + wm * 64) >> 6;
+            long slice = (em0 + wm * 64) >> 6;
+            if (MODE != MODE_PLAIN && p.out_phase) {
+                // the statistics only need every slice to lie inside one sample: phase ph of sample s files its
+                // hw/64 slices at [s*4 + ph] * (hw/64) of the 4hw/64 slices the full-resolution sample owns
+                const int spp = (p.OH * p.OW) >> 6;
+                const long smp = slice / spp;
+                slice = (smp * 4 + (p.out_phase & 3)) * spp + (slice - smp * spp);
+            }
             if (em0 + wm * 64 < p.M) {
                 for (int c = lane; c < OW; c += 64) {
                     float ss = 0.f, qq = 0.f;
@@ -808,7 +823,10 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     if (p.colstats && ((p.flags & (GEMM_GEGLU | GEMM_OUT_F32)) || (p.ld_colstats & 1) || ((uintptr_t)p.colstats & 15))) return VF_ERR_ARG;
     if (p.A2 && (p.mode != 0 || p.K1 <= 0 || (p.K1 % BK) || (p.lda2 & 7) || ((uintptr_t)p.A2 & 15))) return VF_ERR_ALIGN;
     if (p.mode == 1) {
-        if (p.Cin <= 0 || (p.Cin & 7) || p.K != 9 * p.Cin) return VF_ERR_SHAPE;
+        if (p.ntaps == 0) { p.KH = p.KW = 3; p.ntaps = 9; p.pad_x = p.pad; }   // the plain 3x3 window
+        if (p.Cin <= 0 || (p.Cin & 7) || p.K != p.ntaps * p.Cin || p.ntaps != p.KH * p.KW || p.ntaps > 9) return VF_ERR_SHAPE;
+        if (p.out_phase && (p.residual || (p.flags & GEMM_OUT_F32) || (p.N & 7))) return VF_ERR_SHAPE;
+        if (p.out_phase && p.colstats && ((p.OH * p.OW) & 63)) return VF_ERR_SHAPE;
         if (p.stride != 1 && p.stride != 2) return VF_ERR_SHAPE;
     }
     // extents of the operand views for the buffer descriptors (bytes; must stay below 4 GiB - 16)
@@ -823,7 +841,8 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb; p.a2_bytes = (unsigned)a2b;
     }
     const int variant = pick_variant(p);
-    if (p.workspace && (variant == 5 || variant == 6) && !((p.flags >> 8) & 0xF) && !(p.flags & 0x4000)) {
+    if (p.mode == 1 && (p.ntaps != 9 || p.out_phase) && variant != 5 && variant != 6) return VF_ERR_SHAPE;
+    if (p.workspace && !p.out_phase && (variant == 5 || variant == 6) && !((p.flags >> 8) & 0xF) && !(p.flags & 0x4000)) {
         const int s = split_for(p.M, p.N, p.K, p.flags, p.rows_per_sample);
         if (s > 1 && p.workspace_bytes >= (long)s * p.M * p.N * 4 && !((uintptr_t)p.workspace & 15) &&
             !(p.residual && (((uintptr_t)p.residual & 15) || (p.ldr & 7))) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) {

@@ -18,7 +18,10 @@ struct GemmParams {
     int M, N, K;
     // conv geometry (stored input H x W, output OH x OW)
     int H, W, Cin, OH, OW, stride, upsample;
-    int pad;  // leading (top / left) zero padding: 1, or 0 for the VAE encoder's (0,1,0,1) stride-2 convolution
+    int pad;  // leading (top) zero padding: 1, or 0 for the VAE encoder's (0,1,0,1) stride-2 convolution
+    int pad_x;           // leading (left) zero padding; KH x KW window (ntaps = KH*KW <= 9; 0 = the launcher fills 3x3)
+    int KH, KW, ntaps;
+    int out_phase;       // 0, or 4 | (py << 1) | px: output rows are the (py, px) parity phase of a 2OH x 2OW image
     const float* bias;     // [N] or null
     const float* rowbias;  // [M / rows_per_sample][ld_rowbias] or null
     int rows_per_sample;

@@ -18,6 +18,8 @@ There is no CPU path here.
 """
 from __future__ import annotations
 
+import os
+
 import math
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence
@@ -201,6 +203,16 @@ def attn_module_forward(mod, x: torch.Tensor, context: Optional[torch.Tensor], c
     return out.reshape(B, n, -1)
 
 
+def _phase_form_pays(hw_in: int, cout: int) -> bool:
+    """The four parity-phase launches of an upsampling conv each cover hw_in rows per sample: below ~400 tiles per
+    launch (at the nominal 24-sample batch, so the choice -- and the bits -- do not depend on the batch) the 9-tap form
+    on the upsampled grid fills the chip better (measured: 8x8 -> 16x16 at 1280 channels 230 vs 284 us; 16x16 -> 32x32
+    741 vs 375 us)."""
+    if os.environ.get("VFACE_NO_PHASE_UPSAMPLE") == "1":   # A/B switch for measurements
+        return False
+    return (24 * hw_in // 128) * (cout // 128) >= 400
+
+
 class UNetEngine:
     """Packed weights + kernel sequencing for one ``UNetModel``."""
 
@@ -256,6 +268,8 @@ class UNetEngine:
                 P[prefix] = conv3(prefix + ".op")
             elif kind == "up":
                 P[prefix] = conv3(prefix + ".conv")
+                # nearest x2 + conv3x3 = four parity-phase 2x2 convs with pre-summed taps (4/9 of the multiply-adds)
+                P[prefix]["phases"] = self._w16(packing.pack_upsample_phases(cpu(prefix + ".conv.weight")))
             elif kind == "res":
                 d = {"in_gn": (self._f32(sd[prefix + ".in_layers.0.weight"]), self._f32(sd[prefix + ".in_layers.0.bias"])),
                      "conv1": conv3(prefix + ".in_layers.2"),
@@ -362,6 +376,11 @@ class UNetEngine:
         else:
             out, cs = tgt
         assert x.C == w["cinp"], (x.C, w["cinp"])
+        if upsample and "phases" in w and _phase_form_pays(x.H * x.W, w["cout"]) and residual is None and not out_f32 \
+                and (cs is None or (x.H * x.W) % 64 == 0):
+            hip.upsample2x_conv3x3(x.t, w["phases"], out, nimg=x.N, H=x.H, W=x.W, cin=w["cinp"], cout=w["cout"], ldx=x.ld,
+                                   ldy=out.stride(0), bias=w["b"], rowbias=rowbias, colstats=cs)
+            return Act(out, x.N, OH, OW, cs)
         hip.conv3x3(x.t, w["w"], out, nimg=x.N, H=x.H, W=x.W, cin=w["cinp"], cout=w["cout"], ldx=x.ld,
                     ldy=out.stride(0), stride=stride, upsample=upsample, bias=w["b"], rowbias=rowbias,
                     residual=residual, ldr=residual.stride(0) if residual is not None else 0,

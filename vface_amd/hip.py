@@ -32,6 +32,8 @@ SIGNATURES = {
     "vface_conv3x3": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp,
                                 _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "vface_splitk_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "vface_upsample2x_conv3x3_phase": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32,
+                                                 _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp]),
     "vface_groupnorm_finalize_cols": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vface_attention": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32,
                                   _i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
@@ -315,3 +317,18 @@ def vae_sample(moments: torch.Tensor, noise: Optional[torch.Tensor], z: torch.Te
                scale: float):
     rc = load().vface_vae_sample(_p(moments), moments.stride(0), _p(noise), _p(z), F, hw, zc, scale, _stream())
     _check(rc, "vface_vae_sample")
+
+
+def upsample2x_conv3x3(x: torch.Tensor, wt_phases: torch.Tensor, out: torch.Tensor, *, nimg: int, H: int, W: int, cin: int,
+                       cout: int, ldx: int, ldy: int, bias=None, rowbias=None, flags: int = 0, colstats=None):
+    """conv3x3(nearest_upsample2x(x)) as four parity-phase 2x2 convolutions (4/9 of the multiply-adds).
+    ``wt_phases``: [4, cout, 4*cin] from ``packing.pack_upsample_phases``; ``out``: [nimg*2H*2W, >= cout]."""
+    lib = load()
+    for py in (0, 1):
+        for px in (0, 1):
+            rc = lib.vface_upsample2x_conv3x3_phase(_p(x), ldx, nimg, H, W, cin, _p(wt_phases[2 * py + px]), 4 * cin, cout, py, px,
+                                                    _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0,
+                                                    _p(out), ldy, _p(zeros_page(x.device)), flags, dtype_code(x.dtype),
+                                                    _p(colstats), colstats.stride(0) // 2 if colstats is not None else 0,
+                                                    _stream())
+            _check(rc, "vface_upsample2x_conv3x3_phase")

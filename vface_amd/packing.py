@@ -32,6 +32,34 @@ def pack_conv3x3(w: torch.Tensor, cin_pad: int | None = None) -> torch.Tensor:
     return taps.reshape(cout, 9 * cp).contiguous()
 
 
+def pack_conv_window(w: torch.Tensor, cin_pad: int | None = None) -> torch.Tensor:
+    """[Cout, Cin, KH, KW] -> [Cout, KH*KW*Cin_pad] in the K order of ``pack_conv3x3`` for any window up to 3x3."""
+    cout, cin, kh, kw = w.shape
+    cp = cin_pad if cin_pad is not None else (cin + 7) // 8 * 8
+    taps = torch.zeros(cout, kh * kw, cp, dtype=w.dtype)
+    taps[..., :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    if cp % 64 == 0:
+        taps = taps.reshape(cout, kh * kw, cp // 64, 64).permute(0, 2, 1, 3)
+    return taps.reshape(cout, kh * kw * cp).contiguous()
+
+
+def pack_upsample_phases(w: torch.Tensor) -> torch.Tensor:
+    """conv3x3(nearest_upsample2x(x)) by output parity (openaimodel.py:108-118): pixel (2i+py, 2j+px) sees source rows
+    {i-1, i} (py = 0) or {i, i+1} (py = 1) -- likewise columns -- so the 3x3 kernel collapses, exactly, into one 2x2 kernel
+    per phase whose taps are sums of the original ones (summed here in fp64).  -> [4 (2*py+px), Cout, 4*Cin_pad] packed."""
+    w64 = w.double()
+    rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}     # parity -> (taps folded onto the first source row, onto the second)
+    out = []
+    for py in (0, 1):
+        for px in (0, 1):
+            k = torch.zeros(w.shape[0], w.shape[1], 2, 2, dtype=torch.float64)
+            for ty, kys in enumerate(rows[py]):
+                for tx, kxs in enumerate(rows[px]):
+                    k[:, :, ty, tx] = w64[:, :, kys][:, :, :, kxs].sum(dim=(2, 3))
+            out.append(pack_conv_window(k.float()))
+    return torch.stack(out).contiguous()
+
+
 def pack_conv1x1(w: torch.Tensor) -> torch.Tensor:
     return w.reshape(w.shape[0], w.shape[1]).contiguous()
 

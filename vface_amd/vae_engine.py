@@ -21,7 +21,7 @@ from typing import Optional
 import torch
 
 from . import hip, packing
-from .engine import Act
+from .engine import Act, _phase_form_pays
 from .ldm.modules.distributions.distributions import DiagonalGaussianDistribution
 
 
@@ -107,6 +107,8 @@ class VAEEngine:
                 P[f"dec.up.{lvl}.{blk}"] = res(f"decoder.up.{lvl}.block.{blk}")
             if lvl != 0:
                 P[f"dec.up.{lvl}.us"] = conv3(f"decoder.up.{lvl}.upsample.conv")
+                P[f"dec.up.{lvl}.us"]["phases"] = self._w16(packing.pack_upsample_phases(
+                    sd[f"decoder.up.{lvl}.upsample.conv.weight"].float()))
         P["dec.norm_out"] = gn("decoder.norm_out")
         P["dec.conv_out"] = conv3("decoder.conv_out", cout_pad=4)
         self._packed = P
@@ -141,6 +143,12 @@ class VAEEngine:
         cs = None if out_f32 else self._cs(rows, w["cout"], OH * OW)
         assert x.C == w["cinp"], (x.C, w["cinp"])
         flags = (hip.EPI_OUT_F32 if out_f32 else 0) | (hip.CONV_PAD_TRAILING if trailing_pad else 0)
+        if upsample and "phases" in w and residual is None and not out_f32 and (x.H * x.W) % 64 == 0 \
+                and _phase_form_pays(x.H * x.W, w["cout"]):
+            # Upsample (model.py:55-58) as four parity-phase 2x2 convs with pre-summed taps: 4/9 of the multiply-adds
+            hip.upsample2x_conv3x3(x.t, w["phases"], out, nimg=x.N, H=x.H, W=x.W, cin=w["cinp"], cout=w["cout"], ldx=x.ld,
+                                   ldy=out.stride(0), bias=w["b"], colstats=cs)
+            return Act(out, x.N, OH, OW, cs)
         hip.conv3x3(x.t, w["w"], out, nimg=x.N, H=x.H, W=x.W, cin=w["cinp"], cout=w["cout"], ldx=x.ld, ldy=out.stride(0),
                     stride=stride, upsample=upsample, bias=w["b"], residual=residual,
                     ldr=residual.stride(0) if residual is not None else 0, flags=flags, colstats=cs)
