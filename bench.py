@@ -92,6 +92,18 @@ class ConvTimer:
             timer.extra_launches += 3
             timer.flops += 4 * 2.0 * nimg * H * W * cout * 4 * cin
         hip.upsample2x_conv3x3 = upsample2x_conv3x3
+        orig_p1 = hip.conv3x3_plus_1x1
+
+        def conv3x3_plus_1x1(x, x2, wt, out, *, nimg, H, W, cin, c2, cout, **kw):
+            if not timer.on:
+                return orig_p1(x, x2, wt, out, nimg=nimg, H=H, W=W, cin=cin, c2=c2, cout=cout, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            orig_p1(x, x2, wt, out, nimg=nimg, H=H, W=W, cin=cin, c2=c2, cout=cout, **kw)
+            e1.record()
+            timer.events.append((e0, e1))
+            timer.flops += 2.0 * nimg * H * W * cout * (9 * cin + c2)
+        hip.conv3x3_plus_1x1 = conv3x3_plus_1x1
 
     def summary(self):
         ms = sum(a.elapsed_time(b) for a, b in self.events)

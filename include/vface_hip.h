@@ -89,6 +89,15 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
                   const void* residual, int64_t ldr, void* Y, int64_t ldy, const void* zeros, int flags, int dtype,
                   float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Y = conv3x3(X) + X2 W2^T + bias: the second convolution of a ResBlock together with the block's 1x1 shortcut
+ * (openaimodel.py:228-232, 274 `skip_connection(x) + h`; diffusionmodules/model.py:137-141 `nin_shortcut`), accumulated in
+ * one K loop -- the shortcut's own launch, its 16-bit intermediate and the residual read disappear.  Wt: [Cout][9*Cin + C2],
+ * the packed 3x3 weights followed by the 1x1 weights; X2: [nimg*H*W][ldx2 >= C2].  Cin % 64 == 0, C2 % 64 == 0, stride 1. */
+int vface_conv3x3_plus_1x1(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* X2, int64_t ldx2, int C2,
+                           const void* Wt, int64_t ldw, int Cout, const float* bias, const float* rowbias, int ld_rowbias,
+                           void* Y, int64_t ldy, const void* zeros, int flags, int dtype, float* colstats,
+                           int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* One output-parity phase of conv3x3(nearest_upsample2x(X)) (Upsample: openaimodel.py:108-118, diffusionmodules/model.py:
  * 55-58).  Every output pixel (2i+py, 2j+px) of the upsampled convolution sees only a 2x2 block of source pixels, so the
  * nine taps collapse -- exactly -- into four with pre-summed weights (vface_amd/packing.py::pack_upsample_phases): 4/9 of

@@ -549,3 +549,26 @@ def test_upsample_conv_as_parity_phases(dt, cin, cout, H, W):
         st_cols = h.groupnorm_stats_from_cols(cs, nimg=nimg, hw=4 * H * W, C_=cout)
         st_ref = h.groupnorm_stats(y, nimg=nimg, hw=4 * H * W, C_=cout, ldx=cout)
         assert torch.allclose(st_cols, st_ref, rtol=3e-4, atol=3e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,c2,cout,H,nimg", [(64, 128, 64, 8, 3), (320, 960, 320, 16, 2), (1280, 2560, 1280, 8, 6)])
+def test_conv3x3_plus_1x1_shortcut(dt, cin, c2, cout, H, nimg):
+    """A ResBlock's second conv with the 1x1 shortcut accumulated in the same K loop (also through split-K at 8x8)."""
+    h = hip()
+    from vface_amd.packing import pack_conv3x3
+    x = rnd((nimg, cin, H, H), 1, dt)
+    x2 = rnd((nimg, c2, H, H), 2, dt)
+    w = rnd((cout, cin, 3, 3), 3, dt, 1 / math.sqrt(9 * cin))
+    w2 = rnd((cout, c2), 4, dt, 1 / math.sqrt(c2))
+    b = rnd((cout,), 5, torch.float32, 0.1)
+    ref = F.conv2d(x.float(), w.float(), b, padding=1) + torch.einsum("nchw,oc->nohw", x2.float(), w2.float())
+    wt = torch.cat([pack_conv3x3(w), w2], 1).contiguous().to(DEV)
+    out = torch.zeros(nimg, H, H, cout, dtype=dt, device=DEV)
+    cs = torch.zeros(nimg * H * H // 64, cout, 2, dtype=torch.float32, device=DEV)
+    h.conv3x3_plus_1x1(x.permute(0, 2, 3, 1).contiguous().to(DEV), x2.permute(0, 2, 3, 1).contiguous().to(DEV), wt, out,
+                       nimg=nimg, H=H, W=H, cin=cin, c2=c2, cout=cout, ldx=cin, ldx2=c2, ldy=cout, bias=b.to(DEV), colstats=cs)
+    assert rel_l2(out.cpu().float().permute(0, 3, 1, 2), ref) < TOL[dt]
+    yf = out.float().reshape(nimg * H * H // 64, 64, cout)
+    assert torch.allclose(cs[..., 0], yf.sum(1), rtol=1e-4, atol=2e-2)

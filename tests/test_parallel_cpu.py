@@ -32,8 +32,8 @@ def _free_port():
 
 def _worker(rank, world, port, mode, q):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # `port` is a rendezvous FILE path: nothing to race for between choosing a port and binding it
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
         total, C, h, w = 5, 8, 16, 16
         x = synth.synth_normal("par.x", (total, C, h, w))
@@ -65,7 +65,8 @@ def _worker(rank, world, port, mode, q):
 def test_halo_exchange_gloo_world2(mode):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
+    import tempfile
+    port = os.path.join(tempfile.mkdtemp(prefix="vface_rdzv_"), "store")
     procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -33,9 +33,9 @@ def _run(rank, world, port, outdir):
     from vface_amd.ldm.models.pnp_utils import register_spa_attn_injection as reg
     from vface_amd.parallel import FrameShard
     from vface_amd.utils import synth
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if world > 1:
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # file rendezvous: no port to race for between picking it and binding it
+        dist.init_process_group("gloo", init_method=f"file://{outdir}/rendezvous_w{world}", rank=rank, world_size=world)
     dev = "cuda:0"
     total, h, w = 4, 32, 32
     ldm = LatentDiffusion(_cfg())

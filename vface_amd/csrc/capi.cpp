@@ -71,6 +71,25 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
     return vf_launch_gemm(p, dtype, S(stream));
 }
 
+int vface_conv3x3_plus_1x1(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* X2, int64_t ldx2, int C2,
+                           const void* Wt, int64_t ldw, int Cout, const float* bias, const float* rowbias, int ld_rowbias,
+                           void* Y, int64_t ldy, const void* zeros, int flags, int dtype, float* colstats,
+                           int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (nimg <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || C2 <= 0 || !X2) return VFACE_ERR_ARG;
+    if (flags & (VFACE_EPI_GEGLU | VFACE_CONV_PAD_TRAILING)) return VFACE_ERR_SHAPE;
+    GemmParams p{};
+    p.mode = 1; p.A = X; p.lda = ldx; p.Wt = Wt; p.ldw = ldw; p.Kw = 9 * Cin + C2;
+    p.A2 = X2; p.lda2 = ldx2; p.K1 = 9 * Cin;
+    p.H = H; p.W = W; p.Cin = Cin; p.stride = 1; p.upsample = 0; p.pad = 1;
+    p.OH = H; p.OW = W;
+    p.M = nimg * H * W; p.N = Cout; p.K = 9 * Cin + C2;
+    p.bias = bias; p.rowbias = rowbias; p.rows_per_sample = H * W; p.ld_rowbias = ld_rowbias;
+    p.C = Y; p.ldc = ldy; p.zeros = zeros; p.flags = flags;
+    p.colstats = colstats; p.ld_colstats = ld_colstats;
+    p.workspace = static_cast<float*>(workspace); p.workspace_bytes = workspace ? workspace_bytes : 0;
+    return vf_launch_gemm(p, dtype, S(stream));
+}
+
 int vface_upsample2x_conv3x3_phase(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw,
                                    int Cout, int py, int px, const float* bias, const float* rowbias, int ld_rowbias, void* Y,
                                    int64_t ldy, const void* zeros, int flags, int dtype, float* colstats,

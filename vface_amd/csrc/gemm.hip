@@ -125,6 +125,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                 a_mask[rr] = mk;
                 // may wrap below zero for the halo row above the first image: only used when the tap's bit is set
                 a_off[rr] = (unsigned)(((((long)img * p.H + y0) * p.W + x0) * p.lda + schunk * 8) * ES);
+                // appended 1x1 source (ResBlock shortcut): output row m of a second matrix
+                if (p.A2 && ok) a2_off[rr] = (unsigned)(((long)m * p.lda2 + schunk * 8) * ES);
             } else {
                 a_mask[rr] = ok ? 1u : 0u;
                 a_off[rr] = 0;
@@ -164,7 +166,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             const int cc = kt / p.ntaps, tap = kt - cc * p.ntaps;  // wave-uniform
             const int ky = tap / p.KW, kx = tap - ky * p.KW;
             const int ci0 = cc * BK;
-            if (!p.upsample) {
+            if (kbase >= p.K1 && p.A2) {
+                // K tiles past the window: the 1x1 shortcut of a ResBlock (openaimodel.py:228-232, 274: skip_connection(x)
+                // + h) accumulated into the same tile -- its own launch, its 16-bit intermediate and the residual read
+                // of the second convolution disappear
+                const unsigned koff = (unsigned)(kbase - p.K1) * ES;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const unsigned off = a2_off[rr] != OOB ? a2_off[rr] + koff : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(sA + (rr * 256 + wave * 64) * 8), 16, off, 0, 0, 0);
+                }
+            } else if (!p.upsample) {
                 const unsigned toff = (unsigned)((((long)ky * p.W + kx) * p.lda + ci0) * ES);
 #pragma unroll
                 for (int rr = 0; rr < 4; ++rr) {
@@ -821,10 +833,12 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     if (p.rowbias && (p.rows_per_sample <= 0 || (p.ld_rowbias & 3))) return VF_ERR_ARG;
     if ((p.flags & GEMM_GEGLU) && ((p.N & 31) || (p.flags & GEMM_OUT_F32) || p.residual || p.rowbias)) return VF_ERR_SHAPE;
     if (p.colstats && ((p.flags & (GEMM_GEGLU | GEMM_OUT_F32)) || (p.ld_colstats & 1) || ((uintptr_t)p.colstats & 15))) return VF_ERR_ARG;
-    if (p.A2 && (p.mode != 0 || p.K1 <= 0 || (p.K1 % BK) || (p.lda2 & 7) || ((uintptr_t)p.A2 & 15))) return VF_ERR_ALIGN;
+    if (p.A2 && (p.K1 <= 0 || (p.K1 % BK) || (p.lda2 & 7) || ((uintptr_t)p.A2 & 15))) return VF_ERR_ALIGN;
+    if (p.A2 && p.mode == 1 && ((p.Cin % 64) || ((p.K - p.K1) % BK) || p.upsample || p.a2_row_mod)) return VF_ERR_SHAPE;
     if (p.mode == 1) {
         if (p.ntaps == 0) { p.KH = p.KW = 3; p.ntaps = 9; p.pad_x = p.pad; }   // the plain 3x3 window
-        if (p.Cin <= 0 || (p.Cin & 7) || p.K != p.ntaps * p.Cin || p.ntaps != p.KH * p.KW || p.ntaps > 9) return VF_ERR_SHAPE;
+        if (p.Cin <= 0 || (p.Cin & 7) || p.ntaps != p.KH * p.KW || p.ntaps > 9) return VF_ERR_SHAPE;
+        if (p.A2 ? (p.K1 != p.ntaps * p.Cin || p.K <= p.K1) : (p.K != p.ntaps * p.Cin)) return VF_ERR_SHAPE;
         if (p.out_phase && (p.residual || (p.flags & GEMM_OUT_F32) || (p.N & 7))) return VF_ERR_SHAPE;
         if (p.out_phase && p.colstats && ((p.OH * p.OW) & 63)) return VF_ERR_SHAPE;
         if (p.stride != 1 && p.stride != 2) return VF_ERR_SHAPE;
@@ -841,7 +855,7 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb; p.a2_bytes = (unsigned)a2b;
     }
     const int variant = pick_variant(p);
-    if (p.mode == 1 && (p.ntaps != 9 || p.out_phase) && variant != 5 && variant != 6) return VF_ERR_SHAPE;
+    if (p.mode == 1 && (p.ntaps != 9 || p.out_phase || p.A2) && variant != 5 && variant != 6) return VF_ERR_SHAPE;
     if (p.workspace && !p.out_phase && (variant == 5 || variant == 6) && !((p.flags >> 8) & 0xF) && !(p.flags & 0x4000)) {
         const int s = split_for(p.M, p.N, p.K, p.flags, p.rows_per_sample);
         if (s > 1 && p.workspace_bytes >= (long)s * p.M * p.N * 4 && !((uintptr_t)p.workspace & 15) &&

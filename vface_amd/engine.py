@@ -277,6 +277,12 @@ class UNetEngine:
                      "conv2": conv3(prefix + ".out_layers.3")}
                 if (prefix + ".skip_connection.weight") in sd:
                     d["skip"] = lin(prefix + ".skip_connection", conv=True)
+                    wsk = sd[prefix + ".skip_connection.weight"]
+                    if d["conv2"]["cinp"] % 64 == 0 and wsk.shape[1] % 64 == 0:
+                        # second conv + 1x1 shortcut in one K loop (vface_conv3x3_plus_1x1): weights side by side, biases summed
+                        d["conv2_skip"] = dict(d["conv2"], c2=wsk.shape[1],
+                                               w=torch.cat([d["conv2"]["w"], d["skip"]["w"]], 1).contiguous(),
+                                               b=(d["conv2"]["b"] + d["skip"]["b"]).contiguous())
                 cout = d["conv1"]["cout"]
                 emb_w.append(sd[prefix + ".emb_layers.1.weight"].float())
                 emb_b.append(sd[prefix + ".emb_layers.1.bias"].float())
@@ -393,6 +399,12 @@ class UNetEngine:
         a, b = p["emb_slice"]
         h = self._conv(h, p["conv1"], None, rowbias=emb_all[:, a:b])
         h = self._gn(h, p["out_gn"], 1e-5, True)
+        if "conv2_skip" in p and os.environ.get("VFACE_NO_SKIP_FUSION") != "1":   # (env: A/B switch for measurements)
+            w = p["conv2_skip"]
+            o, cs = self._new_target(x.M, w["cout"], x.hw) if out is None else out
+            hip.conv3x3_plus_1x1(h.t, x.t, w["w"], o, nimg=x.N, H=x.H, W=x.W, cin=w["cinp"], c2=w["c2"], cout=w["cout"],
+                                 ldx=h.ld, ldx2=x.ld, ldy=o.stride(0), bias=w["b"], colstats=cs)
+            return Act(o, x.N, x.H, x.W, cs)
         if "skip" in p:
             skip = self._new(x.M, p["conv2"]["cout"])
             self._gemm(x.t, p["skip"], skip, hw=x.H * x.W)

@@ -32,6 +32,8 @@ SIGNATURES = {
     "vface_conv3x3": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp,
                                 _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "vface_splitk_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "vface_conv3x3_plus_1x1": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i32,
+                                         _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "vface_upsample2x_conv3x3_phase": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32,
                                                  _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp]),
     "vface_groupnorm_finalize_cols": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
@@ -332,3 +334,17 @@ def upsample2x_conv3x3(x: torch.Tensor, wt_phases: torch.Tensor, out: torch.Tens
                                                     _p(colstats), colstats.stride(0) // 2 if colstats is not None else 0,
                                                     _stream())
             _check(rc, "vface_upsample2x_conv3x3_phase")
+
+
+def conv3x3_plus_1x1(x: torch.Tensor, x2: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, H: int, W: int,
+                     cin: int, c2: int, cout: int, ldx: int, ldx2: int, ldy: int, bias=None, rowbias=None, flags: int = 0,
+                     colstats=None, split_k: bool = True):
+    """out = conv3x3(x) + x2 @ W2^T + bias (a ResBlock's second conv plus its 1x1 shortcut); ``wt``: [cout, 9*cin + c2]."""
+    lib = load()
+    M, K = nimg * H * W, 9 * cin + c2
+    ws, ws_bytes = splitk_workspace(x.device, M, cout, K, flags, H * W) if split_k else (None, 0)
+    rc = lib.vface_conv3x3_plus_1x1(_p(x), ldx, nimg, H, W, cin, _p(x2), ldx2, c2, _p(wt), K, cout, _p(bias), _p(rowbias),
+                                    rowbias.stride(0) if rowbias is not None else 0, _p(out), ldy, _p(zeros_page(x.device)),
+                                    flags, dtype_code(x.dtype), _p(colstats),
+                                    colstats.stride(0) // 2 if colstats is not None else 0, _p(ws), ws_bytes, _stream())
+    _check(rc, "vface_conv3x3_plus_1x1")
