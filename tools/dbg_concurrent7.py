@@ -17,7 +17,7 @@ def victim(iters, q, own_att):
     T = torch.empty(Fn, 2 * d, dtype=torch.float16, device=DEV)
     d1 = torch.empty(Fn, 2 * d, dtype=torch.float16, device=DEV); d2 = torch.empty_like(d1)
     qkv = torch.randn(B * n, 3 * d, generator=g).half().to(DEV); att = torch.empty(B * n, d, dtype=torch.float16, device=DEV)
-    first, bad = None, 0
+    first, bad, dumps = None, 0, []
     kw = dict(F=F_, h=h, w=h, C_=2 * d, ld_src=2 * d, fs_src=n * 2 * d, ld_dst=2 * d, fs_dst=n * 2 * d, alpha=0.8)
     for it in range(iters):
         T.fill_(float(it % 3))
@@ -28,7 +28,15 @@ def victim(iters, q, own_att):
             hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=B, heads=heads, n=n, nk=n, dh=d // heads, ldq=3 * d, ldk=3 * d,
                           ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d, ldo=d, bso=n * d, scale=(d // heads) ** -0.5)
         if first is None: first = c1
-        else: bad += (not torch.equal(c1, first)) + (not torch.equal(c2, first))
+        else:
+            for cc in (c1, c2):
+                if not torch.equal(cc, first):
+                    bad += 1
+                    if len(dumps) < 6:
+                        dumps.append(cc.cpu())
+    if dumps:
+        os.makedirs("gpurun_out", exist_ok=True)
+        torch.save({"T": T.cpu(), "flow": flow.cpu(), "ref": first.cpu(), "bad": dumps, "h": h, "d": d}, "gpurun_out/warp_misreads.pt")
     q.put(("victim", own_att, bad))
 
 def noise(kind, seconds, q):
