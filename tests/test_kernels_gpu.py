@@ -516,7 +516,8 @@ def test_attention_wide_logit_range(dh, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 8, 8), (128, 160, 12, 10), (640, 640, 16, 16), (24, 32, 6, 7)])
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 64, 8, 8), (128, 160, 12, 10), (640, 640, 16, 16), (24, 32, 6, 7),
+                                          (64, 64, 160, 152)])   # the last one: 570 tiles per phase -> persistent form
 def test_upsample_conv_as_parity_phases(dt, cin, cout, H, W):
     """conv3x3(nearest x2 upsample) as four 2x2 parity-phase convolutions with pre-summed taps: equals the direct form
     (the fused-upsample implicit GEMM and torch) -- 4/9 of the multiply-adds."""
@@ -553,7 +554,8 @@ def test_upsample_conv_as_parity_phases(dt, cin, cout, H, W):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("cin,c2,cout,H,nimg", [(64, 128, 64, 8, 3), (320, 960, 320, 16, 2), (1280, 2560, 1280, 8, 6)])
+@pytest.mark.parametrize("cin,c2,cout,H,nimg", [(64, 128, 64, 8, 3), (320, 960, 320, 16, 2), (1280, 2560, 1280, 8, 6),
+                                                (64, 64, 64, 64, 20)])   # the last one: 640 tiles -> persistent form
 def test_conv3x3_plus_1x1_shortcut(dt, cin, c2, cout, H, nimg):
     """A ResBlock's second conv with the 1x1 shortcut accumulated in the same K loop (also through split-K at 8x8)."""
     h = hip()
