@@ -110,3 +110,28 @@ def test_every_entry_point_rejects_null_arguments_without_a_gpu():
     assert lib.vface_splitk_workspace_bytes(0, 0, 0, 0, 0) == 0
     assert lib.vface_attn1_workspace_bytes(0, 0, 0, 0) == 0
     assert lib.vface_attention_shared_scores_supported(40, 3) == 1 and lib.vface_attention_shared_scores_supported(80, 3) == 0
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(5, 7, 4, 6), (64, 8, 3, 3)])
+def test_upsample_phase_weights_are_exact(cin, cout, H, W):
+    """conv3x3(nearest x2 upsample) == the four parity-phase 2x2 convolutions with the pre-summed taps of
+    packing.pack_upsample_phases (checked here on CPU with the packed K order undone)."""
+    import torch.nn.functional as F
+    from vface_amd.packing import pack_upsample_phases
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(cout, cin, 3, 3, generator=g, dtype=torch.float64)
+    x = torch.randn(2, cin, H, W, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+    packed = pack_upsample_phases(w.float()).double()           # [4, cout, 4 * cin_pad]
+    cp = (cin + 7) // 8 * 8
+    out = torch.zeros_like(ref)
+    for py in (0, 1):
+        for px in (0, 1):
+            k = packed[2 * py + px]
+            if cp % 64 == 0:                                     # (chunk, tap, channel) -> (tap, channel)
+                k = k.reshape(cout, cp // 64, 4, 64).permute(0, 2, 1, 3).reshape(cout, 4, cp)
+            else:
+                k = k.reshape(cout, 4, cp)
+            k = k[:, :, :cin].reshape(cout, 2, 2, cin).permute(0, 3, 1, 2)
+            out[:, :, py::2, px::2] = F.conv2d(F.pad(x, (1 - px, px, 1 - py, py)), k)
+    assert torch.allclose(out, ref, atol=1e-5)                   # weights went through fp32 once
