@@ -280,7 +280,11 @@ def main():
                                    f"UNet (859.5M params), attn1 fusion={a.fusion} on input blocks, CFG scale 3.0, "
                                    f"batch [uncond;cond;recon] = {3 * F_} samples per step",
                        "frames_per_gpu": F_, "latent": [h, h], "fusion": a.fusion,
-                       "unet_algorithmic_tflops_per_gpu": unet_tflops},
+                       "unet_algorithmic_tflops_per_gpu": unet_tflops,
+                       # north_star also asks for the rate as a fraction of the attention-GEMM roofline: the attn1 QKV
+                       # projections + QK^T + PV are 160.9 GFLOP per sample-forward at 64x64 = 24.1 TFLOP per
+                       # swapped frame; at the 2.5 PFLOP/s dense peak that alone would allow 103.6 frames/s per GPU
+                       "attention_gemm_roofline_frac": (fps / world) * 24.135e12 / (MFMA_PEAK_TFLOPS * 1e12) if h == 64 else None},
             "inversion": None if inv_ms is None else {
                 "ms_per_step": inv_ms, "steps_timed": a.inv_steps,
                 "note": "DDIM inversion step (hooks off, batch 2F, no guidance), outside the timed region; `value` is "
