@@ -51,8 +51,29 @@ def parse():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-forwards", type=int, default=2)
+    ap.add_argument("--cpu-forwards", type=int, default=3)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1 only: skip the extra workloads (config 3: 32 frames + fft; shipped schedule: 16 frames + flow_fix)")
+    ap.add_argument("--extra-steps", type=int, default=10)
     return ap.parse_args()
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with N > 1 and no rendezvous in the environment: start N ranks (one per GPU) with
+    torch.distributed.run as a CHILD process and pass its exit code on.  This parent never touches the GPU (no HIP call,
+    no torch.cuda.is_available()); rank 0 of the children prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"self-launch: {' '.join(cmd)}")
+    return subprocess.call(cmd, env=env)
 
 
 class ConvTimer:
@@ -111,25 +132,28 @@ class ConvTimer:
         return n, ms, self.flops
 
 
-def cpu_baseline(fusion, n_forwards, ddim_steps):
-    """Oracle (kind 'port') timed on the host cores: F=1, 64x64, full-size UNet, same hook mode."""
+def cpu_baseline(n_forwards, ddim_steps):
+    """Oracle (kind 'port') timed on the host cores, as BASELINE.md 4 plans it: full-size UNet, 64x64 latent, the shipped
+    hook schedule (flow_fix on the input-block attn1), F = 2 frames (batch 6) so the flow warp really runs, 1 warm-up +
+    `n_forwards` (>= 3) timed forwards on every core of the affinity mask."""
     from oracle import hooks as ohooks
     from oracle import unet as ounet
     from vface_amd.utils import synth
-    # the GPU box gives one GPU's share of the host (16 cores); never oversubscribe beyond the affinity mask
-    cores = min(len(os.sched_getaffinity(0)), 16)
+    cores = len(os.sched_getaffinity(0))
     torch.set_num_threads(cores)
+    n_forwards = max(3, n_forwards)
     log(f"cpu_baseline: oracle on {cores} threads ...")
+    F_ = 2
     spec = ounet.UNetSpec()
     sd = synth.synth_state_dict(ounet.param_shapes(spec), seed=0)
-    x = synth.synth_normal("bench.cpu.x", (3, 9, 64, 64))
-    ctx = synth.synth_normal("bench.cpu.ctx", (3, 1, 768))
-    t = torch.full((3,), 481, dtype=torch.long)
+    x = synth.synth_normal("bench.cpu.x", (3 * F_, 9, 64, 64))
+    ctx = synth.synth_normal("bench.cpu.ctx", (3 * F_, 1, 768))
+    t = torch.full((3 * F_,), 481, dtype=torch.long)
+    flow = [f[None] for f in synth.synth_flow(F_ - 1, 64, 64)]
     reg = {}
-    if fusion != "none":
-        ohooks.register_spa_attn_injection(reg, ounet.attn1_names(spec), 1, switch_on=True, input_blocks=True,
-                                           middle_block=False, output_blocks=False, chunks=3,
-                                           block_indices=list(range(9)), fusion=fusion)
+    ohooks.register_spa_attn_injection(reg, ounet.attn1_names(spec), 1, switch_on=True, input_blocks=True,
+                                       middle_block=False, output_blocks=False, chunks=3, flow=flow,
+                                       block_indices=list(range(9)), fusion="flow_fix", split_ratio_fft=0.8, alpha=0.8)
     with torch.no_grad():
         t0 = time.time()
         ounet.unet_forward(sd, spec, x, t, ctx, reg)  # warm-up
@@ -138,16 +162,20 @@ def cpu_baseline(fusion, n_forwards, ddim_steps):
         for _ in range(n_forwards):
             ounet.unet_forward(sd, spec, x, t, ctx, reg)
         dt = (time.time() - t0) / n_forwards
-    return {"value": 1.0 / (ddim_steps * dt), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_forwards} timed hooked-UNet forwards (+1 warm-up) of the CPU oracle, F=1 (batch 3), 64x64 "
-                      f"latent, fp32, fusion={fusion}; {dt:.2f} s per forward, x{ddim_steps} steps per frame"}
+    return {"value": F_ / (ddim_steps * dt), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_forwards} timed hooked-UNet forwards (+1 warm-up) of the CPU oracle, F={F_} (batch {3 * F_}), "
+                      f"64x64 latent, fp32, fusion=flow_fix on the input-block attn1 (the shipped schedule); {dt:.2f} s per "
+                      f"forward, x{ddim_steps} steps per clip of {F_} frames"}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback on the product path)"
     # VFACE_BENCH_REHEARSE=1: every rank on cuda:0 with the gloo backend -- to rehearse the N > 1 control flow on a
     # one-GPU box (the numbers of such a run mean nothing).  The driver's multi-GPU runs never set it.
@@ -156,14 +184,15 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist = None
+    dist, backend = None, None
     if world > 1:
         import torch.distributed as dist
         if rehearse:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+            dist.init_process_group("nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+        backend = dist.get_backend()
 
     from vface_amd import hip
     from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler, HookPlan
@@ -176,39 +205,13 @@ def main():
     timer = ConvTimer()
     timer.wrap(hip)
     dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
-    F_, h = a.frames, a.res // 8
+    h = a.res // 8
     ldm = LatentDiffusion(dict(FFHQ_UNET_CONFIG, compute_dtype=dt))
     synth.fill_module_(ldm.unet, seed=0)
     ldm = ldm.to(dev)
     sampler = DDIMSampler(ldm)
-    sampler.hook_plan = HookPlan(fusion=a.fusion, enabled=a.fusion != "none")
-    shard = FrameShard(rank, world, F_ * world, dist)
-    g0 = shard.first  # global index of this rank's first frame
-    tag = lambda s, f: f"bench.{s}.{g0 + f}"
-    stack = lambda s, shape: torch.stack([synth.synth_normal(tag(s, f), shape) for f in range(F_)]).to(dev)
-    x_T = stack("xT", (4, h, h))
-    c, uc, tc = stack("c", (1, 768)), stack("uc", (1, 768)), stack("tc", (1, 768))
-    inp = stack("inp", (4, h, h)) * 0.18215
-    mask = synth.synth_mask(F_, h, h).to(dev)
     sampler.make_schedule(a.ddim_steps, ddim_eta=0.0, verbose=False)
     steps = [int(s) for s in sampler.ddim_timesteps[::-1]]
-    inv = {s: stack(f"inv{s}", (4, h, h)) for s in steps}  # device-resident recon latents
-    flow = None
-    if a.fusion == "flow_fix":
-        gflow = synth.synth_flow(F_ * world - 1, h, h)  # one field per consecutive global frame pair
-        flow = shard.local_flow(gflow).to(dev)
-        shard.install(ldm.unet.engine, gflow, dev)
-    kw = {"inpaint_image": inp, "inpaint_mask": mask}
-
-    def one_step(img, i):
-        s = steps[i % len(steps)]
-        sampler._register_step_hooks(flow)
-        ts = torch.full((F_,), s, device=dev, dtype=torch.long)
-        img, _ = sampler.p_sample_ddim_with_inverse(img, c, ts, index=len(steps) - 1 - (i % len(steps)),
-                                                    target_conditioning=tc, inverse_results_dir=inv,
-                                                    unconditional_guidance_scale=3.0, flow=flow,
-                                                    unconditional_conditioning=uc, test_model_kwargs=kw)
-        return img
 
     def fence():
         torch.cuda.synchronize()
@@ -216,61 +219,116 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    log("weights resident; warm-up ...")
-    with torch.no_grad():
-        img = x_T
-        for i in range(a.warmup):
-            img = one_step(img, i)
-        img = x_T
-        fence()
-        timer.on = True
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            img = one_step(img, i)
-        t_enq = time.perf_counter() - t0      # host time to enqueue the steps (the GPU runs behind)
-        fence()
-        el = time.perf_counter() - t0
-        timer.on = False
-    assert torch.isfinite(img).all(), "non-finite latents"
-    # DDIM inversion (ddim_w_inv.py:360-490; SURVEY 8d asks for it separately): hooks off, batch 2F = [target ; source],
-    # no guidance -- 50 such steps per clip precede sampling unless the latents are cached.  Timed outside the step loop.
-    inv_ms = None
-    if a.inv_steps > 0:
+    def run_workload(F_, fusion, n_steps, n_warm, time_convs, inv_steps):
+        """W untimed + exactly K timed DDIM steps of an F-frame clip per GPU; returns per-rank wall seconds etc."""
+        sampler.hook_plan = HookPlan(fusion=fusion, enabled=fusion != "none")
+        shard = FrameShard(rank, world, F_ * world, dist)
+        g0 = shard.first  # global index of this rank's first frame
+        tag = lambda s_, f: f"bench.{s_}.{g0 + f}"
+        stack = lambda s_, shape: torch.stack([synth.synth_normal(tag(s_, f), shape) for f in range(F_)]).to(dev)
+        x_T = stack("xT", (4, h, h))
+        c, uc, tc = stack("c", (1, 768)), stack("uc", (1, 768)), stack("tc", (1, 768))
+        inp = stack("inp", (4, h, h)) * 0.18215
+        mask = synth.synth_mask(F_, h, h).to(dev)
+        inv = {s_: stack(f"inv{s_}", (4, h, h)) for s_ in steps}  # device-resident recon latents
+        flow = None
+        eng = ldm.unet.engine
+        eng.halo_exchange, eng.halo_flow = None, None
+        if fusion == "flow_fix":
+            gflow = synth.synth_flow(F_ * world - 1, h, h)  # one field per consecutive global frame pair
+            flow = shard.local_flow(gflow).to(dev)
+            shard.install(eng, gflow, dev)
+        kw = {"inpaint_image": inp, "inpaint_mask": mask}
+
+        def one_step(img, i):
+            s_ = steps[i % len(steps)]
+            sampler._register_step_hooks(flow)
+            ts = torch.full((F_,), s_, device=dev, dtype=torch.long)
+            img, _ = sampler.p_sample_ddim_with_inverse(img, c, ts, index=len(steps) - 1 - (i % len(steps)),
+                                                        target_conditioning=tc, inverse_results_dir=inv,
+                                                        unconditional_guidance_scale=3.0, flow=flow,
+                                                        unconditional_conditioning=uc, test_model_kwargs=kw)
+            return img
+
         with torch.no_grad():
-            x2 = torch.cat([x_T, stack("xsrc", (4, h, h))])
-            c2 = torch.cat([c, tc])
-            kw2 = {"inpaint_image": torch.cat([inp, inp]), "inpaint_mask": torch.cat([mask, mask])}
-            store = {}
-            sampler.ddim_invert(x2, c2, a.ddim_steps, (4, h, h), inverse_dir=store, batch_size=F_, max_steps=1,
-                                test_model_kwargs=kw2)
+            img = x_T
+            for i in range(n_warm):
+                img = one_step(img, i)
+            img = x_T
             fence()
-            t1 = time.perf_counter()
-            sampler.ddim_invert(x2, c2, a.ddim_steps, (4, h, h), inverse_dir=store, batch_size=F_, max_steps=a.inv_steps,
-                                test_model_kwargs=kw2)
+            timer.on = time_convs
+            t0 = time.perf_counter()
+            for i in range(n_steps):
+                img = one_step(img, i)
+            t_enq = time.perf_counter() - t0      # host time to enqueue the steps (the GPU runs behind)
             fence()
-            inv_ms = (time.perf_counter() - t1) / a.inv_steps * 1e3
-        sampler.make_schedule(a.ddim_steps, ddim_eta=0.0, verbose=False)
+            el = time.perf_counter() - t0
+            timer.on = False
+        assert torch.isfinite(img).all(), "non-finite latents"
+        # DDIM inversion (ddim_w_inv.py:360-490; SURVEY 8d asks for it separately): hooks off, batch 2F = [target ; source],
+        # no guidance -- 50 such steps per clip precede sampling unless the latents are cached.  Timed outside the step loop.
+        inv_ms = None
+        if inv_steps > 0:
+            with torch.no_grad():
+                x2 = torch.cat([x_T, stack("xsrc", (4, h, h))])
+                c2 = torch.cat([c, tc])
+                kw2 = {"inpaint_image": torch.cat([inp, inp]), "inpaint_mask": torch.cat([mask, mask])}
+                store = {}
+                sampler.ddim_invert(x2, c2, a.ddim_steps, (4, h, h), inverse_dir=store, batch_size=F_, max_steps=1,
+                                    test_model_kwargs=kw2)
+                fence()
+                t1 = time.perf_counter()
+                sampler.ddim_invert(x2, c2, a.ddim_steps, (4, h, h), inverse_dir=store, batch_size=F_, max_steps=inv_steps,
+                                    test_model_kwargs=kw2)
+                fence()
+                inv_ms = (time.perf_counter() - t1) / inv_steps * 1e3
+            sampler.make_schedule(a.ddim_steps, ddim_eta=0.0, verbose=False)
+        if dist is not None:
+            tt = torch.tensor([el], device="cpu" if rehearse else dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return {"ms_step": el / n_steps * 1e3, "enqueue_ms": t_enq / n_steps * 1e3, "inv_ms": inv_ms, "elapsed": el}
+
+    F_ = a.frames
+    log("weights resident; warm-up ...")
+    r = run_workload(F_, a.fusion, a.steps, a.warmup, True, a.inv_steps)
+    ms_step, inv_ms, el = r["ms_step"], r["inv_ms"], r["elapsed"]
+    if inv_ms is not None:
         log(f"inversion: {inv_ms:.2f} ms/step (2F = {2 * F_} unhooked sample-forwards)")
-    if dist is not None:
-        tt = torch.tensor([el], device="cpu" if rehearse else dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-    ms_step = el / a.steps * 1e3
-    log(f"timed {a.steps} steps: {ms_step:.2f} ms/step (host enqueue {t_enq / a.steps * 1e3:.2f} ms/step)")
+    log(f"timed {a.steps} steps: {ms_step:.2f} ms/step (host enqueue {r['enqueue_ms']:.2f} ms/step)")
     fps = (F_ * world) / (a.ddim_steps * ms_step / 1e3)
     n_launch, conv_ms, conv_flops = timer.summary()
-    out = None
+    unet_gflop = {64: 796.94, 96: 2137.52, 32: 176.34}.get(h)   # BASELINE.md 2, per sample-forward
+
+    # the other single-GPU BASELINE configurations, same process and build, outside the timed region of the headline run
+    extras = []
+    if world == 1 and not a.no_extras and h == 64:
+        for name, f2, fus in (("BASELINE configs[2]: 32-frame 512x512 clip + frequency-spectrum attention interpolation", 32, "fft"),
+                              ("shipped hook schedule (ddim_w_inv.py:303-305), config 4's per-GPU share: 16 frames + flow_fix", 16, "flow_fix")):
+            if f2 == F_ and fus == a.fusion:
+                continue
+            log(f"extra workload: {f2} frames, fusion={fus} ...")
+            e = run_workload(f2, fus, a.extra_steps, 2, False, 0)
+            extras.append({"workload": name, "frames_per_gpu": f2, "fusion": fus, "steps": a.extra_steps, "warmup": 2,
+                           "ms_per_step": e["ms_step"], "host_enqueue_ms_per_step": e["enqueue_ms"],
+                           "frames_per_s": f2 / (a.ddim_steps * e["ms_step"] / 1e3),
+                           "unet_algorithmic_tflops": 3 * f2 * unet_gflop * 1e9 / (e["ms_step"] * 1e-3) / 1e12})
+            log(f"  {e['ms_step']:.2f} ms/step = {extras[-1]['frames_per_s']:.2f} frames/s")
+
     if rank == 0:
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        unet_tflops = 3 * F_ * 796.94e9 / (ms_step * 1e-3) / 1e12 if h == 64 else None
-        # HBM-side bytes per conv launch come from separate rocprofv3 --pmc passes of this same command (tools/traffic.sh:
-        # 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md "HBM"); the committed summary is quoted
-        # only for the workload it was collected on, otherwise null.
+        unet_tflops = 3 * F_ * unet_gflop * 1e9 / (ms_step * 1e-3) / 1e12 if unet_gflop else None
+        # HBM-side bytes per conv launch are NOT measured in this run: they come from separate rocprofv3 --pmc passes of this
+        # same command (tools/traffic.sh: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md "HBM");
+        # the committed summary is quoted only for the workload it was collected on, otherwise null.
         traffic, traffic_src = None, None
-        tf = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_d_hbm_traffic.json")
-        if os.path.exists(tf) and F_ == 8 and h == 64 and a.fusion == "replace" and a.dtype == "fp16":
+        prof = os.path.join(ROOT, "profiles")
+        cands = sorted(f for f in os.listdir(prof) if f.endswith("_hbm_traffic.json")) if os.path.isdir(prof) else []
+        if cands and F_ == 8 and h == 64 and a.fusion == "replace" and a.dtype == "fp16":
+            tf = os.path.join(prof, cands[-1])
             traffic = json.load(open(tf))["_conv_all"]["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r01_d_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+            traffic_src = (f"QUOTED from profiles/{cands[-1]} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                           "command on the build it names), not measured in this run")
         out = {
             "metric": "swapped frames/sec at 512x512, 50-step DDIM", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -280,7 +338,9 @@ def main():
                                    f"UNet (859.5M params), attn1 fusion={a.fusion} on input blocks, CFG scale 3.0, "
                                    f"batch [uncond;cond;recon] = {3 * F_} samples per step",
                        "frames_per_gpu": F_, "latent": [h, h], "fusion": a.fusion,
+                       "world_size": world, "backend": backend,
                        "unet_algorithmic_tflops_per_gpu": unet_tflops,
+                       "host_enqueue_ms_per_step": r["enqueue_ms"],
                        # north_star also asks for the rate as a fraction of the attention-GEMM roofline: the attn1 QKV
                        # projections + QK^T + PV are 160.9 GFLOP per sample-forward at 64x64 = 24.1 TFLOP per
                        # swapped frame; at the 2.5 PFLOP/s dense peak that alone would allow 103.6 frames/s per GPU
@@ -290,14 +350,15 @@ def main():
                 "note": "DDIM inversion step (hooks off, batch 2F, no guidance), outside the timed region; `value` is "
                         "sampling only, as BASELINE's metric",
                 "frames_per_s_sampling_plus_inversion": (F_ * world) / (a.ddim_steps * (ms_step + inv_ms) / 1e3)},
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<MODE_CONV> (implicit-GEMM 3x3 conv)",
+            "extra": extras,
+            "roofline": {"bound": "mfma", "kernel": "implicit-GEMM 3x3 conv launches (conv3x3 / conv3x3_plus_1x1 / upsample phases)",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                          "launches": n_launch, "mean_launch_us": conv_ms * 1e3 / max(n_launch, 1),
                          "share_of_step_time": conv_ms / (el * 1e3)},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.fusion, a.cpu_forwards, a.ddim_steps)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_forwards, a.ddim_steps)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VFACE_ABI_VERSION 2
+#define VFACE_ABI_VERSION 3
 
 #define VFACE_OK 0
 #define VFACE_ERR_ARG (-1)
@@ -57,6 +57,25 @@ extern "C" {
 
 int vface_abi_version(void);
 const char* vface_error_string(int code);
+/* 1 if the library was built with the experimental GEMM schedules (`make VARIANTS=1`): VFACE_TUNE_VARIANT(1..4, 9, 10)
+ * are then accepted; the product build returns 0 and refuses them with VFACE_ERR_SHAPE. */
+int vface_gemm_variants_built(void);
+
+/* The fp32 residual stream (optional last argument of the GEMM-family calls; NULL = everything 16-bit).
+ * The reference adds every residual in the autocast type (openaimodel.py:274 `skip_connection(x) + h`,
+ * attention.py:240-242 `attn(...) + x`, :289 `x + x_in`); carrying those sums in fp32 between kernels removes the
+ * largest single share of the 16-bit path's whole-network error.  A HOST struct, read during the call:
+ *   residual32 / ldr32   the residual operand as fp32 [M][ldr32] -- used INSTEAD of the 16-bit `residual` argument
+ *   out32 / ldo32        fp32 [M][ldo32] receives acc + bias + rowbias + residual before the rounding to 16 bits; the
+ *                        16-bit output pointer of the call may then be NULL (no 16-bit copy wanted).  With `colstats`
+ *                        the statistics are those of the fp32 values (what a GroupNorm reading out32 normalises).
+ * 16-byte aligned, ld % 4 == 0; needs N % 8 == 0 and no GEGLU / OUT_F32 epilogue. */
+typedef struct vface_stream32 {
+    const float* residual32;
+    int64_t ldr32;
+    float* out32;
+    int64_t ldo32;
+} vface_stream32;
 
 /* C[M][N] (+)= A[M][K] * Wt[N][K]^T with fused epilogue.
  * Replaces every nn.Linear / 1x1 conv on the path: to_q/to_k/to_v/to_out (attention.py:161-177),
@@ -69,7 +88,8 @@ const char* vface_error_string(int code);
 int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1, int a2_row_mod, const void* Wt,
                int64_t ldw, int M, int N, int K, const float* bias, const float* rowbias, int rows_per_sample,
                int ld_rowbias, const void* residual, int64_t ldr, void* C, int64_t ldc, const void* zeros, int flags,
-               int dtype, float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream);
+               int dtype, float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream,
+               const vface_stream32* s32);
 
 /* Bytes of device scratch a vface_gemm / vface_conv3x3 launch of this shape (M rows = nimg*OH*OW for a convolution,
  * K = 9*Cin) can use to split its K loop over more workgroups when M x N alone would leave most of the 256 CUs idle
@@ -87,7 +107,8 @@ int64_t vface_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_pe
 int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw, int Cout,
                   int stride, int upsample, const float* bias, const float* rowbias, int ld_rowbias,
                   const void* residual, int64_t ldr, void* Y, int64_t ldy, const void* zeros, int flags, int dtype,
-                  float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream);
+                  float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream,
+                  const vface_stream32* s32);
 
 /* Y = conv3x3(X) + X2 W2^T + bias: the second convolution of a ResBlock together with the block's 1x1 shortcut
  * (openaimodel.py:228-232, 274 `skip_connection(x) + h`; diffusionmodules/model.py:137-141 `nin_shortcut`), accumulated in
@@ -96,7 +117,8 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
 int vface_conv3x3_plus_1x1(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* X2, int64_t ldx2, int C2,
                            const void* Wt, int64_t ldw, int Cout, const float* bias, const float* rowbias, int ld_rowbias,
                            void* Y, int64_t ldy, const void* zeros, int flags, int dtype, float* colstats,
-                           int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream);
+                           int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream,
+                           const vface_stream32* s32);
 
 /* One output-parity phase of conv3x3(nearest_upsample2x(X)) (Upsample: openaimodel.py:108-118, diffusionmodules/model.py:
  * 55-58).  Every output pixel (2i+py, 2j+px) of the upsampled convolution sees only a 2x2 block of source pixels, so the
@@ -109,7 +131,7 @@ int vface_conv3x3_plus_1x1(const void* X, int64_t ldx, int nimg, int H, int W, i
 int vface_upsample2x_conv3x3_phase(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw,
                                    int Cout, int py, int px, const float* bias, const float* rowbias, int ld_rowbias, void* Y,
                                    int64_t ldy, const void* zeros, int flags, int dtype, float* colstats,
-                                   int64_t ld_colstats, void* stream);
+                                   int64_t ld_colstats, void* stream, const vface_stream32* s32);
 
 /* O = softmax(Q K^T * scale) V per (sample, head), streaming softmax, no [n x n] matrix.
  * Replaces attention.py:206-220 / pnp_utils.py:270-285.  Output sample b uses q,k of sample qk_map[b] and
@@ -124,21 +146,24 @@ int vface_attention(const void* Q, const void* K, const void* V, int64_t ldq, in
  * v_sets 2|3 and dh 8|16|32|40 (vface_attention_shared_scores_supported); other shapes: use qk_map. */
 int vface_attention_shared_scores_supported(int dh, int v_sets);
 
-/* y = LayerNorm(x) * gamma + beta, fp32 statistics (attention.py:231-233). */
+/* y = LayerNorm(x) * gamma + beta, fp32 statistics (attention.py:231-233).  in_f32: x is the fp32 residual-stream
+ * copy [M][ldx] (ldx in floats); y is always 16-bit (its consumer is a GEMM). */
 int vface_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy, int M,
-                    int C, float eps, int dtype, void* stream);
+                    int C, float eps, int in_f32, int dtype, void* stream);
 
 /* GroupNorm statistics (mean, rstd) per (image, group) -> stats[nimg][groups][2] fp32;
  * `partial` is scratch of vface_groupnorm_partial_floats() floats.  util.py:214-216, attention.py:76-77. */
 int vface_groupnorm_partial_floats(int nimg, int hw, int C, int groups);
 int vface_groupnorm_stats(const void* x, int64_t ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
-                          float* stats, int dtype, void* stream);
+                          float* stats, int in_f32, int dtype, void* stream);
 /* The same statistics from producer-side column sums (colstats of vface_gemm / vface_conv3x3); needs hw % 64 == 0. */
 int vface_groupnorm_finalize_cols(const float* colstats, int64_t ld_colstats, int nimg, int hw, int C, int groups, float eps,
                                   float* stats, void* stream);
-/* y = (x - mean) * rstd * gamma + beta, then SiLU if `silu` (openaimodel.py:201-205,225-232). */
+/* y = (x - mean) * rstd * gamma + beta, then SiLU if `silu` (openaimodel.py:201-205,225-232).  in_f32 (here and in
+ * vface_groupnorm_stats): x is the fp32 residual-stream copy (ldx in floats); y is always 16-bit. */
 int vface_groupnorm_apply(const void* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
-                          void* y, int64_t ldy, int nimg, int hw, int C, int groups, int silu, int dtype, void* stream);
+                          void* y, int64_t ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype,
+                          void* stream);
 
 /* Flow-guided temporal smoothing of a token-major map [F][h*w][C] (temporal_flow.py:40-53,222-237):
  *   dst[f] = alpha * src[f] + one_minus_alpha * bilinear(src[f-1], (x + dx, y + dy)); dst[0] = src[0]
@@ -161,7 +186,7 @@ int vface_flow_warp(const void* src, int64_t ld_src, int64_t fs_src, const void*
  * (pnp_utils.py:201-218).  v_fixed: v of chunks 1,2 <- their first frame (fft_vfixed :255-256).
  * halo_qk / halo_flow: previous rank's last-frame fused q|k [n][2d] and the flow into this rank's frame 0.
  * tail_qk (optional out): this rank's last-frame fused q|k, to hand to the next rank.
- * workspace: vface_attn1_workspace_bytes() bytes. */
+ * workspace: vface_attn1_workspace_bytes() bytes.  s32: fp32 residual / fp32 output of the out-projection. */
 size_t vface_attn1_workspace_bytes(int B, int n, int d, int chunks);
 int vface_attn1_forward(const void* x, int64_t ldx, const void* Wqkv, const void* Wlin, const void* Wo,
                         const float* bo, const float* rowbias, int ld_rowbias, const void* residual, int64_t ldr,
@@ -169,7 +194,7 @@ int vface_attn1_forward(const void* x, int64_t ldx, const void* Wqkv, const void
                         int v_fixed, const float* flow, int h, int w, float alpha, float one_minus_alpha,
                         int warp_flags, const void* halo_qk, const float* halo_flow, void* tail_qk,
                         const int32_t* qk_map, const int32_t* v_map, void* workspace, size_t workspace_bytes,
-                        const void* zeros, int dtype, void* stream);
+                        const void* zeros, int dtype, void* stream, const vface_stream32* s32);
 
 /* fusion="temporal" (pnp_utils.py:59-90,145-154): 5-tap Gaussian (sigma 1, renormalised at the clip ends) over the
  * FRAME axis of src [F][n][C] (chunk 0's q|k), written to dst1 and dst2 (chunk 1 and chunk 2). */

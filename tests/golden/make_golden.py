@@ -343,6 +343,51 @@ def gen_full_unet():
     save("full_unet", **out)
 
 
+def _round_weights_(module, dtype=torch.float16):
+    for prm in module.parameters():
+        prm.data = prm.data.to(dtype).float()
+
+
+@torch.no_grad()
+def gen_lowp(full=False):
+    """Evidence for the whole-network tolerance: the REFERENCE's own low-precision behaviour, made by the
+    reference itself.  For each case two outputs beside the fp32 ones of tiny_unet.npz / full_unet.npz:
+      *_autocast_f16  the reference UNet under ``torch.autocast("cpu", dtype=torch.float16)`` -- the arithmetic the shipped
+                      entry point runs it in (VFace_inference_batch.py:407-408 autocast) with CPU-ATen kernels;
+      *_w16           the reference UNet in fp32 arithmetic with every parameter rounded to fp16 first: the error floor of
+                      ANY implementation that feeds fp16 weights to the matrix cores.
+    Only outputs are stored (same seeded inputs as the fp32 fixtures)."""
+    import ldm.models.pnp_utils as pnp
+    out = {}
+    for tag, mc in (("tiny", 32),) + ((("full", 320),) if full else ()):
+        unet = ref_unet(mc)
+        sampler, dd = make_sampler(unet)
+        F_, h, w = 2, 64, 64
+        x, ctx = unet_inputs(F_, h, w, tag)
+        t = torch.full((3 * F_,), 481, dtype=torch.long)
+        flow = [synth.synth_flow(F_ - 1, h, w)[i][None] for i in range(F_ - 1)]
+
+        def hook(fusion):
+            pnp.register_spa_attn_injection(sampler, 1, switch_on=False, input_blocks=True, middle_block=True,
+                                            output_blocks=True, attn_component="attn1", chunks=3)
+            if fusion is not None:
+                pnp.register_spa_attn_injection(sampler, 1, switch_on=True, input_blocks=True, middle_block=False,
+                                                output_blocks=False, attn_component="attn1",
+                                                flow=flow if fusion == "flow_fix" else None, chunks=3,
+                                                block_indices=list(range(9)), fusion=fusion, split_ratio_fft=0.8, alpha=0.8)
+
+        modes = (("plain", None), ("flow_fix", "flow_fix"), ("replace", "replace"))
+        for name, fusion in modes:
+            hook(fusion)
+            with torch.autocast("cpu", dtype=torch.float16):
+                out[f"{tag}.{name}_autocast_f16"] = unet(x, t, context=ctx).float()
+        _round_weights_(unet)
+        for name, fusion in modes:
+            hook(fusion)
+            out[f"{tag}.{name}_w16"] = unet(x, t, context=ctx)
+    save("lowp", **out)
+
+
 def gen_vae():
     """First-stage KL-VAE: the reference's own Encoder / Decoder (diffusionmodules/model.py:368-568) and
     DiagonalGaussianDistribution, wired as AutoencoderKL.encode / decode wires them (autoencoder.py:301-302,323-333 --
@@ -389,6 +434,7 @@ if __name__ == "__main__":
     _print = builtins.print
     gens = {"fsai": gen_fsai, "warp": gen_warp, "attn": gen_attn_module, "tiny": gen_tiny_unet, "ddim": gen_ddim,
             "vae": gen_vae}
+    gens["lowp"] = lambda: gen_lowp(a.full)
     if a.full:
         gens["full"] = gen_full_unet
     for name, fn in gens.items():

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     for name in decls:
         assert hasattr(lib, name), f"{name} declared in include/vface_hip.h but not exported"
     lib.vface_abi_version.restype = ctypes.c_int
-    assert lib.vface_abi_version() == 2
+    assert lib.vface_abi_version() == 3
 
 
 def test_ctypes_table_matches_header():
@@ -100,7 +100,7 @@ def test_every_entry_point_rejects_null_arguments_without_a_gpu():
             continue
         if name in ("vface_attention_shared_scores_supported",):
             continue
-        args = [None if a is C.c_void_p else (0.0 if a is C.c_float else 0) for a in argtypes]
+        args = [None if (a is C.c_void_p or a is hip._s32p) else (0.0 if a is C.c_float else 0) for a in argtypes]
         rc = getattr(lib, name)(*args)
         assert rc < 0, (name, rc)
         msg = lib.vface_error_string(rc)
@@ -135,3 +135,27 @@ def test_upsample_phase_weights_are_exact(cin, cout, H, W):
             k = k[:, :, :cin].reshape(cout, 2, 2, cin).permute(0, 3, 1, 2)
             out[:, :, py::2, px::2] = F.conv2d(F.pad(x, (1 - px, px, 1 - py, py)), k)
     assert torch.allclose(out, ref, atol=1e-5)                   # weights went through fp32 once
+
+
+def test_bench_self_launches_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` (the driver's form, no rendezvous in the environment) must start N ranks itself, as a
+    child process, before anything touches the GPU; a rank started by torch.distributed.run must not re-launch."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = []
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: calls.append((cmd, env)) or 0)
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("parent touched the GPU")))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(calls) == 1
+    cmd, env = calls[0]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -27,6 +27,12 @@ def rnd(shape, seed, dt, scale=1.0):
 
 
 VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]  # 0 = automatic schedule; 1..8 forced (include/vface_hip.h)
+EXPERIMENTAL = (1, 2, 3, 4, 9, 10)              # built by `make VARIANTS=1` only
+
+
+def need_variant(h, variant):
+    if variant in EXPERIMENTAL and not h.load().vface_gemm_variants_built():
+        pytest.skip("experimental GEMM schedule: not in the product build (make VARIANTS=1)")
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -35,6 +41,7 @@ VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]  # 0 = automatic schedule; 1..8 fo
                                    (700, 160, 1096)])
 def test_gemm_plain_bias_residual(dt, M, N, K, variant):
     h = hip()
+    need_variant(h, variant)
     if variant and dt == torch.bfloat16 and (M, N, K) != (1000, 320, 320):
         pytest.skip("forced variants: bf16 checked on one shape")
     a, w = rnd((M, K), 1, dt), rnd((N, K), 2, dt, 1 / math.sqrt(K))
@@ -72,6 +79,7 @@ def test_gemm_strided_views_rowbias_dual_source():
 @pytest.mark.parametrize("variant", [0, 1, 3, 5, 7, 9])
 def test_gemm_geglu(variant):
     h = hip()
+    need_variant(h, variant)
     dt = torch.float16
     M, d = 300, 64
     x = rnd((M, d), 1, dt)
@@ -94,6 +102,7 @@ def test_gemm_geglu(variant):
                                                     (128, 160, 20, 12, 1, False)])
 def test_conv3x3(dt, cin, cout, H, W, stride, up, variant):
     h = hip()
+    need_variant(h, variant)
     if variant and dt == torch.bfloat16:
         pytest.skip("forced variants: fp16 only")
     from vface_amd.packing import pack_conv3x3
@@ -574,3 +583,63 @@ def test_conv3x3_plus_1x1_shortcut(dt, cin, c2, cout, H, nimg):
     assert rel_l2(out.cpu().float().permute(0, 3, 1, 2), ref) < TOL[dt]
     yf = out.float().reshape(nimg * H * H // 64, 64, cout)
     assert torch.allclose(cs[..., 0], yf.sum(1), rtol=1e-4, atol=2e-2)
+
+
+# ------------------------------------------------------------------------------------------ fp32 residual stream
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,want16", [(1000, 320, 320, True), (4096, 640, 640, False), (130, 72, 64, True)])
+def test_gemm_fp32_residual_stream(dt, M, N, K, want16):
+    """vface_stream32: the residual is read in fp32, the un-rounded sum is stored as fp32 (the carrier) and -- when
+    asked for -- its single rounding as the 16-bit copy; column statistics are those of the fp32 values."""
+    h = hip()
+    a, w = rnd((M, K), 1, dt), rnd((N, K), 2, dt, 1 / math.sqrt(K))
+    bias, res32 = rnd((N,), 3, torch.float32), rnd((M, N), 4, torch.float32)
+    out32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    out16 = torch.empty(M, N, dtype=dt, device=DEV) if want16 else None
+    cs = torch.zeros((M + 63) // 64, N, 2, dtype=torch.float32, device=DEV) if M % 64 == 0 else None
+    h.gemm(a.to(DEV), w.to(DEV), out16, M=M, N=N, K=K, lda=K, ldc=N, bias=bias.to(DEV), residual32=res32.to(DEV),
+           out32=out32, colstats=cs)
+    ref = a.double() @ w.double().t() + bias.double() + res32.double()
+    assert rel_l2(out32.cpu(), ref) < 2e-6          # fp32 accumulate of exact 16-bit products, fp32 epilogue
+    if want16:
+        assert torch.equal(out16.cpu(), out32.cpu().to(dt))   # one rounding of the very same sum
+    if cs is not None:
+        o = out32.cpu().double().reshape(M // 64, 64, N)
+        assert rel_l2(cs[..., 0].cpu(), o.sum(1)) < 1e-5 and rel_l2(cs[..., 1].cpu(), (o * o).sum(1)) < 1e-5
+
+
+def test_conv_fp32_residual_stream_and_split_k():
+    """The same through the implicit-GEMM convolution, incl. a split-K shape (the 8x8 level) and the fused 1x1 shortcut."""
+    h = hip()
+    dt = torch.float16
+    for cin, cout, H, nimg in ((64, 64, 16, 2), (1280, 1280, 8, 6)):
+        x = rnd((nimg, cin, H, H), 1, dt)
+        wt = rnd((cout, cin, 3, 3), 2, dt, 1 / math.sqrt(9 * cin))
+        bias, res32 = rnd((cout,), 3, torch.float32), rnd((nimg * H * H, cout), 4, torch.float32)
+        from vface_amd import packing
+        xn = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(DEV)
+        wp = packing.pack_conv3x3(wt.float()).to(dt).to(DEV)
+        out32 = torch.empty(nimg * H * H, cout, dtype=torch.float32, device=DEV)
+        out16 = torch.empty(nimg * H * H, cout, dtype=dt, device=DEV)
+        h.conv3x3(xn, wp, out16, nimg=nimg, H=H, W=H, cin=cin, cout=cout, ldx=cin, ldy=cout, bias=bias.to(DEV),
+                  residual32=res32.to(DEV), out32=out32)
+        ref = F.conv2d(x.double(), wt.double(), bias.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, cout) + res32.double()
+        assert rel_l2(out32.cpu(), ref) < 3e-6, (cin, cout)
+        assert torch.equal(out16.cpu(), out32.cpu().to(dt))
+
+
+@pytest.mark.parametrize("C", [320, 1280])
+def test_norms_read_the_fp32_stream(C):
+    """LayerNorm / GroupNorm statistics + apply on an fp32 input equal the fp32 torch result to 16-bit rounding."""
+    h = hip()
+    dt = torch.float16
+    M, hw, nimg = 512, 256, 2
+    x = rnd((M, C), 1, torch.float32)
+    gm, bt = 1 + 0.1 * rnd((C,), 2, torch.float32), 0.1 * rnd((C,), 3, torch.float32)
+    y = torch.empty(M, C, dtype=dt, device=DEV)
+    h.layernorm(x.to(DEV), gm.to(DEV), bt.to(DEV), y, M=M, C_=C, ldx=C, ldy=C)
+    assert rel_l2(y.cpu().float(), F.layer_norm(x, (C,), gm, bt, 1e-5)) < 4e-4
+    st = h.groupnorm_stats(x.to(DEV), nimg=nimg, hw=hw, C_=C, ldx=C)
+    h.groupnorm_apply(x.to(DEV), st, gm.to(DEV), bt.to(DEV), y, nimg=nimg, hw=hw, C_=C, ldx=C, ldy=C, silu=True)
+    ref = F.silu(F.group_norm(x.reshape(nimg, hw, C).permute(0, 2, 1), 32, gm, bt, 1e-5)).permute(0, 2, 1).reshape(M, C)
+    assert rel_l2(y.cpu().float(), ref) < 4e-4

@@ -1,7 +1,11 @@
-"""Frame sharding on the MI355X box: two ranks (both on the one visible GPU, gloo for the boundary exchange through
-host staging) run the flow_fix UNet on 2 + 2 frames; every rank's eps must equal the unsharded 4-frame run bit for
-bit (same kernels, same arithmetic, only the halo frame arrives over the wire).  The production backend is "nccl"
-(RCCL over xGMI), one process per GPU -- see bench.py --gpus N --fusion flow_fix."""
+"""Frame sharding on the MI355X box.
+
+* STRICT (gating): every shard of a clip runs through ``UNetEngine._attn1_sharded`` -- the only code that differs between
+  1 and N ranks -- one after another in ONE process, with an in-memory loop-back exchange (``parallel.LoopbackShard``);
+  each shard's eps must equal the unsharded run bit for bit (``torch.equal``), for an even and an uneven split.
+* DIAGNOSTIC (non-gating on bit-identity): two PROCESSES time-slicing the one visible GPU, gloo host staging for the
+  halo -- a rehearsal of the multi-process control flow.  The production backend is "nccl" (RCCL over xGMI), one
+  process per GPU: bench.py --gpus N --fusion flow_fix."""
 import os
 import socket
 
@@ -60,6 +64,57 @@ def _run(rank, world, port, outdir):
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _shard_inputs(total, h, w, f0, fc, dev):
+    from vface_amd.utils import synth
+    xs = [synth.synth_normal(f"shard.x.{c}", (total, 9, h, w)) for c in range(3)]      # per chunk, per global frame
+    cs = [synth.synth_normal(f"shard.c.{c}", (total, 1, 768)) for c in range(3)]
+    x = torch.cat([t[f0:f0 + fc] for t in xs]).to(dev)
+    ctx = torch.cat([t[f0:f0 + fc] for t in cs]).to(dev)
+    return x, ctx
+
+
+@pytest.mark.parametrize("total,world", [(4, 2), (5, 3)])
+def test_loopback_shards_equal_unsharded_bit_for_bit(total, world):
+    """One process, one GPU: ranks 0..world-1 of the real engine (flow_fix on the input-block attn1) run in order, the
+    boundary slabs handed over in memory.  torch.equal against the unsharded run."""
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler
+    from vface_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from vface_amd.ldm.models.pnp_utils import register_spa_attn_injection as reg
+    from vface_amd.parallel import LoopbackShard
+    from vface_amd.utils import synth
+    dev = "cuda:0"
+    h = w = 32
+    ldm = LatentDiffusion(_cfg())
+    synth.fill_module_(ldm.unet, seed=0)
+    ldm = ldm.to(dev)
+    sampler = DDIMSampler(ldm)
+    gflow = synth.synth_flow(total - 1, h, w)
+    eng = ldm.unet.engine
+
+    def run(shard):
+        x, ctx = _shard_inputs(total, h, w, shard.first, shard.count, dev)
+        tt = torch.full((3 * shard.count,), 481, dtype=torch.long, device=dev)
+        shard.install(eng, gflow, dev)
+        flow = shard.local_flow(gflow)
+        reg(sampler, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True)
+        reg(sampler, 1, switch_on=True, input_blocks=True, middle_block=False, output_blocks=False, chunks=3,
+            flow=[f[None] for f in flow], block_indices=list(range(9)), fusion="flow_fix", split_ratio_fft=0.8, alpha=0.8)
+        shard.begin_forward()
+        return ldm.apply_model(x, tt, ctx).float()
+
+    full = run(LoopbackShard(0, 1, total, {}))
+    store = {}
+    n_exchanges = 0
+    for r in range(world):
+        sh = LoopbackShard(r, world, total, store)
+        out = run(sh)
+        assert eng.halo_exchange is sh
+        n_exchanges = max(n_exchanges, len(store[r]))
+        ref = torch.cat([full[c * total + sh.first:c * total + sh.first + sh.count] for c in range(3)])
+        assert torch.equal(out, ref), f"rank {r}/{world}: max diff {(out - ref).abs().max().item():.3e}"
+    assert n_exchanges == 2, n_exchanges   # the two level-0 hooked layers (n == h*w of the flow field)
 
 
 def test_two_rank_flow_fix_equals_unsharded(tmp_path):

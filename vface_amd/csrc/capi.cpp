@@ -17,11 +17,18 @@ GemmParams plain_gemm(const void* A, long lda, const void* Wt, long ldw, int M, 
     p.bias = bias; p.C = C; p.ldc = ldc; p.zeros = zeros;
     return p;
 }
+// the optional fp32 residual stream of a GEMM-family call
+inline void apply_s32(GemmParams& p, const vface_stream32* s) {
+    if (!s) return;
+    if (s->residual32) { p.residual = s->residual32; p.ldr = s->ldr32; p.res_f32 = 1; }
+    if (s->out32) { p.C32 = s->out32; p.ldc32 = s->ldo32; }
+}
 }  // namespace
 
 extern "C" {
 
 int vface_abi_version(void) { return VFACE_ABI_VERSION; }
+int vface_gemm_variants_built(void) { return vf_gemm_variants_built() ? 1 : 0; }
 
 const char* vface_error_string(int code) {
     switch (code) {
@@ -39,20 +46,23 @@ const char* vface_error_string(int code) {
 int vface_gemm(const void* A, int64_t lda, const void* A2, int64_t lda2, int K1, int a2_row_mod, const void* Wt,
                int64_t ldw, int M, int N, int K, const float* bias, const float* rowbias, int rows_per_sample,
                int ld_rowbias, const void* residual, int64_t ldr, void* C, int64_t ldc, const void* zeros, int flags,
-               int dtype, float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream) {
+               int dtype, float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream,
+               const vface_stream32* s32) {
     GemmParams p = plain_gemm(A, lda, Wt, ldw, M, N, K, bias, C, ldc, zeros);
     p.colstats = colstats; p.ld_colstats = ld_colstats;
     p.workspace = static_cast<float*>(workspace); p.workspace_bytes = workspace ? workspace_bytes : 0;
     p.A2 = A2; p.lda2 = lda2; p.K1 = K1; p.a2_row_mod = a2_row_mod;
     p.rowbias = rowbias; p.rows_per_sample = rows_per_sample; p.ld_rowbias = ld_rowbias;
     p.residual = residual; p.ldr = ldr; p.flags = flags;
+    apply_s32(p, s32);
     return vf_launch_gemm(p, dtype, S(stream));
 }
 
 int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw, int Cout,
                   int stride, int upsample, const float* bias, const float* rowbias, int ld_rowbias,
                   const void* residual, int64_t ldr, void* Y, int64_t ldy, const void* zeros, int flags, int dtype,
-                  float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream) {
+                  float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream,
+                  const vface_stream32* s32) {
     if (nimg <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return VFACE_ERR_ARG;
     if (stride != 1 && stride != 2) return VFACE_ERR_SHAPE;
     if (flags & VFACE_EPI_GEGLU) return VFACE_ERR_SHAPE;
@@ -68,13 +78,15 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
     p.residual = residual; p.ldr = ldr; p.C = Y; p.ldc = ldy; p.zeros = zeros; p.flags = flags;
     p.colstats = colstats; p.ld_colstats = ld_colstats;
     p.workspace = static_cast<float*>(workspace); p.workspace_bytes = workspace ? workspace_bytes : 0;
+    apply_s32(p, s32);
     return vf_launch_gemm(p, dtype, S(stream));
 }
 
 int vface_conv3x3_plus_1x1(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* X2, int64_t ldx2, int C2,
                            const void* Wt, int64_t ldw, int Cout, const float* bias, const float* rowbias, int ld_rowbias,
                            void* Y, int64_t ldy, const void* zeros, int flags, int dtype, float* colstats,
-                           int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream) {
+                           int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream,
+                           const vface_stream32* s32) {
     if (nimg <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || C2 <= 0 || !X2) return VFACE_ERR_ARG;
     if (flags & (VFACE_EPI_GEGLU | VFACE_CONV_PAD_TRAILING)) return VFACE_ERR_SHAPE;
     GemmParams p{};
@@ -87,14 +99,16 @@ int vface_conv3x3_plus_1x1(const void* X, int64_t ldx, int nimg, int H, int W, i
     p.C = Y; p.ldc = ldy; p.zeros = zeros; p.flags = flags;
     p.colstats = colstats; p.ld_colstats = ld_colstats;
     p.workspace = static_cast<float*>(workspace); p.workspace_bytes = workspace ? workspace_bytes : 0;
+    apply_s32(p, s32);
     return vf_launch_gemm(p, dtype, S(stream));
 }
 
 int vface_upsample2x_conv3x3_phase(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* Wt, int64_t ldw,
                                    int Cout, int py, int px, const float* bias, const float* rowbias, int ld_rowbias, void* Y,
                                    int64_t ldy, const void* zeros, int flags, int dtype, float* colstats,
-                                   int64_t ld_colstats, void* stream) {
+                                   int64_t ld_colstats, void* stream, const vface_stream32* s32) {
     if (nimg <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (py & ~1) || (px & ~1)) return VFACE_ERR_ARG;
+    if (s32 && s32->residual32) return VFACE_ERR_SHAPE;
     if (flags & (VFACE_EPI_GEGLU | VFACE_EPI_OUT_F32 | VFACE_CONV_PAD_TRAILING)) return VFACE_ERR_SHAPE;
     GemmParams p{};
     p.mode = 1; p.A = X; p.lda = ldx; p.Wt = Wt; p.ldw = ldw; p.Kw = 4 * Cin;
@@ -106,6 +120,7 @@ int vface_upsample2x_conv3x3_phase(const void* X, int64_t ldx, int nimg, int H, 
     p.bias = bias; p.rowbias = rowbias; p.rows_per_sample = H * W; p.ld_rowbias = ld_rowbias;
     p.C = Y; p.ldc = ldy; p.zeros = zeros; p.flags = flags;
     p.colstats = colstats; p.ld_colstats = ld_colstats;
+    apply_s32(p, s32);
     return vf_launch_gemm(p, dtype, S(stream));
 }
 
@@ -132,8 +147,8 @@ int vface_attention_shared_scores_supported(int dh, int v_sets) {
 }
 
 int vface_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* y, int64_t ldy, int M,
-                    int C, float eps, int dtype, void* stream) {
-    return vf_launch_layernorm(x, ldx, gamma, beta, y, ldy, M, C, eps, dtype, S(stream));
+                    int C, float eps, int in_f32, int dtype, void* stream) {
+    return vf_launch_layernorm(x, ldx, gamma, beta, y, ldy, M, C, eps, in_f32, dtype, S(stream));
 }
 
 int vface_groupnorm_partial_floats(int nimg, int hw, int C, int groups) {
@@ -142,8 +157,8 @@ int vface_groupnorm_partial_floats(int nimg, int hw, int C, int groups) {
 }
 
 int vface_groupnorm_stats(const void* x, int64_t ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
-                          float* stats, int dtype, void* stream) {
-    return vf_launch_gn_stats(x, ldx, nimg, hw, C, groups, eps, partial, stats, dtype, S(stream));
+                          float* stats, int in_f32, int dtype, void* stream) {
+    return vf_launch_gn_stats(x, ldx, nimg, hw, C, groups, eps, partial, stats, in_f32, dtype, S(stream));
 }
 
 int vface_groupnorm_finalize_cols(const float* colstats, int64_t ld_colstats, int nimg, int hw, int C, int groups, float eps,
@@ -152,9 +167,9 @@ int vface_groupnorm_finalize_cols(const float* colstats, int64_t ld_colstats, in
 }
 
 int vface_groupnorm_apply(const void* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
-                          void* y, int64_t ldy, int nimg, int hw, int C, int groups, int silu, int dtype,
+                          void* y, int64_t ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype,
                           void* stream) {
-    return vf_launch_gn_apply(x, ldx, stats, gamma, beta, y, ldy, nimg, hw, C, groups, silu, dtype, S(stream));
+    return vf_launch_gn_apply(x, ldx, stats, gamma, beta, y, ldy, nimg, hw, C, groups, silu, in_f32, dtype, S(stream));
 }
 
 int vface_flow_warp(const void* src, int64_t ld_src, int64_t fs_src, const void* prev, int64_t ld_prev,
@@ -177,8 +192,8 @@ int vface_attn1_forward(const void* x, int64_t ldx, const void* Wqkv, const void
                         int v_fixed, const float* flow, int h, int w, float alpha, float one_minus_alpha,
                         int warp_flags, const void* halo_qk, const float* halo_flow, void* tail_qk,
                         const int32_t* qk_map, const int32_t* v_map, void* workspace, size_t workspace_bytes,
-                        const void* zeros, int dtype, void* stream) {
-    if (!x || !Wqkv || !Wo || !out || !workspace || !zeros) return VFACE_ERR_ARG;
+                        const void* zeros, int dtype, void* stream, const vface_stream32* s32) {
+    if (!x || !Wqkv || !Wo || (!out && !(s32 && s32->out32)) || !workspace || !zeros) return VFACE_ERR_ARG;
     if (B <= 0 || n <= 0 || d <= 0 || heads <= 0 || chunks <= 0 || d % heads) return VFACE_ERR_ARG;
     if (dtype != VFACE_F16 && dtype != VFACE_BF16) return VFACE_ERR_DTYPE;
     if (fusion != VFACE_FUSION_NONE && B % chunks) return VFACE_ERR_SHAPE;
@@ -249,6 +264,7 @@ int vface_attn1_forward(const void* x, int64_t ldx, const void* Wqkv, const void
     GemmParams po = plain_gemm(att, d, Wo, d, B * n, d, d, bo, out, ldo, zeros);
     po.rowbias = rowbias; po.rows_per_sample = n; po.ld_rowbias = ld_rowbias;
     po.residual = residual; po.ldr = ldr;
+    apply_s32(po, s32);
     return vf_launch_gemm(po, dtype, st);
 }
 

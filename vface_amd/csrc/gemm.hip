@@ -285,8 +285,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         const bool gg = p.flags & GEMM_GEGLU;
         const float* bias = p.bias;
         const float* rowbias = p.rowbias;
-        const E* res = reinterpret_cast<const E*>(p.residual);
+        // residual: 16-bit, or the fp32 residual-stream carrier (res_f32); output: 16-bit C and / or the fp32 carrier C32
+        const E* res = p.res_f32 ? nullptr : reinterpret_cast<const E*>(p.residual);
+        const float* res32 = p.res_f32 ? reinterpret_cast<const float*>(p.residual) : nullptr;
         E* Cout = reinterpret_cast<E*>(p.C);
+        float* C32 = p.C32;
         float* colstats = p.colstats;
         const bool want_stats = colstats && !(p.flags & 0x4000);
         float* scr = scr_base + wave * (16 * SP);
@@ -316,6 +319,20 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // fp32 residual rows of this tile row: requested before the transpose below, used after it
+            float4 r32[RI][2];
+            if (res32) {
+#pragma unroll
+                for (int it = 0; it < RI; ++it) {
+                    const int r = rrow + it * LPRC;
+                    const int m = em0 + wm * 64 + i * 16 + r;
+                    if (act && r < 16 && m < p.M && ncol < nout) {
+                        const float* rp = res32 + (long)m * p.ldr + ncol;
+                        r32[it][0] = *reinterpret_cast<const float4*>(rp);
+                        r32[it][1] = *reinterpret_cast<const float4*>(rp + 4);
+                    }
+                }
+            }
             {
                 const int m = em0 + wm * 64 + i * 16 + fr;
                 const float* rb = (rowbias && m < p.M) ? rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
@@ -366,6 +383,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) v[e] += to_f32(r8[e]);
                         }
+                        if (res32) {
+                            const float4 a = r32[it < RI ? it : 0][0], b = r32[it < RI ? it : 0][1];
+                            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+                        }
                         V8 o;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
@@ -376,10 +397,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                             const int hw = p.OH * p.OW, img = m / hw, rem = m - img * hw, oy = rem / p.OW, ox = rem - oy * p.OW;
                             orow = ((long)img * 2 * p.OH + 2 * oy + ((p.out_phase >> 1) & 1)) * (2 * p.OW) + 2 * ox + (p.out_phase & 1);
                         }
-                        *reinterpret_cast<V8*>(Cout + orow * p.ldc + ncol) = o;
+                        if (Cout) *reinterpret_cast<V8*>(Cout + orow * p.ldc + ncol) = o;
+                        if (C32) {
+                            float* d32 = C32 + orow * p.ldc32 + ncol;
+                            *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        }
                         if (want_stats) {
+                            // statistics of the values the following GroupNorm will read: the fp32 carrier if there is one
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] += f * f; }
+                            for (int e = 0; e < 8; ++e) { const float f = C32 ? v[e] : to_f32(o[e]); s8[e] += f; q8[e] += f * f; }
                         }
                     }
                 }
@@ -671,7 +698,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
     const int n = blockIdx.y * 256 + c8 * 8;
     const int mbase = blockIdx.x * 64;
     const bool ncol_ok = n < p.N;
-    const E* res = reinterpret_cast<const E*>(p.residual);
+    const E* res = p.res_f32 ? nullptr : reinterpret_cast<const E*>(p.residual);
+    const float* res32 = p.res_f32 ? reinterpret_cast<const float*>(p.residual) : nullptr;
     E* Cout = reinterpret_cast<E*>(p.C);
     float s8[8], q8[8];
 #pragma unroll
@@ -702,12 +730,22 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += to_f32(r8[e]);
         }
+        if (res32) {
+            const float* rp = res32 + (long)m * p.ldr + n;
+            const float4 a = *reinterpret_cast<const float4*>(rp), b = *reinterpret_cast<const float4*>(rp + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
         V8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
-        *reinterpret_cast<V8*>(Cout + (long)m * p.ldc + n) = o;
+        if (Cout) *reinterpret_cast<V8*>(Cout + (long)m * p.ldc + n) = o;
+        if (p.C32) {
+            float* d32 = p.C32 + (long)m * p.ldc32 + n;
+            *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] += f * f; }
+        for (int e = 0; e < 8; ++e) { const float f = p.C32 ? v[e] : to_f32(o[e]); s8[e] += f; q8[e] += f * f; }
     }
     if (p.colstats) {
 #pragma unroll
@@ -816,6 +854,14 @@ int split_for(int M, int N, int K, int flags, int rows_per_sample) {
 
 }  // namespace
 
+bool vf_gemm_variants_built() {
+#ifdef VFACE_GEMM_VARIANTS
+    return true;
+#else
+    return false;
+#endif
+}
+
 long vf_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_sample) {
     const int s = split_for(M, N, K, flags, rows_per_sample);
     return s > 1 ? (long)s * M * N * 4 : 0;
@@ -824,11 +870,20 @@ long vf_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_samp
 int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     GemmParams p = p_in;
     p.split_k = 1; p.kt_per_split = 0;
-    if (!p.A || !p.Wt || !p.C || !p.zeros) return VF_ERR_ARG;
+    if (!p.A || !p.Wt || (!p.C && !p.C32) || !p.zeros) return VF_ERR_ARG;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return VF_ERR_ARG;
+    if (p.res_f32 && !p.residual) p.res_f32 = 0;
+    if (p.res_f32 || p.C32) {
+        // the fp32 residual stream lives in the wide epilogue (and the split-K reduce) only
+        if ((p.flags & (GEMM_GEGLU | GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE | 0x4000)) || (p.N & 7)) return VF_ERR_SHAPE;
+        if (p.C32 && (((uintptr_t)p.C32 & 15) || (p.ldc32 & 3))) return VF_ERR_ALIGN;
+        if (p.res_f32 && (((uintptr_t)p.residual & 15) || (p.ldr & 3))) return VF_ERR_ALIGN;
+        if (p.out_phase && p.res_f32) return VF_ERR_SHAPE;
+    }
     if ((p.K & 7) || (p.Kw & 7) || (p.lda & 7) || (p.ldw & 7) || (p.N & 3) || (p.ldc & 3)) return VF_ERR_ALIGN;
     if (((uintptr_t)p.A | (uintptr_t)p.Wt | (uintptr_t)p.zeros) & 15) return VF_ERR_ALIGN;
     if ((uintptr_t)p.C & 7) return VF_ERR_ALIGN;
+    if (p.C32 && (((uintptr_t)p.C & 15) || (p.ldc & 7))) return VF_ERR_ALIGN;
     if (p.residual && (((uintptr_t)p.residual & 7) || (p.ldr & 3))) return VF_ERR_ALIGN;
     if (p.rowbias && (p.rows_per_sample <= 0 || (p.ld_rowbias & 3))) return VF_ERR_ARG;
     if ((p.flags & GEMM_GEGLU) && ((p.N & 31) || (p.flags & GEMM_OUT_F32) || p.residual || p.rowbias)) return VF_ERR_SHAPE;
@@ -855,6 +910,7 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb; p.a2_bytes = (unsigned)a2b;
     }
     const int variant = pick_variant(p);
+    if ((p.res_f32 || p.C32) && variant != 5 && variant != 6) return VF_ERR_SHAPE;
     if (p.mode == 1 && (p.ntaps != 9 || p.out_phase || p.A2) && variant != 5 && variant != 6) return VF_ERR_SHAPE;
     if (p.workspace && !p.out_phase && (variant == 5 || variant == 6) && !((p.flags >> 8) & 0xF) && !(p.flags & 0x4000)) {
         const int s = split_for(p.M, p.N, p.K, p.flags, p.rows_per_sample);
@@ -868,8 +924,12 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     }
     if ((p.flags & GEMM_GEGLU) && (variant == 2 || variant == 4 || variant == 6 || variant == 8 || variant == 10)) return VF_ERR_SHAPE;
     if (p.colstats && (variant < 5 || variant > 8)) return VF_ERR_SHAPE;
+#ifdef VFACE_GEMM_VARIANTS   // experimental schedules, `make VARIANTS=1` builds only
     if (variant >= 1 && variant <= 4) return vf_launch_gemm_pipe(p, dtype, variant, stream);
     if (variant == 9 || variant == 10) return vf_launch_gemm_pp(p, dtype, variant, stream);
+#else
+    if ((variant >= 1 && variant <= 4) || variant == 9 || variant == 10) return VF_ERR_SHAPE;
+#endif
     if (dtype == VF_DTYPE_F16) return launch_gemm<F16>(p, variant, stream);
     if (dtype == VF_DTYPE_BF16) return launch_gemm<BF16>(p, variant, stream);
     return VF_ERR_DTYPE;

@@ -5,12 +5,27 @@
 
 namespace {
 
+// 8 consecutive channels as fp32: from a 16-bit tensor, or (IN32) from the fp32 residual-stream copy of it
+// (`off` counts elements of the tensor's own type)
+template <class TT, bool IN32>
+__device__ __forceinline__ void load8(const void* base, long off, float (&f)[8]) {
+    if constexpr (IN32) {
+        const float4 a = *reinterpret_cast<const float4*>(static_cast<const float*>(base) + off);
+        const float4 b = *reinterpret_cast<const float4*>(static_cast<const float*>(base) + off + 4);
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    } else {
+        const typename TT::v8 t = *reinterpret_cast<const typename TT::v8*>(static_cast<const typename TT::elem*>(base) + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = to_f32(t[j]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ LayerNorm
 // attention.py:231-233 (nn.LayerNorm, eps 1e-5).  fp32 statistics (autocast keeps layer_norm in fp32);
 // the result is written in the 16-bit type because its only consumer is a 16-bit GEMM.
 // One wave per row: the row (<= 2048 channels) lives in registers between the two passes.
-template <class TT, int CH8>  // CH8: 16-B chunks per lane (row length <= 512*CH8)
-__global__ __launch_bounds__(256) void layernorm_kernel(const typename TT::elem* __restrict__ x, long ldx,
+template <class TT, int CH8, bool IN32>  // CH8: 8-channel chunks per lane (row length <= 512*CH8); IN32: x is fp32
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* __restrict__ x, long ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         typename TT::elem* __restrict__ y, long ldy, int M, int C,
@@ -20,16 +35,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const typename TT::elem*
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const E* xr = x + (long)row * ldx;
     float v[CH8][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < CH8; ++i) {
         const int c = (i * 64 + lane) * 8;
         if (c < C) {
-            const V8 t = *reinterpret_cast<const V8*>(xr + c);
+            load8<TT, IN32>(x, (long)row * ldx + c, v[i]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { v[i][j] = to_f32(t[j]); s += v[i][j]; }
+            for (int j = 0; j < 8; ++j) s += v[i][j];
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
@@ -69,16 +83,14 @@ constexpr int GN_PIX = 128;  // pixels per workgroup
 // Thread t owns one 16-B channel chunk (t % CPB) and one pixel lane (t / CPB): its 8 channels' (sum, sumsq) stay in
 // registers across the pixel loop; the pixel lanes are then folded through LDS in a FIXED order (no atomics), so the
 // statistics -- and everything downstream -- are bitwise reproducible.
-template <class TT>
-__global__ __launch_bounds__(256) void gn_partial_kernel(const typename TT::elem* __restrict__ x, long ldx, int hw,
+template <class TT, bool IN32>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const void* __restrict__ x, long ldx, int hw,
                                                          int C, int groups, float* __restrict__ partial) {
-    using E = typename TT::elem;
-    using V8 = typename TT::v8;
     extern __shared__ float gn_lds[];  // [PP][CPB*8][2] lane partials, then [C][2] channel sums
     const int img = blockIdx.y, chunk = blockIdx.x, t = threadIdx.x;
     const int cpg = C / groups, c8 = C / 8;
     const int p0 = chunk * GN_PIX, p1 = min(hw, p0 + GN_PIX);
-    const E* base = x + (long)img * hw * ldx;
+    const long base = (long)img * hw * ldx;
     const int CPB = min(c8, 256), PP = 256 / CPB;
     const int lanep = t / CPB, cl = t - lanep * CPB;
     float* lane_part = gn_lds;                      // PP * CPB * 16 floats
@@ -90,9 +102,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const typename TT::elem
         for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
         if (lanep < PP && ch < c8) {
             for (int p = p0 + lanep; p < p1; p += PP) {
-                const V8 v = *reinterpret_cast<const V8*>(base + (long)p * ldx + ch * 8);
+                float f[8];
+                load8<TT, IN32>(x, base + (long)p * ldx + ch * 8, f);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float f = to_f32(v[j]); s[j] += f; q[j] += f * f; }
+                for (int j = 0; j < 8; ++j) { s[j] += f[j]; q[j] += f[j] * f[j]; }
             }
         }
         if (lanep < PP) {
@@ -164,8 +177,8 @@ __global__ __launch_bounds__(64) void gn_finalize_cols_kernel(const float* __res
     }
 }
 
-template <class TT>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const typename TT::elem* __restrict__ x, long ldx,
+template <class TT, bool IN32>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ x, long ldx,
                                                        const float* __restrict__ stats,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
@@ -177,7 +190,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const typename TT::elem* 
     const int c8 = C / 8, cpg = C / groups;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(hw, p0 + pix_per_block);
     const float* st = stats + (long)img * groups * 2;
-    const E* xb = x + (long)img * hw * ldx;
+    const long xb = (long)img * hw * ldx;
     E* yb = y + (long)img * hw * ldy;
     const int CPB = min(c8, 256), PP = 256 / CPB;
     const int lanep = t / CPB, cl = t - lanep * CPB;
@@ -192,11 +205,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const typename TT::elem* 
             b[j] = beta[c] - st[2 * g] * a[j];
         }
         for (int p = p0 + lanep; p < p1; p += PP) {
-            const V8 v = *reinterpret_cast<const V8*>(xb + (long)p * ldx + ch * 8);
+            float v[8];
+            load8<TT, IN32>(x, xb + (long)p * ldx + ch * 8, v);
             V8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float f = to_f32(v[j]) * a[j] + b[j];
+                float f = v[j] * a[j] + b[j];
                 if (silu) f = silu_f(f);
                 o[j] = from_f32<E>(f);
             }
@@ -250,6 +264,13 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(const typename TT::elem*
     const float* fl = nullptr;
     if (f > 0) { from = src + (long)(f - 1) * fs_src; fl = flow + (long)(f - 1) * 2 * h * w; }
     else if (prev) { from = prev; ld_from = ld_prev; fl = flow_prev; }
+    // The four bilinear taps are read through a buffer descriptor over the source frame (32-bit offsets, one wave-uniform
+    // base; the launcher checks the frame view is < 4 GiB): a tap's address is one 32-bit multiply-add instead of a 64-bit
+    // chain, and the load's destination registers never alias an address pair.
+    typedef unsigned u4_t __attribute__((ext_vector_type(4)));
+    const unsigned from_bytes = from ? (unsigned)((((long)h * w - 1) * ld_from + C) * sizeof(E)) : 0u;
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc(const_cast<E*>(from ? from : cur), 0, (int)from_bytes, 0x00020000);
+    const unsigned row_b = (unsigned)(ld_from * sizeof(E));
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int pix = (int)(i / c8), cc = (int)(i - (long)pix * c8) * 8;
         const V8 xv = *reinterpret_cast<const V8*>(cur + (long)pix * ld_src + cc);
@@ -268,10 +289,11 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(const typename TT::elem*
         const int x1 = vx ? x0 + 1 : x0, y1 = vy ? y0 + 1 : y0;
         const float w00 = wx0 * wy0, w01 = vx ? wx1 * wy0 : 0.f, w10 = vy ? wx0 * wy1 : 0.f,
                     w11 = (vx && vy) ? wx1 * wy1 : 0.f;
-        const V8 a = *reinterpret_cast<const V8*>(from + (long)(y0 * w + x0) * ld_from + cc);
-        const V8 b = *reinterpret_cast<const V8*>(from + (long)(y0 * w + x1) * ld_from + cc);
-        const V8 c = *reinterpret_cast<const V8*>(from + (long)(y1 * w + x0) * ld_from + cc);
-        const V8 d = *reinterpret_cast<const V8*>(from + (long)(y1 * w + x1) * ld_from + cc);
+        const unsigned cb = (unsigned)cc * (unsigned)sizeof(E);
+        const V8 a = __builtin_bit_cast(V8, (u4_t)__builtin_amdgcn_raw_buffer_load_b128(rF, (unsigned)(y0 * w + x0) * row_b + cb, 0, 0));
+        const V8 b = __builtin_bit_cast(V8, (u4_t)__builtin_amdgcn_raw_buffer_load_b128(rF, (unsigned)(y0 * w + x1) * row_b + cb, 0, 0));
+        const V8 c = __builtin_bit_cast(V8, (u4_t)__builtin_amdgcn_raw_buffer_load_b128(rF, (unsigned)(y1 * w + x0) * row_b + cb, 0, 0));
+        const V8 d = __builtin_bit_cast(V8, (u4_t)__builtin_amdgcn_raw_buffer_load_b128(rF, (unsigned)(y1 * w + x1) * row_b + cb, 0, 0));
         V8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -652,22 +674,24 @@ __global__ void vae_sample_kernel(const float* __restrict__ moments, long ldm, c
     else return VF_ERR_DTYPE;
 
 int vf_launch_layernorm(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, int M,
-                        int C, float eps, int dtype, hipStream_t stream) {
+                        int C, float eps, int in_f32, int dtype, hipStream_t stream) {
     if (!x || !gamma || !beta || !y || M <= 0 || C <= 0) return VF_ERR_ARG;
-    if ((C & 7) || (ldx & 7) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VF_ERR_ALIGN;
+    if ((C & 7) || (ldx & (in_f32 ? 3 : 7)) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VF_ERR_ALIGN;
     if (C > 2048) return VF_ERR_SHAPE;
     const int ch8 = (C + 511) / 512;
     dim3 grid((M + 3) / 4);
+#define LN_LAUNCH(CH, IN) hipLaunchKernelGGL((layernorm_kernel<TT, CH, IN>), grid, dim3(256), 0, stream, x, ldx, gamma, beta, yo, ldy, M, C, eps)
     DISPATCH_DTYPE(dtype, {
         using E = typename TT::elem;
-        const E* xi = (const E*)x; E* yo = (E*)y;
+        E* yo = (E*)y;
         switch (ch8) {
-            case 1: hipLaunchKernelGGL((layernorm_kernel<TT, 1>), grid, dim3(256), 0, stream, xi, ldx, gamma, beta, yo, ldy, M, C, eps); break;
-            case 2: hipLaunchKernelGGL((layernorm_kernel<TT, 2>), grid, dim3(256), 0, stream, xi, ldx, gamma, beta, yo, ldy, M, C, eps); break;
-            case 3: hipLaunchKernelGGL((layernorm_kernel<TT, 3>), grid, dim3(256), 0, stream, xi, ldx, gamma, beta, yo, ldy, M, C, eps); break;
-            default: hipLaunchKernelGGL((layernorm_kernel<TT, 4>), grid, dim3(256), 0, stream, xi, ldx, gamma, beta, yo, ldy, M, C, eps); break;
+            case 1: if (in_f32) LN_LAUNCH(1, true); else LN_LAUNCH(1, false); break;
+            case 2: if (in_f32) LN_LAUNCH(2, true); else LN_LAUNCH(2, false); break;
+            case 3: if (in_f32) LN_LAUNCH(3, true); else LN_LAUNCH(3, false); break;
+            default: if (in_f32) LN_LAUNCH(4, true); else LN_LAUNCH(4, false); break;
         }
     });
+#undef LN_LAUNCH
     return ok();
 }
 
@@ -677,15 +701,15 @@ int vf_gn_partial_floats(int nimg, int hw, int C, int groups) {
 }
 
 int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
-                       float* stats, int dtype, hipStream_t stream) {
+                       float* stats, int in_f32, int dtype, hipStream_t stream) {
     if (!x || !partial || !stats || nimg <= 0 || hw <= 0 || C <= 0 || groups <= 0) return VF_ERR_ARG;
-    if ((C & 7) || (ldx & 7) || ((uintptr_t)x & 15)) return VF_ERR_ALIGN;
+    if ((C & 7) || (ldx & (in_f32 ? 3 : 7)) || ((uintptr_t)x & 15)) return VF_ERR_ALIGN;
     if (groups > 64 || C % groups) return VF_ERR_SHAPE;
     const int nchunks = (hw + GN_PIX - 1) / GN_PIX;
     dim3 grid(nchunks, nimg);
     DISPATCH_DTYPE(dtype, {
-        using E = typename TT::elem;
-        hipLaunchKernelGGL((gn_partial_kernel<TT>), grid, dim3(256), (size_t)(2 * C + 256 * 16) * sizeof(float), stream, (const E*)x, ldx, hw, C, groups, partial);
+        if (in_f32) hipLaunchKernelGGL((gn_partial_kernel<TT, true>), grid, dim3(256), (size_t)(2 * C + 256 * 16) * sizeof(float), stream, x, ldx, hw, C, groups, partial);
+        else hipLaunchKernelGGL((gn_partial_kernel<TT, false>), grid, dim3(256), (size_t)(2 * C + 256 * 16) * sizeof(float), stream, x, ldx, hw, C, groups, partial);
     });
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg), dim3(64), 0, stream, (const float*)partial, nchunks, groups,
                        (double)hw * (C / groups), eps, stats);
@@ -693,9 +717,9 @@ int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int gro
 }
 
 int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y,
-                       long ldy, int nimg, int hw, int C, int groups, int silu, int dtype, hipStream_t stream) {
+                       long ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype, hipStream_t stream) {
     if (!x || !stats || !gamma || !beta || !y || nimg <= 0 || hw <= 0) return VF_ERR_ARG;
-    if ((C & 7) || (ldx & 7) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VF_ERR_ALIGN;
+    if ((C & 7) || (ldx & (in_f32 ? 3 : 7)) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VF_ERR_ALIGN;
     if (groups > 64 || C % groups) return VF_ERR_SHAPE;
     // enough workgroups to fill 256 CUs several times over, but long enough pixel loops to amortise the
     // per-thread scale/shift set-up
@@ -704,8 +728,8 @@ int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float*
     dim3 grid((hw + ppb - 1) / ppb, nimg);
     DISPATCH_DTYPE(dtype, {
         using E = typename TT::elem;
-        hipLaunchKernelGGL((gn_apply_kernel<TT>), grid, dim3(256), 0, stream, (const E*)x, ldx, stats,
-                           gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
+        if (in_f32) hipLaunchKernelGGL((gn_apply_kernel<TT, true>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
+        else hipLaunchKernelGGL((gn_apply_kernel<TT, false>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
     });
     return ok();
 }
@@ -720,6 +744,8 @@ int vf_launch_flow_warp(const void* src, long ld_src, long fs_src, const void* p
     if ((C & 7) || (ld_src & 7) || (ld_dst & 7) || (fs_src & 7) || (fs_dst & 7) || (prev && (ld_prev & 7))) return VF_ERR_ALIGN;
     if (((uintptr_t)src | (uintptr_t)dst | (uintptr_t)prev) & 15) return VF_ERR_ALIGN;
     if ((dbg_x0 == nullptr) != (dbg_y0 == nullptr)) return VF_ERR_ARG;
+    // one source frame is addressed through a buffer descriptor with 32-bit byte offsets
+    if ((((long)h * w - 1) * (ld_src > ld_prev ? ld_src : ld_prev) + C) * 2 >= 0xFFFFFFF0l) return VF_ERR_SHAPE;
     const long total = (long)h * w * (C / 8);
     dim3 grid(grid_for(total, 256, 2048), F);
     DISPATCH_DTYPE(dtype, {

@@ -28,8 +28,13 @@ struct GemmParams {
     int ld_rowbias;
     const void* residual;  // [M][ldr] or null
     long ldr;
-    void* C;  // [M][ldc]
+    void* C;  // [M][ldc] 16-bit (or fp32 with GEMM_OUT_F32); may be null when C32 is given
     long ldc;
+    // fp32 residual stream: `residual` is fp32 [M][ldr] when res_f32; C32 (optional) receives the fp32 sum
+    // bias + rowbias + residual + acc BEFORE the rounding to 16 bits -- the carrier the next residual add / norm reads
+    int res_f32;
+    float* C32;
+    long ldc32;
     const void* zeros;  // >= 16 zero bytes, 16-B aligned
     int flags;
     unsigned a_bytes, a2_bytes, w_bytes;  // filled by the launcher: extents of the operand views
@@ -42,6 +47,7 @@ struct GemmParams {
     int split_k, kt_per_split;  // filled by the launcher
 };
 long vf_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_sample);
+bool vf_gemm_variants_built();
 int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 bool vf_attention_shared_scores_supported(int dh, int v_sets);
 int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream);
@@ -62,15 +68,16 @@ struct AttnParams {
 };
 int vf_launch_attention(const AttnParams& p, int dtype, hipStream_t stream);
 
+// in_f32: x is the fp32 residual-stream copy (ldx in floats)
 int vf_launch_layernorm(const void* x, long ldx, const float* gamma, const float* beta, void* y, long ldy, int M,
-                        int C, float eps, int dtype, hipStream_t stream);
+                        int C, float eps, int in_f32, int dtype, hipStream_t stream);
 int vf_launch_gn_finalize_cols(const float* colstats, long ld, int nimg, int hw, int C, int groups, float eps, float* stats,
                                hipStream_t stream);
 int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
-                       float* stats, int dtype, hipStream_t stream);
+                       float* stats, int in_f32, int dtype, hipStream_t stream);
 int vf_gn_partial_floats(int nimg, int hw, int C, int groups);
 int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y,
-                       long ldy, int nimg, int hw, int C, int groups, int silu, int dtype, hipStream_t stream);
+                       long ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype, hipStream_t stream);
 int vf_launch_flow_warp(const void* src, long ld_src, long fs_src, const void* prev, long ld_prev,
                         const float* flow, const float* flow_prev, void* dst, long ld_dst, long fs_dst, int F, int h,
                         int w, int C, float alpha, float one_minus_alpha, int flags, int* dbg_x0, int* dbg_y0, int dtype,

@@ -43,16 +43,27 @@ class HookCfg:
 class Act:
     """A 2-D view ``[rows, C]`` (stride ``(ld, 1)``) of a 16-bit device buffer, with its image geometry and,
     when its producer emitted them, the per-64-row-slice column statistics ``cs`` ``[rows/64, C, 2]`` (fp32 view)
-    from which a following GroupNorm takes mean / rstd without re-reading the tensor."""
-    __slots__ = ("t", "N", "H", "W", "cs")
+    from which a following GroupNorm takes mean / rstd without re-reading the tensor.
 
-    def __init__(self, t: torch.Tensor, N: int, H: int, W: int, cs: Optional[torch.Tensor] = None):
-        assert t.dim() == 2 and t.stride(1) == 1
-        self.t, self.N, self.H, self.W, self.cs = t, N, H, W, cs
+    ``t32`` (optional) is the same activation as the fp32 residual-stream carrier: the un-rounded sum its producer's
+    epilogue formed.  Residual adds and normalisations read it; only matrix-core operands read the 16-bit ``t``,
+    which may then be absent (None) when no consumer needs it."""
+    __slots__ = ("t", "N", "H", "W", "cs", "t32")
+
+    def __init__(self, t: Optional[torch.Tensor], N: int, H: int, W: int, cs: Optional[torch.Tensor] = None,
+                 t32: Optional[torch.Tensor] = None):
+        for v in (t, t32):
+            assert v is None or (v.dim() == 2 and v.stride(1) == 1)
+        assert t is not None or t32 is not None
+        self.t, self.N, self.H, self.W, self.cs, self.t32 = t, N, H, W, cs, t32
+
+    @property
+    def any(self):
+        return self.t if self.t is not None else self.t32
 
     @property
     def C(self):
-        return self.t.shape[1]
+        return self.any.shape[1]
 
     @property
     def ld(self):
@@ -60,7 +71,12 @@ class Act:
 
     @property
     def M(self):
-        return self.t.shape[0]
+        return self.any.shape[0]
+
+    @property
+    def src(self):
+        """What a normalisation reads: the fp32 carrier when there is one."""
+        return self.t32 if self.t32 is not None else self.t
 
     @property
     def hw(self):
@@ -114,7 +130,8 @@ def plan_fusion(cfg: Optional[HookCfg], N: int, n: int) -> dict:
     return pl
 
 
-def staged_attn1(x16: torch.Tensor, wqkv, wo, bo, out, *, B, n, d, heads, mode, rowbias=None, residual=None):
+def staged_attn1(x16: torch.Tensor, wqkv, wo, bo, out, *, B, n, d, heads, mode, rowbias=None, residual=None,
+                 residual32=None, out32=None):
     """Hooked attn1 for fusion modes that edit q,k with their own kernels ("temporal", "adaIn"; pnp_utils.py:145-160):
     full projection -> edit chunk 1 / chunk 2 q,k in the qkv buffer -> attention -> out-projection."""
     dev, dt = x16.device, x16.dtype
@@ -135,9 +152,11 @@ def staged_attn1(x16: torch.Tensor, wqkv, wo, bo, out, *, B, n, d, heads, mode, 
     att = torch.empty(B * n, d, dtype=dt, device=dev)
     hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=B, heads=heads, n=n, nk=n, dh=d // heads, ldq=3 * d, ldk=3 * d,
                   ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d, ldo=d, bso=n * d, scale=(d // heads) ** -0.5)
-    hip.gemm(att, wo, out, M=B * n, N=out.shape[1], K=d, lda=d, ldc=out.stride(0), bias=bo, rowbias=rowbias,
-             rows_per_sample=n, residual=residual, ldr=residual.stride(0) if residual is not None else 0)
-    return out
+    o = out if out is not None else out32
+    hip.gemm(att, wo, out, M=B * n, N=o.shape[1], K=d, lda=d, ldc=out.stride(0) if out is not None else 0, bias=bo,
+             rowbias=rowbias, rows_per_sample=n, residual=residual, ldr=residual.stride(0) if residual is not None else 0,
+             residual32=residual32, out32=out32)
+    return o
 
 
 COMPUTE_DTYPE = torch.float16  # module-level default for standalone module calls
@@ -225,6 +244,9 @@ class UNetEngine:
         # multi-GPU: a parallel.FrameShard (start_exchange / finish_exchange), installed by FrameShard.install
         self.halo_exchange = None
         self.halo_flow: Optional[torch.Tensor] = None  # flow from the previous rank's last frame into our frame 0
+        # fp32 residual stream: residual sums are carried between kernels in fp32, 16-bit copies exist only
+        # where a matrix-core operand needs them.  VFACE_STREAM32=0 restores the all-16-bit activations (A/B switch).
+        self.stream32 = os.environ.get("VFACE_STREAM32", "1") != "0"
         hip.load()
 
     # ------------------------------------------------------------------ weights
@@ -344,100 +366,131 @@ class UNetEngine:
     def _new(self, rows: int, cols: int, dtype=None) -> torch.Tensor:
         return torch.empty(rows, cols, dtype=dtype or self.dtype, device=self.device)
 
-    def _new_target(self, rows: int, cols: int, hw: int):
-        """A fresh output buffer and, when the image size allows (hw % 64 == 0), its column-statistics buffer."""
-        return self._new(rows, cols), self._new_cs(rows, cols, hw)
+    def _new_target(self, rows: int, cols: int, hw: int, need16: bool = True):
+        """A fresh output ``(16-bit buffer | None, column statistics | None, fp32 carrier | None)``: statistics when the
+        image size allows (hw % 64 == 0); the carrier when the fp32 residual stream is on (and then the 16-bit copy only
+        if a matrix-core operand will read it)."""
+        s32 = self.stream32 and cols % 8 == 0
+        return (self._new(rows, cols) if (need16 or not s32) else None, self._new_cs(rows, cols, hw),
+                self._new(rows, cols, torch.float32) if s32 else None)
 
     def _new_cs(self, rows: int, cols: int, hw: int) -> Optional[torch.Tensor]:
         if hw % 64 or cols % 4:
             return None
         return torch.empty(rows // 64, cols, 2, dtype=torch.float32, device=self.device)
 
-    def _gemm(self, a: torch.Tensor, w: dict, out: torch.Tensor, hw: int = 0, **kw):
+    def _gemm(self, a: torch.Tensor, w: dict, out: Optional[torch.Tensor], hw: int = 0, **kw):
         K = a.shape[1]
         if hw > 1 and "rowbias" not in kw:
             kw["rows_per_sample"] = hw   # split-K decided per sample: a frame's bits do not depend on its batch
-        hip.gemm(a, w["w"], out, M=a.shape[0], N=w["w"].shape[0], K=K, lda=a.stride(0), ldc=out.stride(0),
-                 ldw=w["w"].shape[1], bias=w.get("b"), **kw)
+        hip.gemm(a, w["w"], out, M=a.shape[0], N=w["w"].shape[0], K=K, lda=a.stride(0),
+                 ldc=out.stride(0) if out is not None else 0, ldw=w["w"].shape[1], bias=w.get("b"), **kw)
+
+    @staticmethod
+    def _resid(x) -> dict:
+        """Residual operand of an epilogue: the fp32 carrier when the tensor has one."""
+        if isinstance(x, Act):
+            if x.t32 is not None:
+                return {"residual32": x.t32}
+            return {"residual": x.t, "ldr": x.t.stride(0)}
+        if x.dtype == torch.float32:
+            return {"residual32": x}
+        return {"residual": x, "ldr": x.stride(0)}
 
     def _gn(self, x: Act, gn, eps: float, silu: bool) -> Act:
+        src = x.src
         if x.cs is not None:
             st = hip.groupnorm_stats_from_cols(x.cs, nimg=x.N, hw=x.hw, C_=x.C, eps=eps)
         else:
-            st = hip.groupnorm_stats(x.t, nimg=x.N, hw=x.hw, C_=x.C, ldx=x.ld, eps=eps)
+            st = hip.groupnorm_stats(src, nimg=x.N, hw=x.hw, C_=x.C, ldx=src.stride(0), eps=eps)
         y = self._new(x.M, x.C)
-        hip.groupnorm_apply(x.t, st, gn[0], gn[1], y, nimg=x.N, hw=x.hw, C_=x.C, ldx=x.ld, ldy=x.C, silu=silu)
+        hip.groupnorm_apply(src, st, gn[0], gn[1], y, nimg=x.N, hw=x.hw, C_=x.C, ldx=src.stride(0), ldy=x.C, silu=silu)
         return Act(y, x.N, x.H, x.W)
 
-    def _conv(self, x: Act, w: dict, tgt, stride=1, upsample=False, rowbias=None,
-              residual: Optional[torch.Tensor] = None, out_f32=False) -> Act:
-        """``tgt``: None (allocate) or ``(out view, colstats view or None)``."""
+    def _conv(self, x: Act, w: dict, tgt, stride=1, upsample=False, rowbias=None, residual=None, out_f32=False,
+              stream=True) -> Act:
+        """``tgt``: None (allocate) or ``(16-bit out view | None, colstats view | None, fp32 carrier view | None)``.
+        ``residual``: an ``Act`` / tensor added in the epilogue.  ``stream=False``: a branch activation (consumed by one
+        GEMM / GroupNorm only): 16-bit output, no fp32 carrier."""
         VH, VW = (2 * x.H, 2 * x.W) if upsample else (x.H, x.W)
         OH, OW = (VH - 1) // stride + 1, (VW - 1) // stride + 1
         if tgt is None:
             if out_f32:
-                out, cs = self._new(x.N * OH * OW, w["cout"], torch.float32), None
+                out, cs, o32 = self._new(x.N * OH * OW, w["cout"], torch.float32), None, None
+            elif not stream:
+                out, cs, o32 = self._new(x.N * OH * OW, w["cout"]), self._new_cs(x.N * OH * OW, w["cout"], OH * OW), None
             else:
-                out, cs = self._new_target(x.N * OH * OW, w["cout"], OH * OW)
+                out, cs, o32 = self._new_target(x.N * OH * OW, w["cout"], OH * OW)
         else:
-            out, cs = tgt
+            out, cs, o32 = tgt
         assert x.C == w["cinp"], (x.C, w["cinp"])
+        ldy = out.stride(0) if out is not None else 0
         if upsample and "phases" in w and _phase_form_pays(x.H * x.W, w["cout"]) and residual is None and not out_f32 \
                 and (cs is None or (x.H * x.W) % 64 == 0):
             hip.upsample2x_conv3x3(x.t, w["phases"], out, nimg=x.N, H=x.H, W=x.W, cin=w["cinp"], cout=w["cout"], ldx=x.ld,
-                                   ldy=out.stride(0), bias=w["b"], rowbias=rowbias, colstats=cs)
-            return Act(out, x.N, OH, OW, cs)
+                                   ldy=ldy, bias=w["b"], rowbias=rowbias, colstats=cs, out32=o32)
+            return Act(out, x.N, OH, OW, cs, o32)
         hip.conv3x3(x.t, w["w"], out, nimg=x.N, H=x.H, W=x.W, cin=w["cinp"], cout=w["cout"], ldx=x.ld,
-                    ldy=out.stride(0), stride=stride, upsample=upsample, bias=w["b"], rowbias=rowbias,
-                    residual=residual, ldr=residual.stride(0) if residual is not None else 0,
-                    flags=hip.EPI_OUT_F32 if out_f32 else 0, colstats=cs)
-        return Act(out, x.N, OH, OW, cs)
+                    ldy=ldy, stride=stride, upsample=upsample, bias=w["b"], rowbias=rowbias,
+                    flags=hip.EPI_OUT_F32 if out_f32 else 0, colstats=cs, out32=o32,
+                    **(self._resid(residual) if residual is not None else {}))
+        return Act(out, x.N, OH, OW, cs, o32)
 
     def _res(self, x: Act, p: dict, emb_all: torch.Tensor, out) -> Act:
         """ResBlock._forward (openaimodel.py:255-275), non-updown, no scale-shift."""
         h = self._gn(x, p["in_gn"], 1e-5, True)
         a, b = p["emb_slice"]
-        h = self._conv(h, p["conv1"], None, rowbias=emb_all[:, a:b])
+        h = self._conv(h, p["conv1"], None, rowbias=emb_all[:, a:b], stream=False)
         h = self._gn(h, p["out_gn"], 1e-5, True)
         if "conv2_skip" in p and os.environ.get("VFACE_NO_SKIP_FUSION") != "1":   # (env: A/B switch for measurements)
             w = p["conv2_skip"]
-            o, cs = self._new_target(x.M, w["cout"], x.hw) if out is None else out
+            o, cs, o32 = self._new_target(x.M, w["cout"], x.hw) if out is None else out
             hip.conv3x3_plus_1x1(h.t, x.t, w["w"], o, nimg=x.N, H=x.H, W=x.W, cin=w["cinp"], c2=w["c2"], cout=w["cout"],
-                                 ldx=h.ld, ldx2=x.ld, ldy=o.stride(0), bias=w["b"], colstats=cs)
-            return Act(o, x.N, x.H, x.W, cs)
+                                 ldx=h.ld, ldx2=x.ld, ldy=o.stride(0) if o is not None else 0, bias=w["b"], colstats=cs,
+                                 out32=o32)
+            return Act(o, x.N, x.H, x.W, cs, o32)
         if "skip" in p:
-            skip = self._new(x.M, p["conv2"]["cout"])
-            self._gemm(x.t, p["skip"], skip, hw=x.H * x.W)
+            if self.stream32 and p["conv2"]["cout"] % 8 == 0:
+                skip = self._new(x.M, p["conv2"]["cout"], torch.float32)
+                self._gemm(x.t, p["skip"], None, hw=x.H * x.W, out32=skip)
+            else:
+                skip = self._new(x.M, p["conv2"]["cout"])
+                self._gemm(x.t, p["skip"], skip, hw=x.H * x.W)
         else:
-            skip = x.t
+            skip = x
         return self._conv(h, p["conv2"], out, residual=skip)
 
     def _attn1(self, xln: torch.Tensor, resid: torch.Tensor, p: dict, cfg: Optional[HookCfg], a2vec: torch.Tensor,
                N: int, n: int, heads: int, hw) -> torch.Tensor:
+        """``resid`` 16-bit -> 16-bit result; ``resid`` fp32 (the residual stream) -> fp32 result, no 16-bit copy."""
         d = p["c"]
-        out = self._new(N * n, d)
+        s32 = resid.dtype == torch.float32
+        out = None if s32 else self._new(N * n, d)
+        out32 = self._new(N * n, d, torch.float32) if s32 else None
+        res_kw = {"residual32": resid, "out32": out32} if s32 else {"residual": resid, "ldr": resid.stride(0)}
         pl = plan_fusion(cfg, N, n)
         if pl["staged"]:
             if self.halo_exchange is not None:
                 raise NotImplementedError(f"fusion={pl['staged']!r} couples frames beyond one neighbour (temporal: +-2 "
                                           "frames; adaIn: a global std) and is not sharded across GPUs")
+            kw = {"residual32": resid, "out32": out32} if s32 else {"residual": resid}
             return staged_attn1(xln, p["wqkv"], p["wo"]["w"], p["wo"]["b"], out, B=N, n=n, d=d, heads=heads,
-                                mode=pl["staged"], rowbias=a2vec, residual=resid)
+                                mode=pl["staged"], rowbias=a2vec, **kw)
         fusion, chunks, flow, alpha, v_fixed = pl["fusion"], pl["chunks"], pl["flow"], pl["alpha"], pl["v_fixed"]
         wlin = self._wlin(p, *pl["wlin"]) if pl["wlin"] else None
         qk_map = self._map("qk_replace", N, N // chunks) if fusion == hip.FUSION_REPLACE else None
         v_map = self._map("v_fixed", N, N // chunks) if v_fixed else None
         ws = torch.empty(hip.attn1_workspace_bytes(N, n, d, chunks), dtype=torch.uint8, device=self.device)
         if flow is not None and self.halo_exchange is not None:
-            return self._attn1_sharded(xln, resid, p, wlin, a2vec, N, n, heads, flow, alpha, out)
+            return self._attn1_sharded(xln, res_kw, p, wlin, a2vec, N, n, heads, flow, alpha, out)
         hip.attn1_forward(xln, p["wqkv"], wlin, p["wo"]["w"], p["wo"]["b"], out, B=N, n=n, d=d, heads=heads,
                           chunks=chunks, fusion=fusion, ldx=xln.stride(0), ldo=d, workspace=ws,
-                          rowbias=a2vec, residual=resid, ldr=resid.stride(0), v_fixed=v_fixed, flow=flow,
+                          rowbias=a2vec, v_fixed=v_fixed, flow=flow,
                           h=flow.shape[-2] if flow is not None else 0, w=flow.shape[-1] if flow is not None else 0,
-                          alpha=alpha, qk_map=qk_map, v_map=v_map)
-        return out
+                          alpha=alpha, qk_map=qk_map, v_map=v_map, **res_kw)
+        return out32 if s32 else out
 
-    def _attn1_sharded(self, xln, resid, p, wlin, a2vec, N, n, heads, flow, alpha, out):
+    def _attn1_sharded(self, xln, res_kw, p, wlin, a2vec, N, n, heads, flow, alpha, out):
         """flow_fix with frames sharded across ranks: the same kernels as vface_attn1_forward, sequenced here
         so the one-neighbour boundary exchange sits between the fused projection and the warp."""
         d = p["c"]
@@ -466,15 +519,21 @@ class UNetEngine:
                       ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d, ldo=d, bso=n * d,
                       scale=(d // heads) ** -0.5)
         hip.gemm(att, p["wo"]["w"], out, M=N * n, N=d, K=d, lda=d, ldc=d, bias=p["wo"]["b"], rowbias=a2vec,
-                 rows_per_sample=n, residual=resid, ldr=resid.stride(0))
-        return out
+                 rows_per_sample=n, **res_kw)
+        return res_kw.get("out32") if out is None else out
 
     def _st(self, x: Act, p: dict, mod, a2_all: torch.Tensor, tgt) -> Act:
-        """SpatialTransformer.forward + BasicTransformerBlock._forward (attention.py:278-289, 239-243)."""
+        """SpatialTransformer.forward + BasicTransformerBlock._forward (attention.py:278-289, 239-243).
+        With the fp32 residual stream the block's running sum (``x`` after proj_in, after attn1 + attn2) exists in fp32
+        only -- LayerNorm and the next residual add read that; its last value feeds proj_out as a 16-bit operand."""
         N, n, c = x.N, x.hw, p["c"]
+        s32 = self.stream32 and c % 8 == 0
         g = self._gn(x, p["gn"], 1e-6, False)
-        t0 = self._new(x.M, c)
-        self._gemm(g.t, p["proj_in"], t0, hw=x.H * x.W)
+        t0 = self._new(x.M, c, torch.float32 if s32 else None)
+        if s32:
+            self._gemm(g.t, p["proj_in"], None, hw=x.H * x.W, out32=t0)
+        else:
+            self._gemm(g.t, p["proj_in"], t0, hw=x.H * x.W)
         ln = self._new(x.M, c)
         hip.layernorm(t0, p["ln1"][0], p["ln1"][1], ln, M=x.M, C_=c, ldx=c, ldy=c)
         a, b = p["a2_slice"]
@@ -489,10 +548,10 @@ class UNetEngine:
         ff = self._new(x.M, 4 * c)
         hip.gemm(ln, p["ff1"]["w"], ff, M=x.M, N=8 * c, K=c, lda=c, ldc=4 * c, bias=p["ff1"]["b"], flags=hip.EPI_GEGLU)
         t2 = self._new(x.M, c)
-        self._gemm(ff, p["ff2"], t2, residual=t1, ldr=c, hw=x.H * x.W)
-        out, cs = self._new_target(x.M, c, x.hw) if tgt is None else tgt
-        self._gemm(t2, p["proj_out"], out, residual=x.t, ldr=x.ld, colstats=cs, hw=x.H * x.W)
-        return Act(out, x.N, x.H, x.W, cs)
+        self._gemm(ff, p["ff2"], t2, hw=x.H * x.W, **self._resid(t1))
+        out, cs, o32 = self._new_target(x.M, c, x.hw) if tgt is None else tgt
+        self._gemm(t2, p["proj_out"], out, colstats=cs, hw=x.H * x.W, out32=o32, **self._resid(x))
+        return Act(out, x.N, x.H, x.W, cs, o32)
 
     # ------------------------------------------------------------------ the forward
     def embeddings(self, timesteps: torch.Tensor, context: torch.Tensor):
@@ -540,9 +599,16 @@ class UNetEngine:
         emb_all, a2_all = self.embeddings(timesteps, context)
         blocks_in, mid, blocks_out = u.block_table()
 
-        def run(block, h: Act, out: Optional[torch.Tensor]) -> Act:
+        def run(block, h: Act, out) -> Act:
             for i, (kind, prefix, mod) in enumerate(block):
-                tgt = out if i == len(block) - 1 else None
+                last = i == len(block) - 1
+                tgt = out if last else None
+                if tgt is None and kind in ("res", "st"):
+                    # inside a block: the 16-bit copy exists only if the next layer reads it as a matrix-core operand
+                    # (a down / up convolution); a SpatialTransformer reads the fp32 carrier only
+                    need16 = last or block[i + 1][0] != "st"
+                    co = P[prefix]["conv2"]["cout"] if kind == "res" else P[prefix]["c"]
+                    tgt = self._new_target(h.M, co, h.hw, need16=need16)
                 if kind == "conv":
                     h = self._conv(h, P[prefix], tgt)
                 elif kind == "res":
@@ -565,16 +631,17 @@ class UNetEngine:
             shapes.append((H, W, u.block_out_channels(block)))
         nb = len(blocks_in)
         h_ch = [u.block_out_channels(mid)] + [u.block_out_channels(b) for b in blocks_out[:-1]]
-        cats, cats_cs = [], []
+        cats, cats_cs, cats32 = [], [], []
         for j in range(nb):  # output block j consumes cat([h_{j}, skip_{nb-1-j}])
             sh, sw, sc = shapes[nb - 1 - j]
-            buf, cs = self._new_target(x.N * sh * sw, h_ch[j] + sc, sh * sw)
+            buf, cs, b32 = self._new_target(x.N * sh * sw, h_ch[j] + sc, sh * sw)
             cats.append(buf)
             cats_cs.append(cs)
+            cats32.append(b32)
 
-        def part(j, a, b):  # columns [a, b) of concat buffer j and of its statistics
-            cs = cats_cs[j]
-            return cats[j][:, a:b], (cs[:, a:b] if cs is not None else None)
+        def part(j, a, b):  # columns [a, b) of concat buffer j, of its statistics and of its fp32 carrier
+            cs, b32 = cats_cs[j], cats32[j]
+            return cats[j][:, a:b], (cs[:, a:b] if cs is not None else None), (b32[:, a:b] if b32 is not None else None)
 
         h = x
         for i, block in enumerate(blocks_in):
@@ -583,7 +650,7 @@ class UNetEngine:
         h = run(mid, h, part(0, 0, h_ch[0]))
         for j, block in enumerate(blocks_out):
             sh, sw, _ = shapes[nb - 1 - j]
-            inp = Act(cats[j], x.N, sh, sw, cats_cs[j])
+            inp = Act(cats[j], x.N, sh, sw, cats_cs[j], cats32[j])
             tgt = part(j + 1, 0, h_ch[j + 1]) if j + 1 < nb else None
             h = run(block, inp, tgt)
         h = self._gn(h, P["out.gn"], 1e-5, True)

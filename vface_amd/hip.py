@@ -23,33 +23,42 @@ FUSION_NONE, FUSION_REPLACE, FUSION_LINEAR = 0, 1, 2
 
 _i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
 
+
+class Stream32(C.Structure):
+    """``vface_stream32`` of the header: the optional fp32 residual-stream operands of a GEMM-family call."""
+    _fields_ = [("residual32", _vp), ("ldr32", _i64), ("out32", _vp), ("ldo32", _i64)]
+
+
+_s32p = C.POINTER(Stream32)
+
 # name -> (restype, argtypes); mirrors include/vface_hip.h one to one
 SIGNATURES = {
     "vface_abi_version": (C.c_int, []),
     "vface_error_string": (C.c_char_p, [_i32]),
+    "vface_gemm_variants_built": (C.c_int, []),
     "vface_gemm": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp,
-                             _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
+                             _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _s32p]),
     "vface_conv3x3": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp,
-                                _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
+                                _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _s32p]),
     "vface_splitk_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
     "vface_conv3x3_plus_1x1": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i32,
-                                         _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
+                                         _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _s32p]),
     "vface_upsample2x_conv3x3_phase": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32,
-                                                 _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp]),
+                                                 _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _s32p]),
     "vface_groupnorm_finalize_cols": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp]),
     "vface_attention": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _i32,
                                   _i32, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _vp]),
     "vface_attention_shared_scores_supported": (C.c_int, [_i32, _i32]),
-    "vface_layernorm": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _vp]),
+    "vface_layernorm": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _vp]),
     "vface_groupnorm_partial_floats": (C.c_int, [_i32, _i32, _i32, _i32]),
-    "vface_groupnorm_stats": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _vp]),
-    "vface_groupnorm_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vface_groupnorm_stats": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _i32, _vp]),
+    "vface_groupnorm_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vface_flow_warp": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                                   _f32, _i32, _vp, _vp, _i32, _vp]),
     "vface_attn1_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "vface_attn1_forward": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32,
                                       _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp,
-                                      _vp, _vp, _sz, _vp, _i32, _vp]),
+                                      _vp, _vp, _sz, _vp, _i32, _vp, _s32p]),
     "vface_temporal_gauss": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "vface_adain_workspace_bytes": (_sz, [_i64, _i32]),
     "vface_adain_fusion": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _sz, _i32, _vp]),
@@ -87,7 +96,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.vface_abi_version() != 2:
+    if lib.vface_abi_version() != 3:
         raise VFaceHipError("libvface_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -117,6 +126,18 @@ def _p(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+def _s32(residual32: Optional[torch.Tensor], out32: Optional[torch.Tensor]):
+    """The ``vface_stream32`` argument: fp32 residual operand and / or fp32 copy of the output (2-D views, unit column
+    stride); None when neither is given."""
+    if residual32 is None and out32 is None:
+        return None
+    for t in (residual32, out32):
+        if t is not None and (t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1):
+            raise VFaceHipError("fp32 residual-stream tensors must be 2-D fp32 views with unit column stride")
+    return C.byref(Stream32(_p(residual32), residual32.stride(0) if residual32 is not None else 0,
+                            _p(out32), out32.stride(0) if out32 is not None else 0))
 
 
 _zeros = {}
@@ -150,20 +171,23 @@ def splitk_workspace(device, M: int, N: int, K: int, flags: int = 0, rows_per_sa
 # ---------------------------------------------------------------------------------------------- wrappers
 def gemm(a: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldc: int,
          ldw: Optional[int] = None, bias=None, rowbias=None, rows_per_sample: int = 1, residual=None, ldr: int = 0,
-         a2=None, lda2: int = 0, k1: int = 0, a2_row_mod: int = 0, flags: int = 0, colstats=None, split_k: bool = True):
-    """out[M, :N] = a[M, :K] @ wt[:N, :K]^T (+ epilogue).  Tensors are device buffers; M/N/K/ld* describe the view."""
+         a2=None, lda2: int = 0, k1: int = 0, a2_row_mod: int = 0, flags: int = 0, colstats=None, split_k: bool = True,
+         residual32=None, out32=None):
+    """out[M, :N] = a[M, :K] @ wt[:N, :K]^T (+ epilogue).  Tensors are device buffers; M/N/K/ld* describe the view.
+    ``residual32`` / ``out32``: the fp32 residual stream (``vface_stream32``); ``out`` may be None with ``out32``."""
     lib = load()
     ws, ws_bytes = splitk_workspace(a.device, M, N, K, flags, rows_per_sample) if split_k else (None, 0)
     rc = lib.vface_gemm(_p(a), lda, _p(a2), lda2, k1, a2_row_mod, _p(wt), ldw if ldw is not None else K, M, N, K,
                         _p(bias), _p(rowbias), rows_per_sample, rowbias.stride(0) if rowbias is not None else 0,
                         _p(residual), ldr, _p(out), ldc, _p(zeros_page(a.device)), flags, dtype_code(a.dtype),
-                        _p(colstats), colstats.stride(0) // 2 if colstats is not None else 0, _p(ws), ws_bytes, _stream())
+                        _p(colstats), colstats.stride(0) // 2 if colstats is not None else 0, _p(ws), ws_bytes, _stream(),
+                        _s32(residual32, out32))
     _check(rc, "vface_gemm")
 
 
 def conv3x3(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, H: int, W: int, cin: int, cout: int,
             ldx: int, ldy: int, stride: int = 1, upsample: bool = False, bias=None, rowbias=None, residual=None,
-            ldr: int = 0, flags: int = 0, colstats=None, split_k: bool = True):
+            ldr: int = 0, flags: int = 0, colstats=None, split_k: bool = True, residual32=None, out32=None):
     lib = load()
     vh, vw = (2 * H, 2 * W) if upsample else (H, W)
     M = nimg * ((vh - 1) // stride + 1) * ((vw - 1) // stride + 1)
@@ -171,7 +195,8 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, 
     rc = lib.vface_conv3x3(_p(x), ldx, nimg, H, W, cin, _p(wt), 9 * cin, cout, stride, int(upsample), _p(bias),
                            _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, _p(residual), ldr, _p(out),
                            ldy, _p(zeros_page(x.device)), flags, dtype_code(x.dtype), _p(colstats),
-                           colstats.stride(0) // 2 if colstats is not None else 0, _p(ws), ws_bytes, _stream())
+                           colstats.stride(0) // 2 if colstats is not None else 0, _p(ws), ws_bytes, _stream(),
+                           _s32(residual32, out32))
     _check(rc, "vface_conv3x3")
 
 
@@ -189,8 +214,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, *, M: int, C_: int,
               ldx: int, ldy: int, eps: float = 1e-5):
-    rc = load().vface_layernorm(_p(x), ldx, _p(gamma), _p(beta), _p(out), ldy, M, C_, eps, dtype_code(x.dtype),
-                                _stream())
+    rc = load().vface_layernorm(_p(x), ldx, _p(gamma), _p(beta), _p(out), ldy, M, C_, eps,
+                                int(x.dtype == torch.float32), dtype_code(out.dtype), _stream())
     _check(rc, "vface_layernorm")
 
 
@@ -199,8 +224,9 @@ def groupnorm_stats(x: torch.Tensor, *, nimg: int, hw: int, C_: int, ldx: int, g
     nf = lib.vface_groupnorm_partial_floats(nimg, hw, C_, groups)
     partial = torch.empty(nf, dtype=torch.float32, device=x.device)
     stats = torch.empty(nimg, groups, 2, dtype=torch.float32, device=x.device)
-    rc = lib.vface_groupnorm_stats(_p(x), ldx, nimg, hw, C_, groups, eps, _p(partial), _p(stats),
-                                   dtype_code(x.dtype), _stream())
+    in32 = x.dtype == torch.float32
+    rc = lib.vface_groupnorm_stats(_p(x), ldx, nimg, hw, C_, groups, eps, _p(partial), _p(stats), int(in32),
+                                   F16 if in32 else dtype_code(x.dtype), _stream())
     _check(rc, "vface_groupnorm_stats")
     return stats
 
@@ -217,7 +243,7 @@ def groupnorm_stats_from_cols(colstats: torch.Tensor, *, nimg: int, hw: int, C_:
 def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor,
                     *, nimg: int, hw: int, C_: int, ldx: int, ldy: int, groups: int = 32, silu: bool = False):
     rc = load().vface_groupnorm_apply(_p(x), ldx, _p(stats), _p(gamma), _p(beta), _p(out), ldy, nimg, hw, C_, groups,
-                                      int(silu), dtype_code(x.dtype), _stream())
+                                      int(silu), int(x.dtype == torch.float32), dtype_code(out.dtype), _stream())
     _check(rc, "vface_groupnorm_apply")
 
 
@@ -237,13 +263,13 @@ def attn1_workspace_bytes(B: int, n: int, d: int, chunks: int) -> int:
 
 def attn1_forward(x, wqkv, wlin, wo, bo, out, *, B, n, d, heads, chunks, fusion, ldx, ldo, workspace, rowbias=None,
                   residual=None, ldr=0, v_fixed=False, flow=None, h=0, w=0, alpha=0.8, cuda_recip_div=False,
-                  halo_qk=None, halo_flow=None, tail_qk=None, qk_map=None, v_map=None):
+                  halo_qk=None, halo_flow=None, tail_qk=None, qk_map=None, v_map=None, residual32=None, out32=None):
     rc = load().vface_attn1_forward(_p(x), ldx, _p(wqkv), _p(wlin), _p(wo), _p(bo), _p(rowbias),
                                     rowbias.stride(0) if rowbias is not None else 0, _p(residual), ldr, _p(out), ldo,
                                     B, n, d, heads, chunks, fusion, int(v_fixed), _p(flow), h, w, float(alpha),
                                     float(1.0 - alpha), int(cuda_recip_div), _p(halo_qk), _p(halo_flow), _p(tail_qk),
                                     _p(qk_map), _p(v_map), _p(workspace), workspace.numel() * workspace.element_size(),
-                                    _p(zeros_page(x.device)), dtype_code(x.dtype), _stream())
+                                    _p(zeros_page(x.device)), dtype_code(x.dtype), _stream(), _s32(residual32, out32))
     _check(rc, "vface_attn1_forward")
 
 
@@ -322,7 +348,7 @@ def vae_sample(moments: torch.Tensor, noise: Optional[torch.Tensor], z: torch.Te
 
 
 def upsample2x_conv3x3(x: torch.Tensor, wt_phases: torch.Tensor, out: torch.Tensor, *, nimg: int, H: int, W: int, cin: int,
-                       cout: int, ldx: int, ldy: int, bias=None, rowbias=None, flags: int = 0, colstats=None):
+                       cout: int, ldx: int, ldy: int, bias=None, rowbias=None, flags: int = 0, colstats=None, out32=None):
     """conv3x3(nearest_upsample2x(x)) as four parity-phase 2x2 convolutions (4/9 of the multiply-adds).
     ``wt_phases``: [4, cout, 4*cin] from ``packing.pack_upsample_phases``; ``out``: [nimg*2H*2W, >= cout]."""
     lib = load()
@@ -332,13 +358,13 @@ def upsample2x_conv3x3(x: torch.Tensor, wt_phases: torch.Tensor, out: torch.Tens
                                                     _p(bias), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0,
                                                     _p(out), ldy, _p(zeros_page(x.device)), flags, dtype_code(x.dtype),
                                                     _p(colstats), colstats.stride(0) // 2 if colstats is not None else 0,
-                                                    _stream())
+                                                    _stream(), _s32(None, out32))
             _check(rc, "vface_upsample2x_conv3x3_phase")
 
 
 def conv3x3_plus_1x1(x: torch.Tensor, x2: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, H: int, W: int,
                      cin: int, c2: int, cout: int, ldx: int, ldx2: int, ldy: int, bias=None, rowbias=None, flags: int = 0,
-                     colstats=None, split_k: bool = True):
+                     colstats=None, split_k: bool = True, out32=None):
     """out = conv3x3(x) + x2 @ W2^T + bias (a ResBlock's second conv plus its 1x1 shortcut); ``wt``: [cout, 9*cin + c2]."""
     lib = load()
     M, K = nimg * H * W, 9 * cin + c2
@@ -346,5 +372,6 @@ def conv3x3_plus_1x1(x: torch.Tensor, x2: torch.Tensor, wt: torch.Tensor, out: t
     rc = lib.vface_conv3x3_plus_1x1(_p(x), ldx, nimg, H, W, cin, _p(x2), ldx2, c2, _p(wt), K, cout, _p(bias), _p(rowbias),
                                     rowbias.stride(0) if rowbias is not None else 0, _p(out), ldy, _p(zeros_page(x.device)),
                                     flags, dtype_code(x.dtype), _p(colstats),
-                                    colstats.stride(0) // 2 if colstats is not None else 0, _p(ws), ws_bytes, _stream())
+                                    colstats.stride(0) // 2 if colstats is not None else 0, _p(ws), ws_bytes, _stream(),
+                                    _s32(None, out32))
     _check(rc, "vface_conv3x3_plus_1x1")

@@ -97,3 +97,35 @@ class FrameShard:
         hf = self.halo_flow(global_flow)
         engine.halo_flow = hf.to(device=device, dtype=torch.float32).contiguous() if hf is not None else None
         engine.halo_exchange = self if self.world > 1 else None
+
+
+class LoopbackShard(FrameShard):
+    """All shards of a clip run ONE AFTER ANOTHER in one process on one GPU: rank r's boundary slabs are kept in memory
+    (in call order -- one per hooked level-0 layer and UNet call) and handed to rank r+1 when it runs.  The chain has
+    no cycle (rank 0 needs nothing), so running the ranks in order needs no concurrency.  Same engine code path as the
+    RCCL exchange (``UNetEngine._attn1_sharded``), which makes it the strict bit-for-bit test of that path
+    (tests/test_sharded_gpu.py) and a way to walk a clip that does not fit one batch through one GPU."""
+
+    def __init__(self, rank: int, world: int, total_frames: int, store: dict):
+        super().__init__(rank, world, total_frames, dist=object() if world > 1 else None)
+        self.store = store          # {rank: [slab, ...]} shared by the shards of one clip
+        self.store.setdefault(rank, [])
+        self._next = 0
+
+    def begin_forward(self):
+        """Call before each UNet forward of this shard: its slabs are re-recorded, the predecessor's re-read."""
+        self.store[self.rank] = []
+        self._next = 0
+
+    def start_exchange(self, tail: torch.Tensor):
+        if self.world == 1:
+            return None
+        self.store[self.rank].append(tail.detach().clone())
+        i = self._next
+        self._next += 1
+        return ("loop", i, None)
+
+    def finish_exchange(self, handle):
+        if handle is None or self.rank == 0:
+            return None
+        return self.store[self.rank - 1][handle[1]]
