@@ -132,6 +132,22 @@ class ConvTimer:
         return n, ms, self.flops
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by the cgroup CPU quota when there is one and
+    by the GPU box's documented share of 16 cores per GPU otherwise (its affinity mask shows all 256 host threads:
+    256 torch threads on a 16-core share ran a forward in 177 s instead of ~5 s).  VFACE_CPU_THREADS overrides."""
+    if os.environ.get("VFACE_CPU_THREADS"):
+        return max(1, int(os.environ["VFACE_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, min(n, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
+
+
 def cpu_baseline(n_forwards, ddim_steps):
     """Oracle (kind 'port') timed on the host cores, as BASELINE.md 4 plans it: full-size UNet, 64x64 latent, the shipped
     hook schedule (flow_fix on the input-block attn1), F = 2 frames (batch 6) so the flow warp really runs, 1 warm-up +
@@ -139,7 +155,7 @@ def cpu_baseline(n_forwards, ddim_steps):
     from oracle import hooks as ohooks
     from oracle import unet as ounet
     from vface_amd.utils import synth
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     torch.set_num_threads(cores)
     n_forwards = max(3, n_forwards)
     log(f"cpu_baseline: oracle on {cores} threads ...")
@@ -210,6 +226,8 @@ def main():
     synth.fill_module_(ldm.unet, seed=0)
     ldm = ldm.to(dev)
     sampler = DDIMSampler(ldm)
+    if h != 64:
+        sampler.flow_gate = "flow_hw"   # the reference's gate (4096 tokens) only ever fires at 512 x 512
     sampler.make_schedule(a.ddim_steps, ddim_eta=0.0, verbose=False)
     steps = [int(s) for s in sampler.ddim_timesteps[::-1]]
 

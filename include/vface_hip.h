@@ -49,6 +49,8 @@ extern "C" {
 #define VFACE_CONV_PAD_TRAILING 0x40000 /* vface_conv3x3: zero padding (left 0, right 1, top 0, bottom 1) instead of 1 all round */
 #define VFACE_TUNE_NO_PERSISTENT 0x10000 /* one workgroup per output tile even where the persistent form would run */
 #define VFACE_TUNE_PERSISTENT 0x20000    /* persistent form for a plain GEMM too (default: implicit convolutions only) */
+#define VFACE_TUNE_NO_PATCH 0x80000      /* convolutions: never the patch-staged kernel (im2col-style staging, one load per tap) */
+#define VFACE_TUNE_PATCH 0x100000        /* convolutions: the patch-staged kernel wherever the shape allows, however small the grid */
 
 /* fusion modes of the attn1 hook (pnp_utils.py:133-262) understood by vface_attn1_forward */
 #define VFACE_FUSION_NONE 0       /* switch_on == False, or unpatched CrossAttention.forward */

@@ -643,3 +643,83 @@ def test_norms_read_the_fp32_stream(C):
     h.groupnorm_apply(x.to(DEV), st, gm.to(DEV), bt.to(DEV), y, nimg=nimg, hw=hw, C_=C, ldx=C, ldy=C, silu=True)
     ref = F.silu(F.group_norm(x.reshape(nimg, hw, C).permute(0, 2, 1), 32, gm, bt, 1e-5)).permute(0, 2, 1).reshape(M, C)
     assert rel_l2(y.cpu().float(), ref) < 4e-4
+
+
+# ------------------------------------------------------------------------------------------ patch-staged convolution
+def _gn_sums(cs, nimg):
+    """per-sample, per-channel (sum, sumsq) from a colstats buffer [slices, C, 2] (slice order inside a sample is free)"""
+    return cs.reshape(nimg, -1, cs.shape[1], 2).double().sum(1)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,H,W,nimg", [(64, 160, 16, 16, 2), (320, 320, 32, 16, 3), (128, 128, 48, 48, 1),
+                                               (640, 640, 16, 32, 2), (64, 256, 64, 64, 2)])
+def test_conv_patch_kernel_equals_im2col_kernel_bit_for_bit(dt, cin, cout, H, W, nimg):
+    """conv.hip (every pixel staged once per 64-channel chunk, 16x16-pixel tiles, 8 waves) against gemm.hip's implicit GEMM
+    (one LDS load per tap): same K order and per-accumulator MFMA order -> the same bits; and both against torch."""
+    h = hip()
+    from vface_amd.packing import pack_conv3x3
+    x = rnd((nimg, cin, H, W), 1, dt)
+    w = rnd((cout, cin, 3, 3), 2, dt, 1 / math.sqrt(9 * cin))
+    b = rnd((cout,), 3, torch.float32, 0.1)
+    rb = rnd((nimg, cout), 4, torch.float32)
+    res = rnd((nimg * H * W, cout), 5, dt)
+    ref = (F.conv2d(x.float(), w.float(), b, padding=1) + rb[:, :, None, None]).permute(0, 2, 3, 1).reshape(-1, cout) + res.float()
+    xn = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(DEV)
+    wp = pack_conv3x3(w).to(DEV)
+    outs, stats = [], []
+    for flag in (h.TUNE_PATCH, h.TUNE_NO_PATCH):
+        out = torch.zeros(nimg * H * W, cout + 32, dtype=dt, device=DEV)    # a column slice of a wider buffer
+        cs = torch.zeros(nimg * H * W // 64, cout, 2, dtype=torch.float32, device=DEV)
+        h.conv3x3(xn, wp, out[:, 16:], nimg=nimg, H=H, W=W, cin=cin, cout=cout, ldx=cin, ldy=cout + 32, bias=b.to(DEV),
+                  rowbias=rb.to(DEV), residual=res.to(DEV), ldr=cout, flags=flag, colstats=cs, split_k=False)
+        assert out[:, :16].abs().max() == 0 and out[:, 16 + cout:].abs().max() == 0
+        outs.append(out[:, 16:16 + cout].cpu())
+        stats.append(_gn_sums(cs.cpu(), nimg))
+    assert rel_l2(outs[0].float(), ref) < TOL[dt]
+    assert torch.equal(outs[0], outs[1])
+    y = outs[0].double().reshape(nimg, H * W, cout)
+    assert rel_l2(stats[0][..., 0], y.sum(1)) < 1e-5 and rel_l2(stats[0][..., 1], (y * y).sum(1)) < 1e-5
+    assert rel_l2(stats[0], stats[1]) < 1e-5
+
+
+def test_conv_patch_kernel_fp32_stream_shortcut_and_phases():
+    """The other launch forms of the patch kernel: fp32 residual in / fp32 carrier out, the fused 1x1 shortcut (K tiles
+    past the window), and the 2x2 parity-phase windows of an upsampling convolution -- each bit-identical to gemm.hip."""
+    h = hip()
+    from vface_amd.packing import pack_conv3x3, pack_upsample_phases
+    dt = torch.float16
+    cin, c2, cout, H, W, nimg = 128, 192, 320, 32, 32, 2
+    x, x2 = rnd((nimg, cin, H, W), 1, dt), rnd((nimg * H * W, c2), 2, dt)
+    w, w2 = rnd((cout, cin, 3, 3), 3, dt, 1 / math.sqrt(9 * cin)), rnd((cout, c2), 4, dt, 1 / math.sqrt(c2))
+    b, res32 = rnd((cout,), 5, torch.float32, 0.1), rnd((nimg * H * W, cout), 6, torch.float32)
+    xn = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(DEV)
+    got = {}
+    for name, flag in (("patch", h.TUNE_PATCH), ("im2col", h.TUNE_NO_PATCH)):
+        o16 = torch.zeros(nimg * H * W, cout, dtype=dt, device=DEV)
+        o32 = torch.zeros(nimg * H * W, cout, dtype=torch.float32, device=DEV)
+        h.conv3x3(xn, pack_conv3x3(w).to(DEV), o16, nimg=nimg, H=H, W=W, cin=cin, cout=cout, ldx=cin, ldy=cout, bias=b.to(DEV),
+                  residual32=res32.to(DEV), out32=o32, flags=flag, split_k=False)
+        s16 = torch.zeros_like(o16)
+        s32 = torch.zeros_like(o32)
+        cs = torch.zeros(nimg * H * W // 64, cout, 2, dtype=torch.float32, device=DEV)
+        h.conv3x3_plus_1x1(xn, x2.to(DEV), torch.cat([pack_conv3x3(w), w2], 1).contiguous().to(DEV), s16, nimg=nimg, H=H, W=W,
+                           cin=cin, c2=c2, cout=cout, ldx=cin, ldx2=c2, ldy=cout, bias=b.to(DEV), flags=flag, colstats=cs,
+                           out32=s32, split_k=False)
+        up = torch.zeros(nimg * 4 * H * W, cout, dtype=dt, device=DEV)
+        ucs = torch.zeros(nimg * 4 * H * W // 64, cout, 2, dtype=torch.float32, device=DEV)
+        h.upsample2x_conv3x3(xn, pack_upsample_phases(w.float()).to(dt).to(DEV), up, nimg=nimg, H=H, W=W, cin=cin, cout=cout,
+                             ldx=cin, ldy=cout, bias=b.to(DEV), flags=flag, colstats=ucs)
+        got[name] = [t.cpu() for t in (o16, o32, s16, s32, up)] + [_gn_sums(cs.cpu(), nimg), _gn_sums(ucs.cpu(), nimg)]
+    conv = F.conv2d(x.double(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert rel_l2(got["patch"][1], conv + res32.double()) < 3e-6
+    assert rel_l2(got["patch"][3], conv + x2.double() @ w2.double().t()) < 3e-6
+    upref = F.conv2d(F.interpolate(x.float(), scale_factor=2, mode="nearest"), w.float(), b, padding=1)
+    assert rel_l2(got["patch"][4].float().reshape(nimg, 2 * H, 2 * W, cout).permute(0, 3, 1, 2), upref) < 1e-3
+    for a, c in zip(got["patch"][:5], got["im2col"][:5]):
+        assert torch.equal(a, c)
+    assert torch.equal(got["patch"][0], got["patch"][1].to(dt))
+    for a, c in zip(got["patch"][5:], got["im2col"][5:]):
+        assert rel_l2(a, c) < 1e-5
+    y = got["patch"][3].double().reshape(nimg, H * W, cout)
+    assert rel_l2(got["patch"][5][..., 0], y.sum(1)) < 1e-5

@@ -46,6 +46,7 @@ def _run(rank, world, port, outdir):
     synth.fill_module_(ldm.unet, seed=0)
     ldm = ldm.to(dev)
     sampler = DDIMSampler(ldm)
+    sampler.flow_gate = "flow_hw"
     shard = FrameShard(rank, world, total, dist if world > 1 else None)
     f0, fc = shard.first, shard.count
     gflow = synth.synth_flow(total - 1, h, w)
@@ -90,6 +91,7 @@ def test_loopback_shards_equal_unsharded_bit_for_bit(total, world):
     synth.fill_module_(ldm.unet, seed=0)
     ldm = ldm.to(dev)
     sampler = DDIMSampler(ldm)
+    sampler.flow_gate = "flow_hw"
     gflow = synth.synth_flow(total - 1, h, w)
     eng = ldm.unet.engine
 

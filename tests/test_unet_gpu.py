@@ -1,7 +1,14 @@
 """Whole-path parity on the MI355X: the hooked UNet and the DDIM loop through the product modules (HIP kernels)
 against the CPU oracle on the same seeded inputs, and against the reference-generated full-size fixture.
-Tolerance: rel-L2 <= 1e-3 in fp16 is the north-star bound for the UNet output; see TOL below for what is
-asserted per case."""
+
+Tolerance.  The north-star asks for rel-L2 <= 1e-3 against the reference.  Per kernel that is asserted
+(tests/test_kernels_gpu.py).  For a whole 16-bit network it is not reachable by ANY implementation that feeds fp16
+weights to the matrix cores, and the fixtures the reference itself produced show it (tests/golden/lowp.npz,
+make_golden.py::gen_lowp): the reference UNet in fp32 arithmetic with nothing but its parameters rounded to fp16 is
+already 9.6e-4 (full UNet) / 1.1e-3 (small configuration) from its fp32 output, and the reference in its own shipped
+arithmetic (fp16 autocast) is 1.59e-3 / 2.06e-3 away.  What is asserted here instead, per case:
+  * the HIP path is CLOSER to the fp32 reference than the reference's own fp16-autocast run (fixture, not emulation);
+  * an absolute bound a little above the measured value (fp32 residual stream: DESIGN 6), so a regression shows."""
 import pytest
 import torch
 
@@ -30,7 +37,9 @@ def small():
     synth.fill_module_(ldm.unet, seed=0)
     sd = {k: v.clone() for k, v in ldm.unet.state_dict().items()}
     ldm = ldm.to(DEV)
-    return ldm, DDIMSampler(ldm), sd
+    sampler = DDIMSampler(ldm)
+    sampler.flow_gate = "flow_hw"   # 32 x 32 latents: the reference's n == 4096 test would never warp (see the gate test below)
+    return ldm, sampler, sd
 
 
 def _register(sampler, mode, flow):
@@ -159,6 +168,7 @@ def test_small_unet_bf16_measured(small, mode):
     ldm.unet.load_state_dict(sd)
     ldm = ldm.to(DEV)
     sampler = DDIMSampler(ldm)
+    sampler.flow_gate = "flow_hw"
     F_, h, w = 2, 32, 32
     x = synth.synth_normal("small.x", (6, 9, h, w)); ctx = synth.synth_normal("small.ctx", (6, 1, 768))
     t = torch.full((6,), 481, dtype=torch.long)
@@ -192,10 +202,15 @@ def test_full_unet_vs_reference_golden(mode):
             split_ratio_fft=0.8, alpha=0.8)
     got = ldm.apply_model(x, t, ctx).float().cpu()
     err = rel_l2(got, g[mode])
-    print(f"full UNet {mode}: rel-L2 vs reference {err:.3e}")
-    assert err < 2e-3, err
+    lp = load_golden("lowp")
+    e_auto, e_w16 = rel_l2(lp[f"full.{mode}_autocast_f16"], g[mode]), rel_l2(lp[f"full.{mode}_w16"], g[mode])
+    print(f"full UNet {mode}: rel-L2 vs reference {err:.3e}  (reference under fp16 autocast {e_auto:.3e}; reference with "
+          f"fp16-rounded weights only {e_w16:.3e})")
+    assert err < e_auto, (err, e_auto)        # closer to fp32 than the reference's own shipped arithmetic
+    assert err < FULL_BOUND, err
 
 
+FULL_BOUND = 1.35e-3   # measured 1.2e-3 with the fp32 residual stream (1.45e-3 without); the fp16-weight floor is 9.6e-4
 _FULL = {}
 
 
@@ -287,6 +302,7 @@ def _full_run(fusion, frames, f0, fc, h, flow_all=None):
     from vface_amd.ldm.models.pnp_utils import register_spa_attn_injection as reg
     ldm = _full_model()
     sampler = DDIMSampler(ldm)
+    sampler.flow_gate = "flow_hw"
     pick = lambda name, shape: torch.stack([synth.synth_normal(f"cfg.{name}.{c}.{f}", shape)
                                             for c in range(3) for f in range(f0, f0 + fc)])
     x, ctx = pick("x", (9, h, h)).to(DEV), pick("c", (1, 768)).to(DEV)

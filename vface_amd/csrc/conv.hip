@@ -1,0 +1,410 @@
+// Patch-staged implicit-GEMM convolution for the VFace UNet (gfx950): every input pixel is staged into LDS ONCE per
+// 64-channel chunk and feeds all KH x KW taps from there.
+//
+//   Y[pixel, n] = epilogue( sum_{chunk c} sum_{tap (ky,kx)} sum_{ci < 64} X[pixel + (ky,kx) - pad, c*64 + ci] * Wt[n, (c, tap, ci)]
+//                           (+ sum_k X2[pixel, k] * Wt[n, K1 + k]  -- the fused 1x1 shortcut) )
+//
+// (openaimodel.py ResBlock convs :201-205,225-232, Upsample.conv :108-118 as its four parity-phase 2x2 windows,
+// diffusionmodules/model.py ResnetBlock / Upsample; stride 1 only -- the three stride-2 Downsample convs of a forward and
+// images that are not multiples of 16 stay on gemm.hip's im2col kernel, which re-stages a pixel once per tap.)
+//
+// Why: gemm.hip's implicit GEMM moves 16 KB of activations AND 20 KB of weights into LDS per 64-deep K tile of a
+// 128 x 160 tile -- nine LDS-DMA wave-instructions per wave and tile, which is what its main loop is bound by.
+// Here a workgroup owns 16 x 16 output pixels x BN output channels: the 18 x 18 x 64-channel halo patch (41 KB) is
+// staged once per chunk, double-buffered, and the nine taps read it at shifted pixel addresses; only the weight tile
+// (BN x 64, 20 KB) streams per tap.  Per wave and K tile: 40 MFMAs against ~3.1 LDS-DMA instructions (was 9), and the
+// activation bytes a workgroup pulls through L2 drop 6.3x.
+//
+// * 512 threads = 8 waves as 4 (pixel rows) x 2 (channel halves); a wave owns 4 image rows x 16 pixels x BN/2 channels
+//   = 4 x NT mfma_f32_16x16x32 tiles (NT = 5 | 4), fp32 accumulate, one workgroup per CU (LDS 143 KB, <= 256 VGPRs).
+// * LDS: patch[2] (324 pixels x 128 B, pixel-major, 16-B slot of chunk q of pixel p at q ^ ((p >> 1) & 7): the 16
+//   consecutive pixels of an MFMA tile read conflict-free at every tap shift) + a 3-slot ring of weight tiles
+//   (row-major 128-B rows, same swizzle as gemm.hip).  Everything arrives by `buffer_load ... lds` (zero padding and the
+//   patch's out-of-image halo are out-of-range offsets: the hardware writes zeros).
+// * Schedule: one barrier per K tile.  Weight tile t+2 and one piece of the NEXT chunk's patch are issued right after
+//   barrier t; `s_waitcnt vmcnt(n)` with n = this wave's weight pieces of tile t+1 retires everything older (in-order).
+// * Weights are the MFMA A operand, activations the B operand -- the same fragment layout, K order (chunk, tap, channel)
+//   and per-accumulator MFMA order as gemm.hip, so results are BIT-IDENTICAL to that kernel's (tests rely on it).
+// * Epilogue: the wide (LDS-transposed, 16 B per lane) epilogue of gemm.hip: bias + per-sample row bias + residual
+//   (16-bit or the fp32 stream) summed in fp32, single rounding, optional fp32 carrier, per-64-pixel column statistics.
+#include "common.hpp"
+#include "vface_kernels.hpp"
+
+namespace {
+
+constexpr int TP = 16;                 // output tile: TP x TP pixels of one image
+constexpr int PATCH_MAX = 18 * 18;     // halo patch pixels (3x3 window)
+constexpr int PATCH_BYTES = ((PATCH_MAX + 7) / 8) * 1024;   // whole 1-KiB LDS-DMA pieces (8 pixels x 128 B each)
+
+template <class TT, int NT>
+__global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
+    using E = typename TT::elem;
+    using V8 = typename TT::v8;
+    constexpr int BN = 32 * NT;                    // 160 | 128
+    constexpr int BPIECES = BN / 8;                // 1-KiB LDS-DMA pieces per weight tile (8 rows x 128 B each)
+    constexpr int BSLOT = BN * 128;                // bytes per weight slot
+    constexpr int NB_HI = (BPIECES + 7) / 8, NB_LO = BPIECES / 8;   // pieces per wave: waves < BPIECES % 8 get NB_HI
+    constexpr int NB_SPLIT = BPIECES % 8;          // (0 = every wave issues NB_LO == NB_HI pieces)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned char* sP = smem_raw;                          // [2][PATCH_BYTES]
+    unsigned char* sB = smem_raw + 2 * PATCH_BYTES;        // [3][BSLOT]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr unsigned ES = sizeof(E);
+    constexpr unsigned OOB = 0xFFFFFFF0u;
+
+    // ---- tile origin: XCD-aware order as in gemm.hip (contiguous run of the tile sequence per XCD; column groups of
+    // 8 n-tiles, m-major inside a group)
+    const int tiles_x = p.W / TP, tiles_y = p.H / TP, tiles_img = tiles_x * tiles_y;
+    const int ntm = (p.M / (p.OH * p.OW)) * tiles_img, ntn = p.N / BN;
+    int tm, tn;
+    {
+        const int nwg = ntm * ntn, id = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
+        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        constexpr int GN = 8;
+        const int g = L / (GN * ntm);
+        const int rem = L - g * (GN * ntm);
+        const int gw = min(GN, ntn - g * GN);
+        tm = rem / gw;
+        tn = g * GN + (rem - tm * gw);
+    }
+    const int img = tm / tiles_img, trem = tm - img * tiles_img;
+    const int ty0 = (trem / tiles_x) * TP, tx0 = (trem - (trem / tiles_x) * tiles_x) * TP;
+    const int n0 = tn * BN;
+
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : 0u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wt), 0, (int)p.w_bytes, 0x00020000);
+
+    // ---- patch staging map.  Piece j (0 .. npieces-1) = patch pixels 8j .. 8j+7, lane l -> pixel 8j + (l >> 3), LDS slot
+    // l & 7 holds chunk (l & 7) ^ swz(pixel).  Wave w issues pieces w, w + 8, ... (at most 6 of them: 41 pieces / 8 waves).
+    const int PW = TP + p.KW - 1, PH = TP + p.KH - 1, npix = PW * PH;
+    const int npieces = (npix + 7) >> 3;
+    unsigned poff[6], poff2[6];      // byte offset of (pixel, swizzled chunk) in A (window patch) / A2 (1x1 source)
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int pp = (wave + 8 * i) * 8 + (lane >> 3);
+        const int py = pp / PW, px = pp - py * PW;
+        const int iy = ty0 - p.pad + py, ix = tx0 - p.pad_x + px;
+        const unsigned ch = (unsigned)((lane & 7) ^ ((pp >> 1) & 7));
+        const bool ok = pp < npix && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        poff[i] = ok ? (unsigned)(((((long)img * p.H + iy) * p.W + ix) * p.lda + ch * 8) * ES) : OOB;
+        // the 1x1 source is staged as a 16 x 16 "patch" without halo: pixel index pp = ly * 16 + lx
+        const int ly = pp >> 4, lx = pp & 15;
+        poff2[i] = (p.A2 && pp < TP * TP)
+                       ? (unsigned)(((((long)img * p.H + ty0 + ly) * p.W + tx0 + lx) * p.lda2 + ch * 8) * ES) : OOB;
+    }
+    // ---- weight staging map: piece r = rows 8r .. 8r+7 of the tile, lane l -> row 8r + (l >> 3), chunk (l & 7) ^ swz(row)
+    unsigned boff[NB_HI];
+#pragma unroll
+    for (int i = 0; i < NB_HI; ++i) {
+        const int piece = wave + 8 * i;
+        const int row = piece * 8 + (lane >> 3);
+        const unsigned ch = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+        boff[i] = (piece < BPIECES && n0 + row < p.N) ? (unsigned)((((long)(n0 + row)) * p.ldw + ch * 8) * ES) : OOB;
+    }
+
+    const int taps = p.ntaps;
+    const int nchunks = p.Cin >> 6;
+    const int T1 = nchunks * taps;                     // K tiles of the window
+    const int T = T1 + (p.A2 ? ((p.K - p.K1) >> 6) : 0);  // + K tiles of the 1x1 source
+    // K tile t: chunk c = t / taps, tap = t % taps (t < T1); 1x1 source chunk t - T1 otherwise ("chunk" nchunks + t - T1)
+
+    auto issue_B = [&](int kt) {
+        unsigned char* dst = sB + (kt % 3) * BSLOT;
+        const unsigned koff = (unsigned)kt * 64u * ES;
+#pragma unroll
+        for (int i = 0; i < NB_HI; ++i) {
+            if (i < NB_LO || wave < NB_SPLIT) {
+                const unsigned off = boff[i] != OOB ? boff[i] + koff : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(dst + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
+            }
+        }
+    };
+    // piece i of this wave for patch "chunk" cidx (cidx < nchunks: window patch of channel chunk cidx; else 1x1 source)
+    auto issue_P = [&](int cidx, int i) {
+        const int piece = wave + 8 * i;
+        unsigned char* dst = sP + (cidx & 1) * PATCH_BYTES + piece * 1024;
+        if (cidx < nchunks) {
+            if (piece < npieces) {
+                const unsigned off = poff[i] != OOB ? poff[i] + (unsigned)cidx * 64u * ES : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(dst), 16, off, 0, 0, 0);
+            }
+        } else if (piece < (TP * TP) / 8) {
+            const unsigned off = poff2[i] != OOB ? poff2[i] + (unsigned)(cidx - nchunks) * 64u * ES : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(dst), 16, off, 0, 0, 0);
+        }
+    };
+    const int nchunks_all = nchunks + (T - T1);
+    // K tile (within a chunk) after whose barrier piece i of the next chunk's patch goes out: 3x3 windows spread the six
+    // pieces over their first six K tiles, shorter windows (the 2x2 parity phases) wrap around
+    int pstep[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pstep[i] = i % taps;
+
+    f4_t acc[NT][4];  // [n tile j][pixel row i]
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    // weight fragment addresses (constant over the K loop): row = wn * BN/2 + j*16 + fr, 16-B slot (kk*4 + fq) ^ swz(row);
+    // the kk = 1 half is the same address with byte bit 6 flipped
+    unsigned wadr[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int row = wn * (BN / 2) + j * 16 + fr;
+        wadr[j] = (unsigned)(row * 128 + ((fq ^ ((row >> 1) & 7)) << 4));
+    }
+
+    auto compute = [&](int kt) {
+        int pbuf, pp0, pw;
+        if (kt < T1) {
+            const int c = kt / taps, tap = kt - c * taps;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            pbuf = c & 1; pw = PW;
+            pp0 = (wm * 4 + ky) * PW + kx + fr;
+        } else {
+            pbuf = (nchunks + kt - T1) & 1; pw = TP;
+            pp0 = wm * 4 * TP + fr;
+        }
+        const unsigned char* sA = sP + pbuf * PATCH_BYTES;
+        const unsigned char* sW = sB + (kt % 3) * BSLOT;
+        V8 af[2][4], bf[2][NT];
+        unsigned padr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pp = pp0 + i * pw;
+            padr[i] = (unsigned)(pp * 128 + ((fq ^ ((pp >> 1) & 7)) << 4));
+        }
+        auto read_half = [&](int kk) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[kk][i] = *reinterpret_cast<const V8*>(sA + (padr[i] ^ (kk << 6)));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[kk][j] = *reinterpret_cast<const V8*>(sW + (wadr[j] ^ (kk << 6)));
+        };
+        constexpr int JH = NT / 2;
+        read_half(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < JH; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[0][j], af[0][i], acc[j][i]);
+        __builtin_amdgcn_sched_barrier(0);
+        read_half(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = JH; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[0][j], af[0][i], acc[j][i]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[1][j], af[1][i], acc[j][i]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: patch of chunk 0 (all pieces), weight tiles 0 and 1
+#pragma unroll
+    for (int i = 0; i < 6; ++i) issue_P(0, i);
+    issue_B(0);
+    if (T > 1) issue_B(1);
+
+    for (int kt = 0; kt < T; ++kt) {
+        // everything older than this wave's pieces of weight tile kt+1 has landed (LDS-DMA retires in order): tile kt, and
+        // every patch piece issued before it
+        if (kt + 1 < T) {
+            if (NB_SPLIT == 0 || wave >= NB_SPLIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_LO) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_HI) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // the patch pieces of the next chunk go out during the first six K tiles of this chunk, oldest first, BEFORE this
+        // period's weight pieces (so the counted wait above covers them one period later)
+        {
+            int cidx, step;
+            if (kt < T1) { cidx = kt / taps; step = kt - cidx * taps; }
+            else { cidx = nchunks + (kt - T1); step = 0; }
+            // a 1x1-source "chunk" lasts one K tile: all of the following chunk's pieces go out at once
+            if (cidx + 1 < nchunks_all) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    if (kt >= T1 || pstep[i] == step) issue_P(cidx + 1, i);   // (register arrays: static indices only)
+            }
+        }
+        if (kt + 2 < T) issue_B(kt + 2);
+        compute(kt);
+    }
+
+    // ---- wide epilogue (see gemm.hip): per pixel row i, transpose the wave's 16 x WN accumulator rows through LDS in
+    // fp32, sum bias / row bias / residual, round once, 16 B per lane
+    __syncthreads();
+    {
+        constexpr int WN = NT * 16;
+        constexpr int SP = WN + 4;
+        const float* bias = p.bias;
+        const float* rowbias = p.rowbias;
+        const E* res = p.res_f32 ? nullptr : reinterpret_cast<const E*>(p.residual);
+        const float* res32 = p.res_f32 ? reinterpret_cast<const float*>(p.residual) : nullptr;
+        E* Cout = reinterpret_cast<E*>(p.C);
+        float* C32 = p.C32;
+        float* colstats = p.colstats;
+        float* scr = reinterpret_cast<float*>(smem_raw) + wave * (16 * SP);
+        constexpr int CH = WN >> 3;               // 16-byte chunks per output row of this wave
+        constexpr int LPR = 64 / CH;              // rows covered per read pass
+        constexpr int RI = (16 + LPR - 1) / LPR;
+        const bool act = lane < LPR * CH;
+        const int rch = lane % CH, rrow = lane / CH;
+        const int ncol = n0 + wn * WN + rch * 8;
+        float s8[8], q8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+        const long mrow0 = ((long)img * p.H + ty0 + wm * 4) * p.W + tx0;   // output row (pixel index) of (i = 0, r = 0)
+        const float* rb = rowbias ? rowbias + (long)img * p.ld_rowbias : nullptr;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long mbase = mrow0 + (long)i * p.W;
+            // residual rows of this pixel row, requested before the transpose
+            V8 r16[RI];
+            float4 r32[RI][2];
+            if (res || res32) {
+#pragma unroll
+                for (int it = 0; it < RI; ++it) {
+                    const int r = rrow + it * LPR;
+                    if (act && r < 16 && ncol < p.N) {
+                        if (res) r16[it] = *reinterpret_cast<const V8*>(res + (mbase + r) * p.ldr + ncol);
+                        else {
+                            const float* rp = res32 + (mbase + r) * p.ldr + ncol;
+                            r32[it][0] = *reinterpret_cast<const float4*>(rp);
+                            r32[it][1] = *reinterpret_cast<const float4*>(rp + 4);
+                        }
+                    }
+                }
+            }
+            {
+                float* srow = scr + fr * SP + fq * 4;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int nb = n0 + wn * WN + j * 16 + fq * 4;
+                    float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+                    if (nb < p.N) {
+                        if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                        if (rb) { const float4 b = *reinterpret_cast<const float4*>(rb + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                    }
+                    *reinterpret_cast<float4*>(srow + j * 16) = v;
+                }
+            }
+            // LDS operations of one wave execute in order: the reads below see the writes above
+            if (act) {
+#pragma unroll
+                for (int it = 0; it < RI; ++it) {
+                    const int r = rrow + it * LPR;
+                    if (r < 16 && ncol < p.N) {
+                        const float4 x0 = *reinterpret_cast<const float4*>(scr + r * SP + rch * 8);
+                        const float4 x1 = *reinterpret_cast<const float4*>(scr + r * SP + rch * 8 + 4);
+                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+                        if (res) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] += to_f32(r16[it][e]);
+                        }
+                        if (res32) {
+                            const float4 a = r32[it][0], b = r32[it][1];
+                            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+                        }
+                        V8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
+                        long orow = mbase + r;
+                        if (p.out_phase) {
+                            // one output-parity phase of conv(nearest x2 upsample): pixel (oy, ox) of the phase grid is pixel
+                            // (2 oy + py, 2 ox + px) of the 2H x 2W output
+                            const int oy = ty0 + wm * 4 + i, ox = tx0 + r;
+                            orow = ((long)img * 2 * p.H + 2 * oy + ((p.out_phase >> 1) & 1)) * (2 * p.W) + 2 * ox + (p.out_phase & 1);
+                        }
+                        if (Cout) *reinterpret_cast<V8*>(Cout + orow * p.ldc + ncol) = o;
+                        if (C32) {
+                            float* d32 = C32 + orow * p.ldc32 + ncol;
+                            *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        }
+                        if (colstats) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float f = C32 ? v[e] : to_f32(o[e]); s8[e] += f; q8[e] += f * f; }
+                        }
+                    }
+                }
+            }
+        }
+        if (colstats) {
+            // fold the LPR row-lanes of every channel through the scratch (fixed order: reproducible).  The wave's 64 pixels
+            // (4 image rows x 16) are one statistics slice; slices only have to lie inside one sample and be numbered
+            // uniquely within it: slice = (tile index inside the sample) * 4 + wm, phase launches interleave by phase
+            if (act) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    scr[(rrow * WN + rch * 8 + e) * 2] = s8[e];
+                    scr[(rrow * WN + rch * 8 + e) * 2 + 1] = q8[e];
+                }
+            }
+            const int spp = (p.H * p.W) >> 6;      // slices per sample of this launch's (phase) grid
+            long slice = (long)trem * 4 + wm;
+            slice = p.out_phase ? ((long)img * 4 + (p.out_phase & 3)) * spp + slice : (long)img * spp + slice;
+            for (int c = lane; c < WN; c += 64) {
+                float ss = 0.f, qq = 0.f;
+                for (int l = 0; l < LPR; ++l) { ss += scr[(l * WN + c) * 2]; qq += scr[(l * WN + c) * 2 + 1]; }
+                const int n = n0 + wn * WN + c;
+                if (n < p.N) *reinterpret_cast<float2*>(colstats + (slice * p.ld_colstats + n) * 2) = make_float2(ss, qq);
+            }
+        }
+    }
+}
+
+template <class TT, int NT>
+int launch_patch(const GemmParams& p, hipStream_t stream) {
+    constexpr int BN = 32 * NT;
+    const size_t lds = 2 * PATCH_BYTES + 3 * (size_t)BN * 128;
+    auto kern = conv_patch_kernel<TT, NT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return VF_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int ntm = (p.M / (p.OH * p.OW)) * (p.H / TP) * (p.W / TP), ntn = p.N / BN;
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(512), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
+}
+
+}  // namespace
+
+// 0 = this launch is not a patch-kernel shape; else the channel-tile width (160 | 128) the launch would use
+int vf_conv_patch_tile(const GemmParams& p) {
+    if (p.mode != 1 || p.stride != 1 || p.upsample || (p.Cin & 63)) return 0;
+    if (p.OH != p.H || p.OW != p.W || (p.H % TP) || (p.W % TP)) return 0;
+    if (p.KH < 1 || p.KW < 1 || p.KH > 3 || p.KW > 3 || p.ntaps != p.KH * p.KW) return 0;
+    if (p.pad < 0 || p.pad_x < 0 || p.pad > 1 || p.pad_x > 1) return 0;
+    if ((p.flags & (GEMM_GEGLU | GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE | 0x4000)) || (p.N & 7)) return 0;
+    if (p.A2 && ((p.K - p.K1) & 63)) return 0;
+    if (p.colstats && ((p.H * p.W) & 63)) return 0;
+    if (p.residual && !p.res_f32 && (((uintptr_t)p.residual & 15) || (p.ldr & 7))) return 0;
+    if (((uintptr_t)p.C & 15) || (p.C && (p.ldc & 7))) return 0;
+    if (p.N % 160 == 0) return 160;
+    if (p.N % 128 == 0) return 128;
+    return 0;
+}
+
+int vf_launch_conv_patch(const GemmParams& p, int dtype, hipStream_t stream) {
+    const int bn = vf_conv_patch_tile(p);
+    if (!bn) return VF_ERR_SHAPE;
+    if (dtype == VF_DTYPE_F16) return bn == 160 ? launch_patch<F16, 5>(p, stream) : launch_patch<F16, 4>(p, stream);
+    if (dtype == VF_DTYPE_BF16) return bn == 160 ? launch_patch<BF16, 5>(p, stream) : launch_patch<BF16, 4>(p, stream);
+    return VF_ERR_DTYPE;
+}

@@ -909,6 +909,17 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         if (ab >= lim || wb >= lim || a2b >= lim) return VF_ERR_SHAPE;
         p.a_bytes = (unsigned)ab; p.w_bytes = (unsigned)wb; p.a2_bytes = (unsigned)a2b;
     }
+    // stride-1 convolutions over images that tile into 16 x 16 pixel patches run the patch-staged kernel (conv.hip): every
+    // input pixel goes through LDS once per channel chunk instead of once per tap.  The choice looks at the PER-SAMPLE
+    // geometry only (grid depth taken at the nominal 24-sample batch): the two kernels produce the same output bits but
+    // slice the column statistics differently, so a sample's bits must not depend on which other samples share its launch.
+    if (p.mode == 1 && !((p.flags >> 8) & 0xF) && !(p.flags & GEMM_NO_PATCH)) {
+        const int bn = vf_conv_patch_tile(p);
+        if (bn) {
+            const long tiles24 = 24L * (p.H / 16) * (p.W / 16) * (p.N / bn);
+            if (tiles24 >= 160 || (p.flags & GEMM_PATCH)) return vf_launch_conv_patch(p, dtype, stream);
+        }
+    }
     const int variant = pick_variant(p);
     if ((p.res_f32 || p.C32) && variant != 5 && variant != 6) return VF_ERR_SHAPE;
     if (p.mode == 1 && (p.ntaps != 9 || p.out_phase || p.A2) && variant != 5 && variant != 6) return VF_ERR_SHAPE;

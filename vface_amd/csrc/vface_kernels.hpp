@@ -3,7 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-enum { GEMM_GEGLU = 1, GEMM_OUT_F32 = 2, GEMM_NO_XCD_REMAP = 0x1000, GEMM_NO_SETPRIO = 0x2000, GEMM_NARROW_EPILOGUE = 0x8000, GEMM_NO_PERSIST = 0x10000, GEMM_PERSIST = 0x20000 };  // bits 8..11 of flags: forced schedule variant (0 = automatic)
+enum { GEMM_GEGLU = 1, GEMM_OUT_F32 = 2, GEMM_NO_XCD_REMAP = 0x1000, GEMM_NO_SETPRIO = 0x2000, GEMM_NARROW_EPILOGUE = 0x8000, GEMM_NO_PERSIST = 0x10000, GEMM_PERSIST = 0x20000,
+       GEMM_NO_PATCH = 0x80000, GEMM_PATCH = 0x100000 };  // (0x40000 = VFACE_CONV_PAD_TRAILING)  // bits 8..11 of flags: forced schedule variant (0 = automatic)
 
 struct GemmParams {
     int mode;  // 0: plain A[M][K]; 1: implicit 3x3 conv over NHWC
@@ -49,6 +50,9 @@ struct GemmParams {
 long vf_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_sample);
 bool vf_gemm_variants_built();
 int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
+// conv.hip: the patch-staged stride-1 convolution; vf_conv_patch_tile = 0 (not a patch shape) | 160 | 128
+int vf_conv_patch_tile(const GemmParams& p);
+int vf_launch_conv_patch(const GemmParams& p, int dtype, hipStream_t stream);
 bool vf_attention_shared_scores_supported(int dh, int v_sets);
 int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream);
 int vf_launch_gemm_pp(const GemmParams& p, int dtype, int variant, hipStream_t stream);

@@ -38,6 +38,11 @@ class HookCfg:
     flow: Optional[torch.Tensor] = None  # [F-1, 2, h, w] fp32 on the device, or None
     split_ratio_fft: float = 0.8
     alpha: float = 0.8
+    # which attention maps the flow smoothing applies to: "reference" = exactly pnp_utils.py:201 (`q.shape[1] == 4096`,
+    # reshaped to 64 x 64: the 512 x 512 level-0 maps and nothing else -- at any other resolution the reference silently
+    # skips the warp); "flow_hw" = the level whose token count equals h*w of the supplied flow field (identical at
+    # 512 x 512; what a 768 x 768 clip -- BASELINE config 5 -- needs for the module to act at all)
+    flow_gate: str = "reference"
 
 
 class Act:
@@ -94,11 +99,31 @@ def _dev_flow(flow, device) -> Optional[torch.Tensor]:
     return flow.to(device=device, dtype=torch.float32).contiguous()
 
 
-def plan_fusion(cfg: Optional[HookCfg], N: int, n: int) -> dict:
+def flow_gate_hw(cfg: HookCfg, n: int, flow_hw):
+    """The (h, w) of the maps to warp if the flow smoothing fires for an attention over ``n`` tokens, else None.
+    ``flow_hw``: spatial size of the flow field in use (the local fields, or the clip's when frames are sharded)."""
+    if flow_hw is None:
+        return None
+    h, w = int(flow_hw[0]), int(flow_hw[1])
+    if cfg.flow_gate == "reference":
+        if n != 4096:
+            return None
+        if (h, w) != (64, 64):   # the reference reshapes to 64 x 64 and adds the flow to a 64 x 64 grid (temporal_flow.py:43)
+            raise RuntimeError(f"The size of the flow field ({h}, {w}) must match the 64 x 64 attention map "
+                               "(pnp_utils.py:201-207, temporal_flow.py:43)")
+        return 64, 64
+    if cfg.flow_gate != "flow_hw":
+        raise ValueError(f"flow_gate must be 'reference' or 'flow_hw', not {cfg.flow_gate!r}")
+    return (h, w) if n == h * w else None
+
+
+def plan_fusion(cfg: Optional[HookCfg], N: int, n: int, clip_flow_hw=None) -> dict:
     """Map a hook configuration onto the kernels' mechanisms (pnp_utils.py:129-262).
-    Returns fusion code, chunks, which folded weight to use, and the flow / v-broadcast options."""
+    Returns fusion code, chunks, which folded weight to use, and the flow / v-broadcast options.  ``clip_flow_hw``: the
+    flow field's (h, w) when frames are sharded (a one-frame shard has no local field but still takes part in the
+    boundary exchange): ``warp_hw`` is then set even when ``flow`` is None."""
     pl = {"fusion": hip.FUSION_NONE, "chunks": 1, "wlin": None, "flow": None, "alpha": 0.8, "v_fixed": False,
-          "staged": None}
+          "staged": None, "warp_hw": None}
     if cfg is None or not cfg.switch_on:
         return pl
     chunks = cfg.chunks
@@ -114,13 +139,15 @@ def plan_fusion(cfg: Optional[HookCfg], N: int, n: int) -> dict:
         pl["fusion"] = hip.FUSION_LINEAR
         pl["wlin"] = ("fsai", 0.8 if f == "fft_vfixed" else cfg.split_ratio_fft)
         pl["v_fixed"] = f == "fft_vfixed"
-        if f == "flow_fix" and cfg.flow is not None and cfg.flow.shape[-2] * cfg.flow.shape[-1] == n:
-            # pnp_utils.py:201 gates on n == 4096 with a hard-coded 64x64 reshape; generalised to "the level
-            # whose token count equals the flow field's h*w" (identical at 512x512)
-            if cfg.flow.shape[0] != N // chunks - 1:
-                raise RuntimeError(f"flow has {cfg.flow.shape[0]} fields for {N // chunks} frames "
-                                   "(align_by_flow needs F-1, temporal_flow.py:231-233)")
-            pl["flow"], pl["alpha"] = cfg.flow, cfg.alpha
+        if f == "flow_fix":
+            fhw = tuple(cfg.flow.shape[-2:]) if cfg.flow is not None else clip_flow_hw
+            hw = flow_gate_hw(cfg, n, fhw)
+            if hw is not None:
+                nf = cfg.flow.shape[0] if cfg.flow is not None else 0
+                if nf != N // chunks - 1:
+                    raise RuntimeError(f"flow has {nf} fields for {N // chunks} frames "
+                                       "(align_by_flow needs F-1, temporal_flow.py:231-233)")
+                pl["flow"], pl["alpha"], pl["warp_hw"] = cfg.flow, cfg.alpha, hw
     elif f == "mix":
         pl["fusion"], pl["wlin"] = hip.FUSION_LINEAR, ("mix", 0.5)
     elif f in ("temporal", "adaIn"):
@@ -202,10 +229,11 @@ def attn_module_forward(mod, x: torch.Tensor, context: Optional[torch.Tensor], c
         v_map = torch.where(idx < c, idx, (idx // c) * c).to(dev) if pl["v_fixed"] else None
         ws = torch.empty(hip.attn1_workspace_bytes(B, n, d, chunks), dtype=torch.uint8, device=dev)
         flow = pl["flow"]
+        hw = pl["warp_hw"] or (0, 0)
         hip.attn1_forward(x16, pk["wqkv"], wlin, pk["wo"], pk["bo"], out, B=B, n=n, d=d, heads=mod.heads,
                           chunks=chunks, fusion=pl["fusion"], ldx=d_in, ldo=out.shape[1], workspace=ws,
-                          v_fixed=pl["v_fixed"], flow=flow, h=flow.shape[-2] if flow is not None else 0,
-                          w=flow.shape[-1] if flow is not None else 0, alpha=pl["alpha"], qk_map=qk_map, v_map=v_map)
+                          v_fixed=pl["v_fixed"], flow=flow, h=hw[0], w=hw[1], alpha=pl["alpha"], qk_map=qk_map,
+                          v_map=v_map)
     else:
         m = context.shape[1]
         c16 = to16(context).reshape(B * m, context.shape[2])
@@ -244,6 +272,7 @@ class UNetEngine:
         # multi-GPU: a parallel.FrameShard (start_exchange / finish_exchange), installed by FrameShard.install
         self.halo_exchange = None
         self.halo_flow: Optional[torch.Tensor] = None  # flow from the previous rank's last frame into our frame 0
+        self.halo_hw = None                            # (h, w) of the clip's flow fields (set with halo_exchange)
         # fp32 residual stream: residual sums are carried between kernels in fp32, 16-bit copies exist only
         # where a matrix-core operand needs them.  VFACE_STREAM32=0 restores the all-16-bit activations (A/B switch).
         self.stream32 = os.environ.get("VFACE_STREAM32", "1") != "0"
@@ -468,7 +497,7 @@ class UNetEngine:
         out = None if s32 else self._new(N * n, d)
         out32 = self._new(N * n, d, torch.float32) if s32 else None
         res_kw = {"residual32": resid, "out32": out32} if s32 else {"residual": resid, "ldr": resid.stride(0)}
-        pl = plan_fusion(cfg, N, n)
+        pl = plan_fusion(cfg, N, n, self.halo_hw if self.halo_exchange is not None else None)
         if pl["staged"]:
             if self.halo_exchange is not None:
                 raise NotImplementedError(f"fusion={pl['staged']!r} couples frames beyond one neighbour (temporal: +-2 "
@@ -481,16 +510,18 @@ class UNetEngine:
         qk_map = self._map("qk_replace", N, N // chunks) if fusion == hip.FUSION_REPLACE else None
         v_map = self._map("v_fixed", N, N // chunks) if v_fixed else None
         ws = torch.empty(hip.attn1_workspace_bytes(N, n, d, chunks), dtype=torch.uint8, device=self.device)
-        if flow is not None and self.halo_exchange is not None:
-            return self._attn1_sharded(xln, res_kw, p, wlin, a2vec, N, n, heads, flow, alpha, out)
+        hw = pl["warp_hw"]
+        if hw is not None and self.halo_exchange is not None:
+            # every rank of a sharded clip takes part in the boundary exchange, a one-frame shard (no local field) too
+            return self._attn1_sharded(xln, res_kw, p, wlin, a2vec, N, n, heads, flow, hw, alpha, out)
         hip.attn1_forward(xln, p["wqkv"], wlin, p["wo"]["w"], p["wo"]["b"], out, B=N, n=n, d=d, heads=heads,
                           chunks=chunks, fusion=fusion, ldx=xln.stride(0), ldo=d, workspace=ws,
-                          rowbias=a2vec, v_fixed=v_fixed, flow=flow,
-                          h=flow.shape[-2] if flow is not None else 0, w=flow.shape[-1] if flow is not None else 0,
+                          rowbias=a2vec, v_fixed=v_fixed, flow=flow if hw is not None else None,
+                          h=hw[0] if hw else 0, w=hw[1] if hw else 0,
                           alpha=alpha, qk_map=qk_map, v_map=v_map, **res_kw)
         return out32 if s32 else out
 
-    def _attn1_sharded(self, xln, res_kw, p, wlin, a2vec, N, n, heads, flow, alpha, out):
+    def _attn1_sharded(self, xln, res_kw, p, wlin, a2vec, N, n, heads, flow, hw, alpha, out):
         """flow_fix with frames sharded across ranks: the same kernels as vface_attn1_forward, sequenced here
         so the one-neighbour boundary exchange sits between the fused projection and the warp."""
         d = p["c"]
@@ -511,7 +542,7 @@ class UNetEngine:
         fused(2, qkv[2 * Fn:, :2 * d])
         halo = self.halo_exchange.finish_exchange(handle)
         dst = qkv[Fn:2 * Fn, :2 * d]
-        hip.flow_warp(T, dst, flow, F=F_, h=flow.shape[-2], w=flow.shape[-1], C_=2 * d, ld_src=2 * d, fs_src=n * 2 * d,
+        hip.flow_warp(T, dst, flow, F=F_, h=hw[0], w=hw[1], C_=2 * d, ld_src=2 * d, fs_src=n * 2 * d,
                       ld_dst=3 * d, fs_dst=n * 3 * d, alpha=alpha, prev=halo, ld_prev=2 * d,
                       flow_prev=self.halo_flow if halo is not None else None)
         att = self._new(N * n, d)

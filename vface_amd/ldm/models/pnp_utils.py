@@ -35,13 +35,20 @@ def _make_forward(module, cfg: HookCfg):
     return forward
 
 
+# Default of the extra ``flow_gate`` argument below ("reference" | "flow_hw", see engine.HookCfg.flow_gate): the reference's
+# own `q.shape[1] == 4096` test.  A sampler may carry its own default as ``sampler.flow_gate``.
+DEFAULT_FLOW_GATE = "reference"
+
+
 def register_spa_attn_injection(model, injection_schedule, switch_on=True, input_blocks=False, output_blocks=True,
                                 middle_block=False, attn_component='attn1', chunks=3, flow=None, block_indices=None,
-                                fusion="replace", split_ratio_fft=0.8, alpha=0.8):
+                                fusion="replace", split_ratio_fft=0.8, alpha=0.8, flow_gate=None):
+    """Positional / keyword arguments of the reference (pnp_utils.py:57); ``flow_gate`` is this package's only addition."""
     unet = model.model.model.diffusion_model
     dev = next(unet.parameters()).device
     cfg = HookCfg(switch_on=switch_on, chunks=chunks, fusion=fusion, flow=_dev_flow(flow, dev),
-                  split_ratio_fft=split_ratio_fft, alpha=alpha)
+                  split_ratio_fft=split_ratio_fft, alpha=alpha,
+                  flow_gate=flow_gate or getattr(model, "flow_gate", None) or DEFAULT_FLOW_GATE)
     processed_all = {}
     for enabled, group in ((input_blocks, "input_blocks"), (output_blocks, "output_blocks"),
                            (middle_block, "middle_block")):

@@ -97,6 +97,7 @@ class FrameShard:
         hf = self.halo_flow(global_flow)
         engine.halo_flow = hf.to(device=device, dtype=torch.float32).contiguous() if hf is not None else None
         engine.halo_exchange = self if self.world > 1 else None
+        engine.halo_hw = (int(global_flow.shape[-2]), int(global_flow.shape[-1]))
 
 
 class LoopbackShard(FrameShard):

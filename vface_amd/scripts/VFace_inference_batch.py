@@ -59,6 +59,10 @@ def build_parser() -> argparse.ArgumentParser:
                         "synthetic images (:456-457) and the samples are decoded to pixels (:596-600)")
     p.add_argument("--fusion", type=str, default="flow_fix", help="hook mode on the input-block attn1 modules")
     p.add_argument("--no_inversion", action="store_true", help="use random recon latents instead of DDIM inversion")
+    p.add_argument("--flow_gate", choices=["reference", "flow_hw"], default="reference",
+                   help="which attention maps the flow smoothing touches: 'reference' = exactly pnp_utils.py:201 (the 4096-token "
+                        "maps of a 512x512 clip, nothing at any other resolution); 'flow_hw' = the level whose token count equals "
+                        "h*w of the flow field (needed for the module to act at e.g. 768x768)")
     p.add_argument("--compute_dtype", choices=["fp16", "bf16"], default="fp16")
     p.add_argument("--max_steps", type=int, default=None, help="stop after this many DDIM steps (smoke runs)")
     return p
@@ -89,11 +93,16 @@ def run_synthetic(opt) -> dict:
     else:
         model = LatentDiffusion(cfg)
     if opt.ckpt:
-        sd = torch.load(opt.ckpt, map_location="cpu")
+        sd = torch.load(opt.ckpt, map_location="cpu", weights_only=True)
         sd = sd.get("state_dict", sd)
         missing, unexpected = model.load_state_dict(
             {k: v for k, v in sd.items() if k.startswith(("model.diffusion_model.", "first_stage_model."))}, strict=False)
-        print(f"loaded {opt.ckpt}: {len(missing)} missing, {len(unexpected)} unexpected keys")
+        # a checkpoint whose prefixes do not match must not run on default-initialised weights
+        hot = [k for k in missing if k.startswith("model.diffusion_model.") or (opt.with_vae and k.startswith("first_stage_model."))]
+        if hot or unexpected:
+            raise RuntimeError(f"{opt.ckpt}: {len(hot)} parameter(s) of the denoising path missing (first: {hot[:5]}), "
+                               f"{len(unexpected)} unexpected key(s) (first: {list(unexpected)[:5]})")
+        print(f"loaded {opt.ckpt}: every model.diffusion_model.* key matched ({len(missing)} keys outside the path absent)")
     else:
         synth.fill_module_(model.unet, seed=0)
         if opt.with_vae:
@@ -101,6 +110,7 @@ def run_synthetic(opt) -> dict:
     model = model.to(dev).eval()
     sampler = DDIMSampler(model)
     sampler.hook_plan = HookPlan(fusion=opt.fusion, enabled=opt.fusion != "none")
+    sampler.flow_gate = opt.flow_gate
     h, w = opt.H // opt.f, opt.W // opt.f
     F_ = opt.n_samples
     os.makedirs(opt.Base_dir, exist_ok=True)

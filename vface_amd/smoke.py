@@ -21,6 +21,7 @@ def run(verbose: bool = True) -> float:
     synth.fill_module_(ldm.unet, seed=0)
     ldm = ldm.to(dev)
     sampler = DDIMSampler(ldm)
+    sampler.flow_gate = "flow_hw"   # a 16x16 latent: the reference's own gate (n == 4096) would skip the warp
     F_, h, w = 2, 16, 16
     x = synth.synth_normal("smoke.x", (3 * F_, 9, h, w))
     ctx = synth.synth_normal("smoke.ctx", (3 * F_, 1, 768))
@@ -41,5 +42,5 @@ def run(verbose: bool = True) -> float:
     err = float((got - ref).norm() / ref.norm())
     if verbose:
         print(f"smoke: hooked UNet (flow_fix) on {torch.cuda.get_device_name(0)}: rel-L2 vs CPU oracle = {err:.3e}")
-    assert err < 5e-3, err
+    assert err < 2e-3, err
     return err
