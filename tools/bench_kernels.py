@@ -36,9 +36,10 @@ def main():
     dt = torch.float16
     g = torch.Generator(device="cpu").manual_seed(0)
     rnd = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dt).to(DEV)
-    variants = {"auto": 0, "db128": 0x500, "db160": 0x600, "pp128": 0x900, "pp160": 0xA00}
+    variants = {"auto": 0, "db128": 0x500, "db160": 0x600}
+    cvariants = {"auto": 0, "patch": hip.TUNE_PATCH, "im2col": hip.TUNE_NO_PATCH}
     if "conv" in a.what:
-        print("== conv3x3 implicit GEMM (TFLOP/s median | best), variants:", list(variants))
+        print("== conv3x3 implicit GEMM (TFLOP/s median | best), variants:", list(cvariants))
         for (H, cin, cout, stride) in [(64, 320, 320, 1), (64, 640, 320, 1), (64, 960, 320, 1), (32, 640, 640, 1),
                                        (32, 1280, 640, 1), (16, 1280, 1280, 1), (16, 2560, 1280, 1), (8, 1280, 1280, 1),
                                        (64, 320, 320, 2)]:
@@ -49,7 +50,7 @@ def main():
             b = torch.zeros(cout, device=DEV)
             fl = 2.0 * N * OH * OH * cout * 9 * cin
             row = f"H{H:3d} {cin:4d}->{cout:4d} s{stride}: "
-            for name, f in variants.items():
+            for name, f in cvariants.items():
                 med, best = timeit(lambda: hip.conv3x3(x, w, out, nimg=N, H=H, W=H, cin=cin, cout=cout, ldx=cin, ldy=cout,
                                                        stride=stride, bias=b, flags=f))
                 row += f"{name} {fl / med / 1e9:6.0f}|{fl / best / 1e9:6.0f}  "

@@ -17,7 +17,7 @@
 //
 // * 512 threads = 8 waves as 4 (pixel rows) x 2 (channel halves); a wave owns 4 image rows x 16 pixels x BN/2 channels
 //   = 4 x NT mfma_f32_16x16x32 tiles (NT = 5 | 4), fp32 accumulate, one workgroup per CU (LDS 143 KB, <= 256 VGPRs).
-// * LDS: patch[2] (324 pixels x 128 B, pixel-major, 16-B slot of chunk q of pixel p at q ^ ((p >> 1) & 7): the 16
+// * LDS: patch[2] (324 pixels x 128 B, pixel-major, 16-B slot of chunk q of pixel p at q ^ (p & 7): the 16
 //   consecutive pixels of an MFMA tile read conflict-free at every tap shift) + a 3-slot ring of weight tiles
 //   (row-major 128-B rows, same swizzle as gemm.hip).  Everything arrives by `buffer_load ... lds` (zero padding and the
 //   patch's out-of-image halo are out-of-range offsets: the hardware writes zeros).
@@ -33,21 +33,27 @@
 namespace {
 
 constexpr int TP = 16;                 // output tile: TP x TP pixels of one image
-constexpr int PATCH_MAX = 18 * 18;     // halo patch pixels (3x3 window)
-constexpr int PATCH_BYTES = ((PATCH_MAX + 7) / 8) * 1024;   // whole 1-KiB LDS-DMA pieces (8 pixels x 128 B each)
 
-template <class TT, int NT>
+template <class TT, int NT, int KH, int KW>
 __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
     constexpr int BN = 32 * NT;                    // 160 | 128
-    constexpr int BPIECES = BN / 8;                // 1-KiB LDS-DMA pieces per weight tile (8 rows x 128 B each)
+    constexpr int TAPS = KH * KW;
+    constexpr int PW = TP + KW - 1, PH = TP + KH - 1, NPIX = PW * PH;
+    constexpr int NPIECES = (NPIX + 7) / 8;        // 1-KiB LDS-DMA pieces per patch (8 pixels x 128 B each)
+    constexpr int PATCH_BYTES = NPIECES * 1024;
+    constexpr int PPW = (NPIECES + 7) / 8;         // patch pieces per wave (wave w: pieces w, w + 8, ...)
+    constexpr int BPIECES = BN / 8;                // pieces per weight tile (8 rows x 128 B each)
     constexpr int BSLOT = BN * 128;                // bytes per weight slot
-    constexpr int NB_HI = (BPIECES + 7) / 8, NB_LO = BPIECES / 8;   // pieces per wave: waves < BPIECES % 8 get NB_HI
+    constexpr int NB_HI = (BPIECES + 7) / 8, NB_LO = BPIECES / 8;   // pieces per wave: waves < BPIECES % 8 issue NB_HI
     constexpr int NB_SPLIT = BPIECES % 8;          // (0 = every wave issues NB_LO == NB_HI pieces)
+    // weight ring: the slot of K tile (chunk c, tap) is tap % NSLOT at compile time (TAPS % NSLOT == 0)
+    constexpr int NSLOT = (TAPS % 3 == 0) ? 3 : 4;
+    static_assert(TAPS % NSLOT == 0 && (NSLOT - 1) * BSLOT < 65536, "slot offsets must fold into the ds_read immediate");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    unsigned char* sP = smem_raw;                          // [2][PATCH_BYTES]
-    unsigned char* sB = smem_raw + 2 * PATCH_BYTES;        // [3][BSLOT]
+    unsigned char* sB = smem_raw;                          // [NSLOT][BSLOT]   (first: slot offsets stay < 64 KiB)
+    unsigned char* sP = smem_raw + NSLOT * BSLOT;          // [2][PATCH_BYTES]
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -81,23 +87,24 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : 0u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wt), 0, (int)p.w_bytes, 0x00020000);
 
-    // ---- patch staging map.  Piece j (0 .. npieces-1) = patch pixels 8j .. 8j+7, lane l -> pixel 8j + (l >> 3), LDS slot
-    // l & 7 holds chunk (l & 7) ^ swz(pixel).  Wave w issues pieces w, w + 8, ... (at most 6 of them: 41 pieces / 8 waves).
-    const int PW = TP + p.KW - 1, PH = TP + p.KH - 1, npix = PW * PH;
-    const int npieces = (npix + 7) >> 3;
-    unsigned poff[6], poff2[6];      // byte offset of (pixel, swizzled chunk) in A (window patch) / A2 (1x1 source)
+    // ---- patch staging map.  Piece j = patch pixels 8j .. 8j+7; lane l -> pixel pp = 8j + (l >> 3), LDS 16-B slot l & 7 of
+    // that pixel's 128-B row holds channel chunk (l & 7) ^ (pp & 7) (conflict-free fragment reads at every tap shift).
+    unsigned poff[PPW], poff2[4];      // byte offset of (pixel, swizzled chunk) in A (window patch) / A2 (1x1 source)
+    const unsigned pch = (unsigned)((lane & 7) ^ ((lane >> 3) & 7));
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < PPW; ++i) {
         const int pp = (wave + 8 * i) * 8 + (lane >> 3);
         const int py = pp / PW, px = pp - py * PW;
         const int iy = ty0 - p.pad + py, ix = tx0 - p.pad_x + px;
-        const unsigned ch = (unsigned)((lane & 7) ^ ((pp >> 1) & 7));
-        const bool ok = pp < npix && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        poff[i] = ok ? (unsigned)(((((long)img * p.H + iy) * p.W + ix) * p.lda + ch * 8) * ES) : OOB;
-        // the 1x1 source is staged as a 16 x 16 "patch" without halo: pixel index pp = ly * 16 + lx
+        const bool ok = pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        poff[i] = ok ? (unsigned)(((((long)img * p.H + iy) * p.W + ix) * p.lda + pch * 8) * ES) : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        // the 1x1 source is staged as a 16 x 16 "patch" without halo: pixel index pp = ly * 16 + lx, 32 pieces
+        const int pp = (wave + 8 * i) * 8 + (lane >> 3);
         const int ly = pp >> 4, lx = pp & 15;
-        poff2[i] = (p.A2 && pp < TP * TP)
-                       ? (unsigned)(((((long)img * p.H + ty0 + ly) * p.W + tx0 + lx) * p.lda2 + ch * 8) * ES) : OOB;
+        poff2[i] = p.A2 ? (unsigned)(((((long)img * p.H + ty0 + ly) * p.W + tx0 + lx) * p.lda2 + pch * 8) * ES) : OOB;
     }
     // ---- weight staging map: piece r = rows 8r .. 8r+7 of the tile, lane l -> row 8r + (l >> 3), chunk (l & 7) ^ swz(row)
     unsigned boff[NB_HI];
@@ -109,14 +116,14 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         boff[i] = (piece < BPIECES && n0 + row < p.N) ? (unsigned)((((long)(n0 + row)) * p.ldw + ch * 8) * ES) : OOB;
     }
 
-    const int taps = p.ntaps;
     const int nchunks = p.Cin >> 6;
-    const int T1 = nchunks * taps;                     // K tiles of the window
-    const int T = T1 + (p.A2 ? ((p.K - p.K1) >> 6) : 0);  // + K tiles of the 1x1 source
-    // K tile t: chunk c = t / taps, tap = t % taps (t < T1); 1x1 source chunk t - T1 otherwise ("chunk" nchunks + t - T1)
+    const int T1 = nchunks * TAPS;                        // K tiles of the window
+    const int ntail = p.A2 ? ((p.K - p.K1) >> 6) : 0;     // K tiles of the fused 1x1 source
+    const int T = T1 + ntail;
 
-    auto issue_B = [&](int kt) {
-        unsigned char* dst = sB + (kt % 3) * BSLOT;
+    // weight tile kt -> ring slot `slot` (every K tile is 64 columns = 128 B of every weight row)
+    auto issue_B = [&](int kt, int slot) {
+        unsigned char* dst = sB + slot * BSLOT;
         const unsigned koff = (unsigned)kt * 64u * ES;
 #pragma unroll
         for (int i = 0; i < NB_HI; ++i) {
@@ -126,26 +133,19 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
             }
         }
     };
-    // piece i of this wave for patch "chunk" cidx (cidx < nchunks: window patch of channel chunk cidx; else 1x1 source)
-    auto issue_P = [&](int cidx, int i) {
+    // piece i (compile-time) of this wave for the window patch of channel chunk c
+    auto issue_P = [&](int c, int i) {
         const int piece = wave + 8 * i;
-        unsigned char* dst = sP + (cidx & 1) * PATCH_BYTES + piece * 1024;
-        if (cidx < nchunks) {
-            if (piece < npieces) {
-                const unsigned off = poff[i] != OOB ? poff[i] + (unsigned)cidx * 64u * ES : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(dst), 16, off, 0, 0, 0);
-            }
-        } else if (piece < (TP * TP) / 8) {
-            const unsigned off = poff2[i] != OOB ? poff2[i] + (unsigned)(cidx - nchunks) * 64u * ES : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(dst), 16, off, 0, 0, 0);
+        if (piece < NPIECES) {
+            const unsigned off = poff[i] != OOB ? poff[i] + (unsigned)c * 64u * ES : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(sP + (c & 1) * PATCH_BYTES + piece * 1024), 16, off, 0, 0, 0);
         }
     };
-    const int nchunks_all = nchunks + (T - T1);
-    // K tile (within a chunk) after whose barrier piece i of the next chunk's patch goes out: 3x3 windows spread the six
-    // pieces over their first six K tiles, shorter windows (the 2x2 parity phases) wrap around
-    int pstep[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) pstep[i] = i % taps;
+    // piece i of the 1x1-source "patch" of tail tile u (patch buffer (nchunks + u) & 1)
+    auto issue_P2 = [&](int u, int i) {
+        const unsigned off = poff2[i] + (unsigned)u * 64u * ES;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(sP + ((nchunks + u) & 1) * PATCH_BYTES + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
+    };
 
     f4_t acc[NT][4];  // [n tile j][pixel row i]
 #pragma unroll
@@ -154,37 +154,29 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         for (int i = 0; i < 4; ++i) acc[j][i] = f4_t{0.f, 0.f, 0.f, 0.f};
 
     // weight fragment addresses (constant over the K loop): row = wn * BN/2 + j*16 + fr, 16-B slot (kk*4 + fq) ^ swz(row);
-    // the kk = 1 half is the same address with byte bit 6 flipped
+    // the kk = 1 half is the same address with byte bit 6 flipped; the ring slot is an immediate offset
     unsigned wadr[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int row = wn * (BN / 2) + j * 16 + fr;
         wadr[j] = (unsigned)(row * 128 + ((fq ^ ((row >> 1) & 7)) << 4));
     }
+    const int lane_pp = wm * 4 * PW + fr;     // patch pixel of (pixel row 0 of this wave, tap (0,0))
 
-    auto compute = [&](int kt) {
-        int pbuf, pp0, pw;
-        if (kt < T1) {
-            const int c = kt / taps, tap = kt - c * taps;
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
-            pbuf = c & 1; pw = PW;
-            pp0 = (wm * 4 + ky) * PW + kx + fr;
-        } else {
-            pbuf = (nchunks + kt - T1) & 1; pw = TP;
-            pp0 = wm * 4 * TP + fr;
-        }
-        const unsigned char* sA = sP + pbuf * PATCH_BYTES;
-        const unsigned char* sW = sB + (kt % 3) * BSLOT;
+    // one K tile: fragments of patch pixels lane_pp + ppk + i * pw (i = 0..3) from the patch at byte `pbase`, weight slot
+    // at byte `wbase`; fragment reads are software-pipelined as in gemm.hip (half 1 is read under the MFMAs of half 0)
+    auto compute = [&](unsigned pbase, int ppk, int pw, unsigned wbase) {
+        const unsigned char* sW = sB + wbase;
         V8 af[2][4], bf[2][NT];
         unsigned padr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int pp = pp0 + i * pw;
-            padr[i] = (unsigned)(pp * 128 + ((fq ^ ((pp >> 1) & 7)) << 4));
+            const int pp = lane_pp + ppk + i * pw;
+            padr[i] = pbase + (unsigned)(pp * 128) + (unsigned)((fq ^ (pp & 7)) << 4);
         }
         auto read_half = [&](int kk) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[kk][i] = *reinterpret_cast<const V8*>(sA + (padr[i] ^ (kk << 6)));
+            for (int i = 0; i < 4; ++i) af[kk][i] = *reinterpret_cast<const V8*>(smem_raw + (padr[i] ^ (kk << 6)));
 #pragma unroll
             for (int j = 0; j < NT; ++j) bf[kk][j] = *reinterpret_cast<const V8*>(sW + (wadr[j] ^ (kk << 6)));
         };
@@ -209,17 +201,10 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
             for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[1][j], af[1][i], acc[j][i]);
         __builtin_amdgcn_s_setprio(0);
     };
-
-    // ---- prologue: patch of chunk 0 (all pieces), weight tiles 0 and 1
-#pragma unroll
-    for (int i = 0; i < 6; ++i) issue_P(0, i);
-    issue_B(0);
-    if (T > 1) issue_B(1);
-
-    for (int kt = 0; kt < T; ++kt) {
-        // everything older than this wave's pieces of weight tile kt+1 has landed (LDS-DMA retires in order): tile kt, and
-        // every patch piece issued before it
-        if (kt + 1 < T) {
+    // start of a K-tile period: everything older than this wave's pieces of weight tile kt+1 has landed (LDS-DMA retires in
+    // order): tile kt, and every patch piece issued before it; then the workgroup barrier that publishes them
+    auto period_sync = [&](bool more) {
+        if (more) {
             if (NB_SPLIT == 0 || wave >= NB_SPLIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_LO) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_HI) : "memory");
         } else {
@@ -227,21 +212,49 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        // the patch pieces of the next chunk go out during the first six K tiles of this chunk, oldest first, BEFORE this
-        // period's weight pieces (so the counted wait above covers them one period later)
-        {
-            int cidx, step;
-            if (kt < T1) { cidx = kt / taps; step = kt - cidx * taps; }
-            else { cidx = nchunks + (kt - T1); step = 0; }
-            // a 1x1-source "chunk" lasts one K tile: all of the following chunk's pieces go out at once
-            if (cidx + 1 < nchunks_all) {
+    };
+
+    // ---- prologue: patch of chunk 0 (all pieces), weight tiles 0 and 1
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
-                    if (kt >= T1 || pstep[i] == step) issue_P(cidx + 1, i);   // (register arrays: static indices only)
+    for (int i = 0; i < PPW; ++i) issue_P(0, i);
+    issue_B(0, 0);
+    if (T > 1) issue_B(1, 1 % NSLOT);
+
+    // ---- main loop: chunks x taps, the tap loop fully unrolled (tap offsets, ring slots and the patch-piece schedule are
+    // compile-time; per K tile the scalar side only counts)
+    int kt = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const unsigned pbase = (unsigned)(NSLOT * BSLOT + (c & 1) * PATCH_BYTES);
+        const bool next_window = c + 1 < nchunks;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            period_sync(kt + 1 < T);
+            // the next chunk's patch goes out over this chunk's K tiles, oldest first, BEFORE this period's weight pieces
+            // (so the counted wait covers them one period later)
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                if (i % TAPS == tap) {
+                    if (next_window) issue_P(c + 1, i);
+                    else if (ntail > 0 && i < 4) issue_P2(0, i);
+                }
             }
+            if (kt + 2 < T) issue_B(kt + 2, (tap + 2) % NSLOT);
+            compute(pbase, (tap / KW) * PW + (tap % KW), PW, (unsigned)((tap % NSLOT) * BSLOT));
+            ++kt;
         }
-        if (kt + 2 < T) issue_B(kt + 2);
-        compute(kt);
+    }
+    // ---- tail: the fused 1x1 shortcut -- one 16 x 16-pixel x 64-channel tile of the second source per K tile
+    for (int u = 0; u < ntail; ++u) {
+        period_sync(kt + 1 < T);
+        if (u + 1 < ntail) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_P2(u + 1, i);
+        }
+        if (kt + 2 < T) issue_B(kt + 2, (kt + 2) % NSLOT);
+        // lane_pp is in units of the window patch's pitch: rebase to the halo-free 16-pixel pitch
+        compute((unsigned)(NSLOT * BSLOT + ((nchunks + u) & 1) * PATCH_BYTES), wm * 4 * TP - wm * 4 * PW, TP,
+                (unsigned)((kt % NSLOT) * BSLOT));
+        ++kt;
     }
 
     // ---- wide epilogue (see gemm.hip): per pixel row i, transpose the wave's 16 x WN accumulator rows through LDS in
@@ -367,11 +380,12 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     }
 }
 
-template <class TT, int NT>
+template <class TT, int NT, int KH, int KW>
 int launch_patch(const GemmParams& p, hipStream_t stream) {
-    constexpr int BN = 32 * NT;
-    const size_t lds = 2 * PATCH_BYTES + 3 * (size_t)BN * 128;
-    auto kern = conv_patch_kernel<TT, NT>;
+    constexpr int BN = 32 * NT, TAPS = KH * KW, NSLOT = (TAPS % 3 == 0) ? 3 : 4;
+    constexpr int NPIECES = ((TP + KW - 1) * (TP + KH - 1) + 7) / 8;
+    const size_t lds = 2 * (size_t)NPIECES * 1024 + NSLOT * (size_t)BN * 128;
+    auto kern = conv_patch_kernel<TT, NT, KH, KW>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -383,13 +397,20 @@ int launch_patch(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
 }
 
+template <class TT>
+int launch_patch_dtype(const GemmParams& p, int bn, hipStream_t stream) {
+    if (p.KH == 3 && p.KW == 3) return bn == 160 ? launch_patch<TT, 5, 3, 3>(p, stream) : launch_patch<TT, 4, 3, 3>(p, stream);
+    if (p.KH == 2 && p.KW == 2) return bn == 160 ? launch_patch<TT, 5, 2, 2>(p, stream) : launch_patch<TT, 4, 2, 2>(p, stream);
+    return VF_ERR_SHAPE;
+}
+
 }  // namespace
 
 // 0 = this launch is not a patch-kernel shape; else the channel-tile width (160 | 128) the launch would use
 int vf_conv_patch_tile(const GemmParams& p) {
     if (p.mode != 1 || p.stride != 1 || p.upsample || (p.Cin & 63)) return 0;
     if (p.OH != p.H || p.OW != p.W || (p.H % TP) || (p.W % TP)) return 0;
-    if (p.KH < 1 || p.KW < 1 || p.KH > 3 || p.KW > 3 || p.ntaps != p.KH * p.KW) return 0;
+    if (!((p.KH == 3 && p.KW == 3) || (p.KH == 2 && p.KW == 2)) || p.ntaps != p.KH * p.KW) return 0;
     if (p.pad < 0 || p.pad_x < 0 || p.pad > 1 || p.pad_x > 1) return 0;
     if ((p.flags & (GEMM_GEGLU | GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE | 0x4000)) || (p.N & 7)) return 0;
     if (p.A2 && ((p.K - p.K1) & 63)) return 0;
@@ -404,7 +425,7 @@ int vf_conv_patch_tile(const GemmParams& p) {
 int vf_launch_conv_patch(const GemmParams& p, int dtype, hipStream_t stream) {
     const int bn = vf_conv_patch_tile(p);
     if (!bn) return VF_ERR_SHAPE;
-    if (dtype == VF_DTYPE_F16) return bn == 160 ? launch_patch<F16, 5>(p, stream) : launch_patch<F16, 4>(p, stream);
-    if (dtype == VF_DTYPE_BF16) return bn == 160 ? launch_patch<BF16, 5>(p, stream) : launch_patch<BF16, 4>(p, stream);
+    if (dtype == VF_DTYPE_F16) return launch_patch_dtype<F16>(p, bn, stream);
+    if (dtype == VF_DTYPE_BF16) return launch_patch_dtype<BF16>(p, bn, stream);
     return VF_ERR_DTYPE;
 }
