@@ -34,7 +34,9 @@ namespace {
 
 constexpr int TP = 16;                 // output tile: TP x TP pixels of one image
 
-template <class TT, int NT, int KH, int KW>
+// DIAG: diagnostic build (flag 0x4000, tools/stamp_conv.py; never used by the engine): s_memtime stamps around the parts of
+// the kernel and of every K-tile period; the sums go to the colstats pointer as [workgroup][wave][8] floats and feed no output.
+template <class TT, int NT, int KH, int KW, bool DIAG = false>
 __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
@@ -62,6 +64,16 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     const int fr = lane & 15, fq = lane >> 4;
     constexpr unsigned ES = sizeof(E);
     constexpr unsigned OOB = 0xFFFFFFF0u;
+    auto stamp = [&]() -> unsigned long long {
+        if constexpr (!DIAG) return 0ull;
+        unsigned long long tt;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tt)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        return tt;
+    };
+    const unsigned long long d_t0 = stamp();
+    const unsigned long long d_sync = 0, d_issue = 0, d_comp = 0;
 
     // ---- tile origin: XCD-aware order as in gemm.hip (contiguous run of the tile sequence per XCD; column groups of
     // 8 n-tiles, m-major inside a group)
@@ -89,7 +101,8 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
 
     // ---- patch staging map.  Piece j = patch pixels 8j .. 8j+7; lane l -> pixel pp = 8j + (l >> 3), LDS 16-B slot l & 7 of
     // that pixel's 128-B row holds channel chunk (l & 7) ^ (pp & 7) (conflict-free fragment reads at every tap shift).
-    unsigned poff[PPW], poff2[4];      // byte offset of (pixel, swizzled chunk) in A (window patch) / A2 (1x1 source)
+    constexpr bool TAIL = KH == 3;     // the fused 1x1 source only ever follows a 3x3 window (no registers for it elsewhere)
+    unsigned poff[PPW], poff2[TAIL ? 4 : 1];   // byte offset of (pixel, swizzled chunk) in A (window patch) / A2 (1x1 source)
     const unsigned pch = (unsigned)((lane & 7) ^ ((lane >> 3) & 7));
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
@@ -100,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         poff[i] = ok ? (unsigned)(((((long)img * p.H + iy) * p.W + ix) * p.lda + pch * 8) * ES) : OOB;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < (TAIL ? 4 : 0); ++i) {
         // the 1x1 source is staged as a 16 x 16 "patch" without halo: pixel index pp = ly * 16 + lx, 32 pieces
         const int pp = (wave + 8 * i) * 8 + (lane >> 3);
         const int ly = pp >> 4, lx = pp & 15;
@@ -118,11 +131,12 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
 
     const int nchunks = p.Cin >> 6;
     const int T1 = nchunks * TAPS;                        // K tiles of the window
-    const int ntail = p.A2 ? ((p.K - p.K1) >> 6) : 0;     // K tiles of the fused 1x1 source
+    const int ntail = (TAIL && p.A2) ? ((p.K - p.K1) >> 6) : 0;     // K tiles of the fused 1x1 source
     const int T = T1 + ntail;
 
     // weight tile kt -> ring slot `slot` (every K tile is 64 columns = 128 B of every weight row)
     auto issue_B = [&](int kt, int slot) {
+        if (DIAG && (p.flags & 0x200000) && kt >= 2) return;     // ablation: no LDS-DMA inside the K loop
         unsigned char* dst = sB + slot * BSLOT;
         const unsigned koff = (unsigned)kt * 64u * ES;
 #pragma unroll
@@ -135,6 +149,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     };
     // piece i (compile-time) of this wave for the window patch of channel chunk c
     auto issue_P = [&](int c, int i) {
+        if (DIAG && (p.flags & 0x200000) && c >= 1) return;
         const int piece = wave + 8 * i;
         if (piece < NPIECES) {
             const unsigned off = poff[i] != OOB ? poff[i] + (unsigned)c * 64u * ES : OOB;
@@ -143,7 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     };
     // piece i of the 1x1-source "patch" of tail tile u (patch buffer (nchunks + u) & 1)
     auto issue_P2 = [&](int u, int i) {
-        const unsigned off = poff2[i] + (unsigned)u * 64u * ES;
+        const unsigned off = poff2[TAIL ? i : 0] + (unsigned)u * 64u * ES;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(sP + ((nchunks + u) & 1) * PATCH_BYTES + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
     };
 
@@ -163,54 +178,69 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     }
     const int lane_pp = wm * 4 * PW + fr;     // patch pixel of (pixel row 0 of this wave, tap (0,0))
 
-    // one K tile: fragments of patch pixels lane_pp + ppk + i * pw (i = 0..3) from the patch at byte `pbase`, weight slot
-    // at byte `wbase`; fragment reads are software-pipelined as in gemm.hip (half 1 is read under the MFMAs of half 0)
-    auto compute = [&](unsigned pbase, int ppk, int pw, unsigned wbase) {
-        const unsigned char* sW = sB + wbase;
-        V8 af[2][4], bf[2][NT];
-        unsigned padr[4];
+    // ---- the K-tile pipeline.  A K tile is two k32 halves; per half a wave reads 4 + NT fragments (ds_read_b128) and issues
+    // 4 x NT MFMAs.  Every wave software-pipelines at HALF-tile granularity across the barrier:
+    //     period t:  sync(t) | read h0(t) -> X | MFMA h1(t-1) from Y | read h1(t) -> Y | MFMA h0(t) from X
+    // so after a barrier a wave has 4 x NT MFMAs ready at once (operands in registers since the previous period) and the
+    // LDS latency of the new tile's first reads runs under them; all LDS reads of tile t still happen inside period t (the
+    // 3-slot ring stays valid).  The LDS-DMA issue of the period (~100 cycles per piece, in-order in the wave's stream) is
+    // placed BEFORE the first MFMA batch (optionally, for A/B runs, BETWEEN the two batches by waves 4..7, the SIMD partners
+    // of waves 0..3: MI355X_MICROARCH.md "Two waves per SIMD").  Every accumulator sees its MFMAs in the order (tile t half 0, tile t half 1, tile t+1 half 0, ...),
+    // the same as gemm.hip: the output bits do not change.
+    V8 afX[4], bfX[NT], afY[4], bfY[NT];
+    unsigned padr[4];
+    bool abl_reads = false;
+    auto read_h0 = [&](unsigned pbase, int ppk, int pw, unsigned wbase) {
+        if (DIAG && abl_reads) return;                           // ablation: fragments stay what the first K tile read
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int pp = lane_pp + ppk + i * pw;
             padr[i] = pbase + (unsigned)(pp * 128) + (unsigned)((fq ^ (pp & 7)) << 4);
         }
-        auto read_half = [&](int kk) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[kk][i] = *reinterpret_cast<const V8*>(smem_raw + (padr[i] ^ (kk << 6)));
+        for (int i = 0; i < 4; ++i) afX[i] = *reinterpret_cast<const V8*>(smem_raw + padr[i]);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[kk][j] = *reinterpret_cast<const V8*>(sW + (wadr[j] ^ (kk << 6)));
-        };
-        constexpr int JH = NT / 2;
-        read_half(0);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < NT; ++j) bfX[j] = *reinterpret_cast<const V8*>(sB + wbase + wadr[j]);
+    };
+    auto read_h1 = [&](unsigned wbase) {
+        if (DIAG && abl_reads) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) afY[i] = *reinterpret_cast<const V8*>(smem_raw + (padr[i] ^ 64u));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bfY[j] = *reinterpret_cast<const V8*>(sB + wbase + (wadr[j] ^ 64u));
+    };
+    auto mfma_X = [&]() {
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int j = 0; j < JH; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[0][j], af[0][i], acc[j][i]);
-        __builtin_amdgcn_sched_barrier(0);
-        read_half(1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = JH; j < NT; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[0][j], af[0][i], acc[j][i]);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bf[1][j], af[1][i], acc[j][i]);
+            for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bfX[j], afX[i], acc[j][i]);
         __builtin_amdgcn_s_setprio(0);
     };
+    auto mfma_Y = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = TT::mfma32(bfY[j], afY[i], acc[j][i]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // measured (tools/bench_kernels.py, 7 UNet shapes): the same order in all waves is 3..12 % faster on 6 of 7 shapes than
+    // the split placement; the split stays selectable for A/B runs (flag GEMM_NO_SETPRIO, unused otherwise by this kernel)
+    const bool late = wave >= 4 && (p.flags & GEMM_NO_SETPRIO);
+    float* const diag_out = DIAG ? p.colstats : nullptr;
+    if (DIAG) p.colstats = nullptr;
     // start of a K-tile period: everything older than this wave's pieces of weight tile kt+1 has landed (LDS-DMA retires in
     // order): tile kt, and every patch piece issued before it; then the workgroup barrier that publishes them
     auto period_sync = [&](bool more) {
+        if (DIAG && (p.flags & 0x200000)) { if (!(p.flags & 0x400000)) __builtin_amdgcn_s_barrier(); return; }   // ablation: no DMA wait
         if (more) {
             if (NB_SPLIT == 0 || wave >= NB_SPLIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_LO) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_HI) : "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
+        if (!(DIAG && (p.flags & 0x400000))) __builtin_amdgcn_s_barrier();                                        // ablation: no barrier
         asm volatile("" ::: "memory");
     };
 
@@ -222,6 +252,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
 
     // ---- main loop: chunks x taps, the tap loop fully unrolled (tap offsets, ring slots and the patch-piece schedule are
     // compile-time; per K tile the scalar side only counts)
+    const unsigned long long d_t1 = stamp();
     int kt = 0;
     for (int c = 0; c < nchunks; ++c) {
         const unsigned pbase = (unsigned)(NSLOT * BSLOT + (c & 1) * PATCH_BYTES);
@@ -229,33 +260,53 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             period_sync(kt + 1 < T);
+            // read_h0 first: its LDS latency runs under the MFMAs of the previous tile's second half
+            read_h0(pbase, (tap / KW) * PW + (tap % KW), PW, (unsigned)((tap % NSLOT) * BSLOT));
+            __builtin_amdgcn_sched_barrier(0);
+            if (late && kt > 0) { mfma_Y(); __builtin_amdgcn_sched_barrier(0); }
             // the next chunk's patch goes out over this chunk's K tiles, oldest first, BEFORE this period's weight pieces
             // (so the counted wait covers them one period later)
 #pragma unroll
             for (int i = 0; i < PPW; ++i) {
                 if (i % TAPS == tap) {
                     if (next_window) issue_P(c + 1, i);
-                    else if (ntail > 0 && i < 4) issue_P2(0, i);
+                    else if (TAIL && ntail > 0 && i < 4) issue_P2(0, i);
                 }
             }
             if (kt + 2 < T) issue_B(kt + 2, (tap + 2) % NSLOT);
-            compute(pbase, (tap / KW) * PW + (tap % KW), PW, (unsigned)((tap % NSLOT) * BSLOT));
+            __builtin_amdgcn_sched_barrier(0);
+            if (!late && kt > 0) { mfma_Y(); __builtin_amdgcn_sched_barrier(0); }
+            read_h1((unsigned)((tap % NSLOT) * BSLOT));
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_X();
+            __builtin_amdgcn_sched_barrier(0);
             ++kt;
+            if (DIAG && (p.flags & 0x800000)) abl_reads = true;
         }
     }
     // ---- tail: the fused 1x1 shortcut -- one 16 x 16-pixel x 64-channel tile of the second source per K tile
     for (int u = 0; u < ntail; ++u) {
         period_sync(kt + 1 < T);
+        const unsigned wb = (unsigned)((kt % NSLOT) * BSLOT);
+        // lane_pp is in units of the window patch's pitch: rebase to the halo-free 16-pixel pitch
+        read_h0((unsigned)(NSLOT * BSLOT + ((nchunks + u) & 1) * PATCH_BYTES), wm * 4 * TP - wm * 4 * PW, TP, wb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (late) { mfma_Y(); __builtin_amdgcn_sched_barrier(0); }
         if (u + 1 < ntail) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) issue_P2(u + 1, i);
         }
         if (kt + 2 < T) issue_B(kt + 2, (kt + 2) % NSLOT);
-        // lane_pp is in units of the window patch's pitch: rebase to the halo-free 16-pixel pitch
-        compute((unsigned)(NSLOT * BSLOT + ((nchunks + u) & 1) * PATCH_BYTES), wm * 4 * TP - wm * 4 * PW, TP,
-                (unsigned)((kt % NSLOT) * BSLOT));
+        __builtin_amdgcn_sched_barrier(0);
+        if (!late) { mfma_Y(); __builtin_amdgcn_sched_barrier(0); }
+        read_h1(wb);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_X();
+        __builtin_amdgcn_sched_barrier(0);
         ++kt;
     }
+    mfma_Y();      // the last half tile
+    const unsigned long long d_t2 = stamp();
 
     // ---- wide epilogue (see gemm.hip): per pixel row i, transpose the wave's 16 x WN accumulator rows through LDS in
     // fp32, sum bias / row bias / residual, round once, 16 B per lane
@@ -378,6 +429,15 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
             }
         }
     }
+    if constexpr (DIAG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long d_t3 = stamp();
+        if (lane == 0 && diag_out) {
+            float* d = diag_out + ((long)blockIdx.x * 8 + wave) * 8;
+            d[0] = (float)(d_t1 - d_t0); d[1] = (float)(d_t2 - d_t1); d[2] = (float)(d_t3 - d_t2);
+            d[3] = (float)d_sync; d[4] = (float)d_issue; d[5] = (float)d_comp; d[6] = (float)T; d[7] = 0.f;
+        }
+    }
 }
 
 template <class TT, int NT, int KH, int KW>
@@ -386,11 +446,15 @@ int launch_patch(const GemmParams& p, hipStream_t stream) {
     constexpr int NPIECES = ((TP + KW - 1) * (TP + KH - 1) + 7) / 8;
     const size_t lds = 2 * (size_t)NPIECES * 1024 + NSLOT * (size_t)BN * 128;
     auto kern = conv_patch_kernel<TT, NT, KH, KW>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if constexpr (NT == 5 && KH == 3 && sizeof(typename TT::elem) == 2) {
+        if (p.flags & 0x4000) kern = conv_patch_kernel<TT, NT, KH, KW, true>;     // diagnostic stamps (tools/stamp_conv.py)
+    }
+    static bool attr_set[2] = {false, false};
+    const bool diag = (p.flags & 0x4000) != 0;
+    if (!attr_set[diag]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VF_ERR_LAUNCH;
-        attr_set = true;
+        attr_set[diag] = true;
     }
     const int ntm = (p.M / (p.OH * p.OW)) * (p.H / TP) * (p.W / TP), ntn = p.N / BN;
     hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(512), lds, stream, p);
@@ -412,8 +476,9 @@ int vf_conv_patch_tile(const GemmParams& p) {
     if (p.OH != p.H || p.OW != p.W || (p.H % TP) || (p.W % TP)) return 0;
     if (!((p.KH == 3 && p.KW == 3) || (p.KH == 2 && p.KW == 2)) || p.ntaps != p.KH * p.KW) return 0;
     if (p.pad < 0 || p.pad_x < 0 || p.pad > 1 || p.pad_x > 1) return 0;
-    if ((p.flags & (GEMM_GEGLU | GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE | 0x4000)) || (p.N & 7)) return 0;
-    if (p.A2 && ((p.K - p.K1) & 63)) return 0;
+    if ((p.flags & (GEMM_GEGLU | GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE)) || (p.N & 7)) return 0;
+    if ((p.flags & 0x4000) && !(p.KH == 3 && p.N % 160 == 0 && p.colstats)) return 0;   // diagnostic build: one instantiation
+    if (p.A2 && (((p.K - p.K1) & 63) || p.KH != 3)) return 0;
     if (p.colstats && ((p.H * p.W) & 63)) return 0;
     if (p.residual && !p.res_f32 && (((uintptr_t)p.residual & 15) || (p.ldr & 7))) return 0;
     if (((uintptr_t)p.C & 15) || (p.C && (p.ldc & 7))) return 0;
