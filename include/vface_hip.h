@@ -179,6 +179,13 @@ int vface_flow_warp(const void* src, int64_t ld_src, int64_t fs_src, const void*
                     int h, int w, int C, float alpha, float one_minus_alpha, int flags, int32_t* dbg_x0,
                     int32_t* dbg_y0, int dtype, void* stream);
 
+/* Pixel-resolution optical flow -> the latent-resolution field vface_flow_warp takes.  The reference computes
+ * RAFT flow between full-resolution frames (temporal_flow.py:163-188 `return_flow`; call site VFace_inference_batch.py:
+ * 550-553) and hands it UNRESIZED to the warp of the 64 x 64 maps, where `grid + flow` fails (temporal_flow.py:43); the
+ * resample is defined here: out[p][c][y][x] = mean(flow_px[p][c][y*f .. y*f+f-1][x*f .. x*f+f-1]) / f   (fp32 in and out;
+ * H, W multiples of `factor`).  RAFT's own weights are third-party: the flow VALUES are outside this library. */
+int vface_flow_to_latent(const float* flow_px, float* out, int pairs, int H, int W, int factor, void* stream);
+
 /* The hooked self-attention as one call (pnp_utils.py:94-287, the closure installed on attn1):
  *   x [B][n][d] (already LayerNorm'd), B = chunks * F laid out [uncond ; cond ; recon]
  *   Wqkv [3d][d]  = rows of to_q | to_k | to_v

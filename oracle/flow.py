@@ -12,12 +12,17 @@ from typing import Sequence, Tuple
 import torch
 
 
-def sample_coords(flow: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def sample_coords(flow: torch.Tensor, cuda_recip_div: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Un-normalised, border-clamped sampling coordinates (ix, iy), each ``[H,W]`` fp32, for one flow
     field ``[2,H,W]`` (channel 0 = dx, 1 = dy, in pixels of the map being warped).
 
     temporal_flow.py:43-49: ``vgrid = grid + flow``; ``g = 2.0*v/max(W-1,1) - 1.0``.
     ATen GridSampler (align_corners=True): ``ix = ((g + 1) / 2) * (W - 1)``; border: clamp to [0, W-1].
+
+    ``cuda_recip_div``: the tensor / python-scalar division ``2.0*v / max(W-1, 1)`` is a true division in CPU ATen (where
+    the golden vectors were made) but CUDA ATen's ``div`` by a scalar multiplies by the fp32 reciprocal
+    (``a * (1 / b)``, BinaryDivTrueKernel.cu): the coordinate differs in its last ulp for most inputs and ``floor`` differs
+    next to integers.  This flag EMULATES that form (the reference cannot be run on its native device here).
     """
     assert flow.dtype == torch.float32 and flow.dim() == 3 and flow.shape[0] == 2
     _, H, W = flow.shape
@@ -25,8 +30,14 @@ def sample_coords(flow: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     ys = torch.arange(H, dtype=torch.float32).view(H, 1).expand(H, W)
     vx = xs + flow[0]
     vy = ys + flow[1]
-    gx = 2.0 * vx / float(max(W - 1, 1)) - 1.0
-    gy = 2.0 * vy / float(max(H - 1, 1)) - 1.0
+    if cuda_recip_div:
+        rw = torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(max(W - 1, 1)), dtype=torch.float32)
+        rh = torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(max(H - 1, 1)), dtype=torch.float32)
+        gx = (2.0 * vx) * rw - 1.0
+        gy = (2.0 * vy) * rh - 1.0
+    else:
+        gx = 2.0 * vx / float(max(W - 1, 1)) - 1.0
+        gy = 2.0 * vy / float(max(H - 1, 1)) - 1.0
     ix = ((gx + 1.0) / 2.0) * float(W - 1)
     iy = ((gy + 1.0) / 2.0) * float(H - 1)
     ix = torch.clamp(ix, 0.0, float(W - 1))
@@ -34,9 +45,9 @@ def sample_coords(flow: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return ix, iy
 
 
-def gather_indices(flow: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def gather_indices(flow: torch.Tensor, cuda_recip_div: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     """Integer north-west corner (x0, y0) of the bilinear footprint, int32 ``[H,W]`` each."""
-    ix, iy = sample_coords(flow)
+    ix, iy = sample_coords(flow, cuda_recip_div)
     return torch.floor(ix).to(torch.int32), torch.floor(iy).to(torch.int32)
 
 
@@ -86,3 +97,14 @@ def align_by_flow(x: torch.Tensor, flow: Sequence[torch.Tensor], alpha: float) -
         # (1-alpha)*warped is fp32, the sum is fp32 and is rounded to x's dtype on store.
         out[i + 1] = (alpha * x[i + 1] + (1.0 - alpha) * warped).to(x.dtype)
     return out
+
+
+def flow_to_latent(flow_px: torch.Tensor, factor: int = 8) -> torch.Tensor:
+    """the reference computes RAFT flow between 512 x 512 frames (``temporal_flow.py:163-188`` ``return_flow``,
+    call site ``VFace_inference_batch.py:550-553``) and hands it, unresized, to a warp of the 64 x 64 attention maps, where
+    ``grid + flow`` fails on the shape mismatch -- the resample it needs is not defined anywhere in the
+    reference.  This build defines it as the area mean over each ``factor x factor`` block of pixels, divided by ``factor``
+    (a displacement of d pixels is d / factor latent cells): ``[P, 2, H, W]`` -> ``[P, 2, H/factor, W/factor]``, fp32.
+    (RAFT itself is third-party ``torchvision==0.14.1`` weights, absent here: parity of the flow VALUES is unpinned.)"""
+    assert flow_px.dim() == 4 and flow_px.shape[1] == 2 and flow_px.shape[2] % factor == 0 and flow_px.shape[3] % factor == 0
+    return torch.nn.functional.avg_pool2d(flow_px.float(), factor) / float(factor)

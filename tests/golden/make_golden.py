@@ -132,6 +132,21 @@ def gen_warp():
     save("warp", **out)
 
 
+def gen_warp_cuda_form():
+    """Gather indices of the six flow cases under CUDA-ATen's scalar division (multiply by the fp32 reciprocal) -- EMULATED
+    by the oracle (oracle/flow.py::sample_coords(cuda_recip_div=True)): the reference cannot run on its native device in
+    this container, so this fixture pins the kernel's `flags bit 0` path to the restated rule, not to a reference run."""
+    from oracle import flow as oflow
+    out = {}
+    for name, fl in make_flows(1, 64, 64).items():
+        f = torch.from_numpy(fl)
+        x0, y0 = oflow.gather_indices(f, cuda_recip_div=True)
+        cx0, cy0 = oflow.gather_indices(f, cuda_recip_div=False)
+        out[f"x0_{name}"], out[f"y0_{name}"] = x0, y0
+        out[f"ndiff_{name}"] = int(((x0 != cx0) | (y0 != cy0)).sum())
+    save("warp_cuda_form", **out)
+
+
 def ref_unet(model_channels, fill_seed=0):
     from ldm.modules.diffusionmodules.openaimodel import UNetModel
     m = UNetModel(image_size=32, in_channels=9, out_channels=4, model_channels=model_channels,
@@ -432,7 +447,7 @@ if __name__ == "__main__":
     install_stubs()
     import builtins
     _print = builtins.print
-    gens = {"fsai": gen_fsai, "warp": gen_warp, "attn": gen_attn_module, "tiny": gen_tiny_unet, "ddim": gen_ddim,
+    gens = {"fsai": gen_fsai, "warp": gen_warp, "warp_cuda": gen_warp_cuda_form, "attn": gen_attn_module, "tiny": gen_tiny_unet, "ddim": gen_ddim,
             "vae": gen_vae}
     gens["lowp"] = lambda: gen_lowp(a.full)
     if a.full:

@@ -723,3 +723,42 @@ def test_conv_patch_kernel_fp32_stream_shortcut_and_phases():
         assert rel_l2(a, c) < 1e-5
     y = got["patch"][3].double().reshape(nimg, H * W, cout)
     assert rel_l2(got["patch"][5][..., 0], y.sum(1)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ flow: CUDA-form indices, latent resample
+def test_flow_warp_cuda_form_indices_vs_emulated_fixture():
+    """flags bit 0 of vface_flow_warp (`cuda_recip_div`): the scalar division of the coordinate normalisation as CUDA ATen
+    performs it (multiply by the fp32 reciprocal) -- what the reference computes on its native device.  Bit-exact against
+    tests/golden/warp_cuda_form.npz, which the ORACLE's restatement of that rule produced ("CUDA-form, emulated": the
+    reference cannot run on CUDA here); and it really is a different rule: integer-valued flows floor differently."""
+    h = hip()
+    g = load_golden("warp_cuda_form")
+    gc = load_golden("warp")
+    cases = _flow_cases()
+    names = list(cases)
+    F_ = len(names) + 1
+    src = torch.zeros(F_, 4096, 8, dtype=torch.float16, device=DEV)
+    flow = torch.stack([cases[n] for n in names]).to(DEV)
+    dst = torch.empty_like(src)
+    x0 = torch.empty(F_ - 1, 64, 64, dtype=torch.int32, device=DEV)
+    y0 = torch.empty_like(x0)
+    h.flow_warp(src, dst, flow, F=F_, h=64, w=64, C_=8, ld_src=8, fs_src=4096 * 8, ld_dst=8, fs_dst=4096 * 8,
+                alpha=0.0, dbg_x0=x0, dbg_y0=y0, cuda_recip_div=True)
+    ndiff = 0
+    for i, n in enumerate(names):
+        assert torch.equal(x0[i].cpu(), g[f"x0_{n}"]), n
+        assert torch.equal(y0[i].cpu(), g[f"y0_{n}"]), n
+        ndiff += int(((x0[i].cpu() != gc[f"x0_{n}"]) | (y0[i].cpu() != gc[f"y0_{n}"])).sum())
+    assert ndiff > 500       # zero / integer flows sit on the floor() boundary: the two division forms disagree there
+
+
+def test_flow_to_latent_matches_oracle():
+    """512x512 flow -> 64x64 (area mean / 8), and other factors, against the oracle's definition."""
+    h = hip()
+    from oracle import flow as oflow
+    from vface_amd.utils import synth
+    for P, H, W, f in ((3, 512, 512, 8), (2, 96, 64, 4), (1, 768, 768, 8)):
+        fl = synth.synth_flow(P, H, W) * f + 0.25 * synth.synth_normal("f2l", (P, 2, H, W))
+        got = h.flow_to_latent(fl.to(DEV), f).cpu()
+        ref = oflow.flow_to_latent(fl, f)
+        assert got.shape == ref.shape and (got - ref).abs().max() < 2e-5

@@ -345,3 +345,71 @@ def test_full_size_768_latent_flow_fix_dependency_window():
     assert not torch.equal(tail[:, 0], whole[:, 1])
     single = _full_run("fft", frames, 0, 1, h)
     assert torch.equal(single[:, 0], whole[:, 0])        # frame 0 is never smoothed (temporal_flow.py:229)
+
+
+def test_reference_flow_gate_is_the_default_and_pixel_flow_is_resampled(small):
+    """(a) pnp_utils.py:201 warps only 4096-token maps: with the default gate a 32x32 clip's `flow_fix` equals `fft` bit for
+    bit (the reference silently skips the warp there); the generalised gate (`flow_gate="flow_hw"`) does warp.
+    (b) SURVEY F8 / 8f-3: a pixel-resolution field raises like the reference unless `flow_resample="area"`, and then equals a
+    run that was handed the latent-resolution field the oracle's resample produces."""
+    from oracle import flow as oflow
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler
+    ldm, _, _ = small
+    h = w = 32
+    F_ = 2
+    x = synth.synth_normal("small.x", (6, 9, h, w)).to(DEV)
+    ctx = synth.synth_normal("small.ctx", (6, 1, 768)).to(DEV)
+    t = torch.full((6,), 481, dtype=torch.long, device=DEV)
+    flow = [synth.synth_flow(F_ - 1, h, w)[i][None] for i in range(F_ - 1)]
+    outs = {}
+    for gate in (None, "flow_hw"):
+        sampler = DDIMSampler(ldm)
+        if gate:
+            sampler.flow_gate = gate
+        for mode in ("in_fft", "in_flow_fix"):
+            _register(sampler, mode, flow)
+            outs[(gate, mode)] = ldm.apply_model(x, t, ctx).float().cpu()
+    assert torch.equal(outs[(None, "in_flow_fix")], outs[(None, "in_fft")])
+    assert torch.equal(outs[("flow_hw", "in_fft")], outs[(None, "in_fft")])
+    assert not torch.equal(outs[("flow_hw", "in_flow_fix")], outs[("flow_hw", "in_fft")])
+    # (b) through the sampler's loop, two steps
+    z = synth.synth_normal("gate.z", (F_, 4, h, w)).to(DEV)
+    cc = synth.synth_normal("gate.c", (F_, 1, 768)).to(DEV)
+    inv = {int(s): z for s in oddim.ddim_timesteps(50)}
+    fpx = synth.synth_flow(F_ - 1, 8 * h, 8 * w) * 8.0
+    kw = dict(S=50, batch_size=F_, shape=[4, h, w], conditioning=cc, target_conditioning=cc, inverse_results_dir=inv,
+              verbose=False, unconditional_guidance_scale=3.0, unconditional_conditioning=cc, x_T=z,
+              test_model_kwargs={"inpaint_image": z, "inpaint_mask": z[:, :1]}, max_steps=2)
+    s1 = DDIMSampler(ldm); s1.flow_gate = "flow_hw"
+    with pytest.raises(RuntimeError):
+        s1.sample(flow=[f[None] for f in fpx], **kw)
+    s1.flow_resample = "area"
+    a, _ = s1.sample(flow=[f[None] for f in fpx], **kw)
+    s2 = DDIMSampler(ldm); s2.flow_gate = "flow_hw"
+    b, _ = s2.sample(flow=[f[None] for f in oflow.flow_to_latent(fpx, 8)], **kw)
+    assert (a - b).abs().max() < 2e-3 and torch.isfinite(a).all()
+
+
+def test_full_size_config4_share_flow_fix_16_frames():
+    """BASELINE configs[3] -- 64 frames, flow-guided smoothing, 4 GPUs -- at its per-GPU size: 16 frames at 64x64 latents
+    with the shipped schedule (flow_fix on the input-block attn1).  No oracle finishes at this size; checked through the
+    path's own invariants: a frame depends on exactly two predecessors (two hooked level-0 layers, each reading one
+    neighbour), so frames 8..15 computed from a run that starts at frame 6 must equal the whole clip bit for bit -- which
+    is also what a shard boundary relies on -- and the first frames of that run must not."""
+    h, frames = 64, 16
+    flow_all = synth.synth_flow(frames - 1, h, h)
+    whole = _full_run("flow_fix", frames, 0, frames, h, flow_all)
+    part = _full_run("flow_fix", frames, 6, 10, h, flow_all)
+    assert torch.equal(part[:, 2:], whole[:, 8:])
+    assert not torch.equal(part[:, 0], whole[:, 6]) and not torch.equal(part[:, 1], whole[:, 7])
+
+
+def test_full_size_config5_share_32_frames_at_768():
+    """BASELINE configs[4] -- 256 frames at 768x768, all three modules, 8 GPUs -- at its per-GPU size: 32 frames at 96x96
+    latents (96 samples, n = 9216 tokens at level 0), flow_fix with the generalised gate.  Same invariants as above."""
+    h, frames = 96, 32
+    flow_all = synth.synth_flow(frames - 1, h, h)
+    whole = _full_run("flow_fix", frames, 0, frames, h, flow_all)
+    part = _full_run("flow_fix", frames, 22, 10, h, flow_all)
+    assert torch.equal(part[:, 2:], whole[:, 24:])
+    assert not torch.equal(part[:, 1], whole[:, 23])

@@ -17,7 +17,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != c:
             continue
-        m = re.search(r"(gemm_kernel|attn_kernel|gn_apply_kernel|layernorm_kernel|splitk_reduce_kernel)<([^>]*)>", r["Kernel_Name"])
+        m = re.search(r"(conv_patch_kernel|gemm_kernel|attn_kernel|gn_apply_kernel|layernorm_kernel|splitk_reduce_kernel)<([^>]*)>", r["Kernel_Name"])
         key = (m.group(1) + "<" + m.group(2) + ">") if m else "other"
         agg[key].append(float(r["Counter_Value"]))
     res[c] = {k: (len(v), sum(v)) for k, v in agg.items()}
@@ -27,10 +27,10 @@ for k in sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"])):
     n = max(nf, nw)
     summary[k] = {"launches": n, "fetch_kb_raw_per_launch": f / max(nf, 1), "write_kb_per_launch": w / max(nw, 1),
                   "hbm_bytes_per_launch": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0}
-conv = [v for k, v in summary.items() if re.match(r"gemm_kernel<\w+, [12],", k)]
+conv = [v for k, v in summary.items() if re.match(r"gemm_kernel<\w+, [12],", k) or k.startswith("conv_patch_kernel")]
 tot_l = sum(v["launches"] for v in conv)
 summary["_conv_all"] = {"launches": tot_l, "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in conv) / max(tot_l, 1),
-                        "note": "implicit-GEMM conv launches (MODE 1|2), bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024, averaged per launch"}
+                        "note": "conv launches (conv_patch_kernel + gemm_kernel MODE 1|2), bytes = (2*FETCH_SIZE + WRITE_SIZE) KB * 1024, averaged per launch"}
 json.dump(summary, open(out, "w"), indent=1)
 for k, v in summary.items():
     print(k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in v.items()})

@@ -180,6 +180,10 @@ int vface_flow_warp(const void* src, int64_t ld_src, int64_t fs_src, const void*
                                alpha, one_minus_alpha, flags, dbg_x0, dbg_y0, dtype, S(stream));
 }
 
+int vface_flow_to_latent(const float* flow_px, float* out, int pairs, int H, int W, int factor, void* stream) {
+    return vf_launch_flow_to_latent(flow_px, out, pairs, H, W, factor, S(stream));
+}
+
 size_t vface_attn1_workspace_bytes(int B, int n, int d, int chunks) {
     if (B <= 0 || n <= 0 || d <= 0 || chunks <= 0) return 0;
     const size_t F = (size_t)B / chunks;

@@ -310,6 +310,26 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(const typename TT::elem*
     }
 }
 
+// Pixel-resolution optical flow -> latent-resolution flow (the resample temporal_flow.py:163-188's output needs
+// before it can meet a 64 x 64 attention map): area mean over each f x f block, divided by f.
+// flow_px [P][2][H][W] fp32 -> out [P][2][H/f][W/f] fp32.  One thread per output element, rows of the block read with
+// consecutive threads on consecutive blocks (f floats apart: every byte of a row is still used by the wave).
+__global__ __launch_bounds__(256) void flow_to_latent_kernel(const float* __restrict__ src, float* __restrict__ dst, long planes,
+                                                             int H, int W, int f) {
+    const int h = H / f, w = W / f;
+    const long total = planes * h * w;
+    const float inv = 1.0f / ((float)f * (float)f * (float)f);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int x = (int)(i % w), y = (int)((i / w) % h);
+        const long pl = i / ((long)w * h);
+        const float* b = src + (pl * H + (long)y * f) * W + (long)x * f;
+        float acc = 0.f;
+        for (int r = 0; r < f; ++r)
+            for (int c = 0; c < f; ++c) acc += b[(long)r * W + c];
+        dst[i] = acc * inv;
+    }
+}
+
 // ------------------------------------------------------------------------------------------ inactive hook modes
 // fusion="temporal" (pnp_utils.py:59-90,145-154): Gaussian-weighted mean over the FRAME axis of chunk 0's q|k
 // (window 5, sigma 1, renormalised at the clip ends), written to chunk 1 and chunk 2.  fp32 math, one rounding.
@@ -754,6 +774,15 @@ int vf_launch_flow_warp(const void* src, long ld_src, long fs_src, const void* p
                            (const E*)prev, ld_prev, flow, flow_prev, (E*)dst, ld_dst, fs_dst, F, h, w, C, alpha, one_minus_alpha, flags,
                            dbg_x0, dbg_y0);
     });
+    return ok();
+}
+
+int vf_launch_flow_to_latent(const float* flow_px, float* out, int pairs, int H, int W, int factor, hipStream_t stream) {
+    if (!flow_px || !out || pairs <= 0 || H <= 0 || W <= 0 || factor <= 0) return VF_ERR_ARG;
+    if ((H % factor) || (W % factor)) return VF_ERR_SHAPE;
+    const long total = (long)pairs * 2 * (H / factor) * (W / factor);
+    hipLaunchKernelGGL(flow_to_latent_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, stream, flow_px, out, (long)pairs * 2,
+                       H, W, factor);
     return ok();
 }
 

@@ -86,6 +86,7 @@ int vf_launch_flow_warp(const void* src, long ld_src, long fs_src, const void* p
                         const float* flow, const float* flow_prev, void* dst, long ld_dst, long fs_dst, int F, int h,
                         int w, int C, float alpha, float one_minus_alpha, int flags, int* dbg_x0, int* dbg_y0, int dtype,
                         hipStream_t stream);
+int vf_launch_flow_to_latent(const float* flow_px, float* out, int pairs, int H, int W, int factor, hipStream_t stream);
 int vf_launch_timestep_embedding(const long long* t, void* out, int N, int dim, int dtype, hipStream_t stream);
 int vf_launch_silu(const void* x, void* y, long count, int in_f32, int dtype, hipStream_t stream);
 int vf_launch_softmax_rows(const float* S, long lds_, void* P, long ldp, int M, int N, float scale, int dtype, hipStream_t stream);

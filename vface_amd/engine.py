@@ -263,9 +263,11 @@ def _phase_form_pays(hw_in: int, cout: int) -> bool:
 class UNetEngine:
     """Packed weights + kernel sequencing for one ``UNetModel``."""
 
-    def __init__(self, unet, dtype: torch.dtype = torch.float16):
+    def __init__(self, unet, dtype: torch.dtype = torch.float16, device=None):
+        """``unet=None``: an engine for stand-alone sub-modules (``vface_amd.module_exec``); ``device`` is then required."""
         self.unet = unet
         self.dtype = dtype
+        self._device = torch.device(device) if device is not None else None
         self._packed: Dict[str, dict] = {}
         self._maps: Dict[tuple, torch.Tensor] = {}
         self._version = None
@@ -281,7 +283,7 @@ class UNetEngine:
     # ------------------------------------------------------------------ weights
     @property
     def device(self):
-        return next(self.unet.parameters()).device
+        return self._device if self._device is not None else next(self.unet.parameters()).device
 
     def _w16(self, t: torch.Tensor) -> torch.Tensor:
         return t.detach().to(device=self.device, dtype=self.dtype).contiguous()
@@ -298,15 +300,8 @@ class UNetEngine:
         sd = {k: v.detach() for k, v in u.state_dict().items()}
         cpu = lambda k: sd[k].float().cpu()
 
-        def conv3(prefix):
-            return {"w": self._w16(packing.pack_conv3x3(cpu(prefix + ".weight"))),
-                    "b": self._f32(sd[prefix + ".bias"]), "cin": sd[prefix + ".weight"].shape[1],
-                    "cinp": (sd[prefix + ".weight"].shape[1] + 7) // 8 * 8, "cout": sd[prefix + ".weight"].shape[0]}
-
-        def lin(prefix, bias=True, conv=False):
-            w = sd[prefix + ".weight"]
-            w = w.reshape(w.shape[0], w.shape[1]) if conv else w
-            return {"w": self._w16(w), "b": self._f32(sd[prefix + ".bias"]) if bias else None}
+        conv3 = lambda prefix: self.pack_conv3(sd, prefix)
+        lin = lambda prefix, bias=True, conv=False: self.pack_lin(sd, prefix, bias, conv)
 
         P["time_embed.0"] = lin("time_embed.0")
         P["time_embed.2"] = lin("time_embed.2")
@@ -318,22 +313,9 @@ class UNetEngine:
             elif kind == "down":
                 P[prefix] = conv3(prefix + ".op")
             elif kind == "up":
-                P[prefix] = conv3(prefix + ".conv")
-                # nearest x2 + conv3x3 = four parity-phase 2x2 convs with pre-summed taps (4/9 of the multiply-adds)
-                P[prefix]["phases"] = self._w16(packing.pack_upsample_phases(cpu(prefix + ".conv.weight")))
+                P[prefix] = self.pack_up(sd, prefix + ".conv")
             elif kind == "res":
-                d = {"in_gn": (self._f32(sd[prefix + ".in_layers.0.weight"]), self._f32(sd[prefix + ".in_layers.0.bias"])),
-                     "conv1": conv3(prefix + ".in_layers.2"),
-                     "out_gn": (self._f32(sd[prefix + ".out_layers.0.weight"]), self._f32(sd[prefix + ".out_layers.0.bias"])),
-                     "conv2": conv3(prefix + ".out_layers.3")}
-                if (prefix + ".skip_connection.weight") in sd:
-                    d["skip"] = lin(prefix + ".skip_connection", conv=True)
-                    wsk = sd[prefix + ".skip_connection.weight"]
-                    if d["conv2"]["cinp"] % 64 == 0 and wsk.shape[1] % 64 == 0:
-                        # second conv + 1x1 shortcut in one K loop (vface_conv3x3_plus_1x1): weights side by side, biases summed
-                        d["conv2_skip"] = dict(d["conv2"], c2=wsk.shape[1],
-                                               w=torch.cat([d["conv2"]["w"], d["skip"]["w"]], 1).contiguous(),
-                                               b=(d["conv2"]["b"] + d["skip"]["b"]).contiguous())
+                d = self.pack_res(sd, prefix)
                 cout = d["conv1"]["cout"]
                 emb_w.append(sd[prefix + ".emb_layers.1.weight"].float())
                 emb_b.append(sd[prefix + ".emb_layers.1.bias"].float())
@@ -341,27 +323,71 @@ class UNetEngine:
                 off += cout
                 P[prefix] = d
             elif kind == "st":
-                t = prefix + ".transformer_blocks.0"
-                c = sd[prefix + ".proj_in.weight"].shape[0]
-                ffw, ffb = packing.pack_geglu(cpu(t + ".ff.net.0.proj.weight"), cpu(t + ".ff.net.0.proj.bias"))
-                d = {"gn": (self._f32(sd[prefix + ".norm.weight"]), self._f32(sd[prefix + ".norm.bias"])),
-                     "proj_in": lin(prefix + ".proj_in", conv=True), "proj_out": lin(prefix + ".proj_out", conv=True),
-                     "ln1": (self._f32(sd[t + ".norm1.weight"]), self._f32(sd[t + ".norm1.bias"])),
-                     "ln3": (self._f32(sd[t + ".norm3.weight"]), self._f32(sd[t + ".norm3.bias"])),
-                     "wqkv": self._w16(packing.pack_qkv(sd[t + ".attn1.to_q.weight"], sd[t + ".attn1.to_k.weight"],
-                                                       sd[t + ".attn1.to_v.weight"])),
-                     "wo": lin(t + ".attn1.to_out.0"),
-                     "ff1": {"w": self._w16(ffw), "b": self._f32(ffb)}, "ff2": lin(t + ".ff.net.2"),
-                     "a2_out": lin(t + ".attn2.to_out.0"), "a2_slice": (voff, voff + c), "c": c,
-                     "wlin": {}, "attn1_name": t + ".attn1"}
-                vcat_w.append(sd[t + ".attn2.to_v.weight"].float())
-                voff += c
+                d = self.pack_st(sd, prefix)
+                d["a2_slice"] = (voff, voff + d["c"])
+                vcat_w.append(sd[prefix + ".transformer_blocks.0.attn2.to_v.weight"].float())
+                voff += d["c"]
                 P[prefix] = d
         P["emb_all"] = {"w": self._w16(torch.cat(emb_w, 0)), "b": self._f32(torch.cat(emb_b, 0)), "n": off}
         P["a2_v_all"] = {"w": self._w16(torch.cat(vcat_w, 0)), "n": voff}
         P["out.gn"] = (self._f32(sd["out.0.weight"]), self._f32(sd["out.0.bias"]))
         P["out.conv"] = conv3("out.2")
         self._version = self._param_version()
+
+    # ---- per-layer packers (also used for stand-alone sub-modules, vface_amd/module_exec.py); `sd`: name -> tensor
+    def pack_conv3(self, sd, prefix):
+        w = sd[prefix + ".weight"]
+        d = {"w": self._w16(packing.pack_conv3x3(w.detach().float().cpu())), "b": self._f32(sd[prefix + ".bias"]),
+             "cin": w.shape[1], "cinp": (w.shape[1] + 7) // 8 * 8, "cout": w.shape[0]}
+        return d
+
+    def pack_up(self, sd, prefix):
+        d = self.pack_conv3(sd, prefix)
+        # nearest x2 + conv3x3 = four parity-phase 2x2 convs with pre-summed taps (4/9 of the multiply-adds)
+        d["phases"] = self._w16(packing.pack_upsample_phases(sd[prefix + ".weight"].detach().float().cpu()))
+        return d
+
+    def pack_lin(self, sd, prefix, bias=True, conv=False):
+        w = sd[prefix + ".weight"]
+        w = w.reshape(w.shape[0], w.shape[1]) if conv else w
+        return {"w": self._w16(w), "b": self._f32(sd[prefix + ".bias"]) if bias else None}
+
+    def pack_res(self, sd, prefix):
+        d = {"in_gn": (self._f32(sd[prefix + ".in_layers.0.weight"]), self._f32(sd[prefix + ".in_layers.0.bias"])),
+             "conv1": self.pack_conv3(sd, prefix + ".in_layers.2"),
+             "out_gn": (self._f32(sd[prefix + ".out_layers.0.weight"]), self._f32(sd[prefix + ".out_layers.0.bias"])),
+             "conv2": self.pack_conv3(sd, prefix + ".out_layers.3")}
+        if (prefix + ".skip_connection.weight") in sd:
+            d["skip"] = self.pack_lin(sd, prefix + ".skip_connection", conv=True)
+            wsk = sd[prefix + ".skip_connection.weight"]
+            if d["conv2"]["cinp"] % 64 == 0 and wsk.shape[1] % 64 == 0:
+                # second conv + 1x1 shortcut in one K loop (vface_conv3x3_plus_1x1): weights side by side, biases summed
+                d["conv2_skip"] = dict(d["conv2"], c2=wsk.shape[1],
+                                       w=torch.cat([d["conv2"]["w"], d["skip"]["w"]], 1).contiguous(),
+                                       b=(d["conv2"]["b"] + d["skip"]["b"]).contiguous())
+        return d
+
+    def pack_block(self, sd, t):
+        """BasicTransformerBlock at state-dict prefix ``t``: attn1 / ff / norms (+ attn2's out projection; its to_v is
+        stacked with the other blocks' by the UNet packer)."""
+        cpu = lambda k: sd[k].detach().float().cpu()
+        ffw, ffb = packing.pack_geglu(cpu(t + ".ff.net.0.proj.weight"), cpu(t + ".ff.net.0.proj.bias"))
+        return {"ln1": (self._f32(sd[t + ".norm1.weight"]), self._f32(sd[t + ".norm1.bias"])),
+                "ln3": (self._f32(sd[t + ".norm3.weight"]), self._f32(sd[t + ".norm3.bias"])),
+                "wqkv": self._w16(packing.pack_qkv(sd[t + ".attn1.to_q.weight"], sd[t + ".attn1.to_k.weight"],
+                                                  sd[t + ".attn1.to_v.weight"])),
+                "wo": self.pack_lin(sd, t + ".attn1.to_out.0"),
+                "ff1": {"w": self._w16(ffw), "b": self._f32(ffb)}, "ff2": self.pack_lin(sd, t + ".ff.net.2"),
+                "a2_out": self.pack_lin(sd, t + ".attn2.to_out.0"), "c": sd[t + ".norm1.weight"].shape[0],
+                "wlin": {}, "attn1_name": t + ".attn1",
+                "qk_src": (sd[t + ".attn1.to_q.weight"], sd[t + ".attn1.to_k.weight"])}
+
+    def pack_st(self, sd, prefix):
+        d = self.pack_block(sd, prefix + ".transformer_blocks.0")
+        d.update({"gn": (self._f32(sd[prefix + ".norm.weight"]), self._f32(sd[prefix + ".norm.bias"])),
+                  "proj_in": self.pack_lin(sd, prefix + ".proj_in", conv=True),
+                  "proj_out": self.pack_lin(sd, prefix + ".proj_out", conv=True)})
+        return d
 
     def _param_version(self):
         return tuple(p._version for p in self.unet.parameters())
@@ -373,9 +399,7 @@ class UNetEngine:
     def _wlin(self, st: dict, kind: str, param: float) -> torch.Tensor:
         key = (kind, round(float(param), 9))
         if key not in st["wlin"]:
-            sd = self.unet.state_dict()
-            wq = sd[st["attn1_name"] + ".to_q.weight"].float().cpu()
-            wk = sd[st["attn1_name"] + ".to_k.weight"].float().cpu()
+            wq, wk = (t.detach().float().cpu() for t in st["qk_src"])
             w = packing.fold_fsai(wq, wk, param) if kind == "fsai" else packing.fold_mix(wq, wk, param)
             st["wlin"][key] = self._w16(w)
         return st["wlin"][key]
@@ -553,6 +577,27 @@ class UNetEngine:
                  rows_per_sample=n, **res_kw)
         return res_kw.get("out32") if out is None else out
 
+    def _block(self, t0: torch.Tensor, p: dict, attn1, a2vec: torch.Tensor, N: int, n: int, hw, want32: bool = False):
+        """BasicTransformerBlock._forward (attention.py:239-243) on the block's running sum ``t0`` ``[N*n, c]`` (fp32 when the
+        residual stream is on, else 16-bit): returns its last value as the 16-bit operand of the next projection (and, if
+        ``want32``, as fp32 too).  ``a2vec``: the single-token cross-attention's contribution, fp32 ``[N, c]``."""
+        c, M = p["c"], t0.shape[0]
+        ln = self._new(M, c)
+        hip.layernorm(t0, p["ln1"][0], p["ln1"][1], ln, M=M, C_=c, ldx=c, ldy=c)
+        cfg = getattr(attn1, "_vface_cfg", None)
+        fw = attn1.__dict__.get("forward")
+        if fw is not None and not getattr(fw, "_vface", False):
+            raise hip.VFaceHipError("attn1.forward was replaced by a closure this engine does not know; use "
+                                    "vface_amd.ldm.models.pnp_utils.register_spa_attn_injection")
+        t1 = self._attn1(ln, t0, p, cfg, a2vec, N, n, attn1.heads, hw)
+        hip.layernorm(t1, p["ln3"][0], p["ln3"][1], ln, M=M, C_=c, ldx=c, ldy=c)
+        ff = self._new(M, 4 * c)
+        hip.gemm(ln, p["ff1"]["w"], ff, M=M, N=8 * c, K=c, lda=c, ldc=4 * c, bias=p["ff1"]["b"], flags=hip.EPI_GEGLU)
+        t2 = self._new(M, c)
+        t2_32 = self._new(M, c, torch.float32) if want32 else None
+        self._gemm(ff, p["ff2"], t2, hw=n, out32=t2_32, **self._resid(t1))
+        return (t2, t2_32) if want32 else t2
+
     def _st(self, x: Act, p: dict, mod, a2_all: torch.Tensor, tgt) -> Act:
         """SpatialTransformer.forward + BasicTransformerBlock._forward (attention.py:278-289, 239-243).
         With the fp32 residual stream the block's running sum (``x`` after proj_in, after attn1 + attn2) exists in fp32
@@ -565,21 +610,8 @@ class UNetEngine:
             self._gemm(g.t, p["proj_in"], None, hw=x.H * x.W, out32=t0)
         else:
             self._gemm(g.t, p["proj_in"], t0, hw=x.H * x.W)
-        ln = self._new(x.M, c)
-        hip.layernorm(t0, p["ln1"][0], p["ln1"][1], ln, M=x.M, C_=c, ldx=c, ldy=c)
         a, b = p["a2_slice"]
-        attn1 = mod.transformer_blocks[0].attn1
-        cfg = getattr(attn1, "_vface_cfg", None)
-        fw = attn1.__dict__.get("forward")
-        if fw is not None and not getattr(fw, "_vface", False):
-            raise hip.VFaceHipError("attn1.forward was replaced by a closure this engine does not know; use "
-                                    "vface_amd.ldm.models.pnp_utils.register_spa_attn_injection")
-        t1 = self._attn1(ln, t0, p, cfg, a2_all[:, a:b], N, n, attn1.heads, (x.H, x.W))
-        hip.layernorm(t1, p["ln3"][0], p["ln3"][1], ln, M=x.M, C_=c, ldx=c, ldy=c)
-        ff = self._new(x.M, 4 * c)
-        hip.gemm(ln, p["ff1"]["w"], ff, M=x.M, N=8 * c, K=c, lda=c, ldc=4 * c, bias=p["ff1"]["b"], flags=hip.EPI_GEGLU)
-        t2 = self._new(x.M, c)
-        self._gemm(ff, p["ff2"], t2, hw=x.H * x.W, **self._resid(t1))
+        t2 = self._block(t0, p, mod.transformer_blocks[0].attn1, a2_all[:, a:b], N, n, (x.H, x.W))
         out, cs, o32 = self._new_target(x.M, c, x.hw) if tgt is None else tgt
         self._gemm(t2, p["proj_out"], out, colstats=cs, hw=x.H * x.W, out32=o32, **self._resid(x))
         return Act(out, x.N, x.H, x.W, cs, o32)

@@ -56,6 +56,7 @@ SIGNATURES = {
     "vface_groupnorm_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vface_flow_warp": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                                   _f32, _i32, _vp, _vp, _i32, _vp]),
+    "vface_flow_to_latent": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vface_attn1_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "vface_attn1_forward": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32,
                                       _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp,
@@ -256,6 +257,18 @@ def flow_warp(src: torch.Tensor, dst: torch.Tensor, flow: Optional[torch.Tensor]
                                 fs_dst, F, h, w, C_, float(alpha), float(1.0 - alpha), int(cuda_recip_div),
                                 _p(dbg_x0), _p(dbg_y0), dtype_code(src.dtype), _stream())
     _check(rc, "vface_flow_warp")
+
+
+def flow_to_latent(flow_px: torch.Tensor, factor: int = 8) -> torch.Tensor:
+    """[P, 2, H, W] fp32 pixel-resolution flow -> [P, 2, H/factor, W/factor] latent-resolution flow (area mean / factor)."""
+    if flow_px.dim() != 4 or flow_px.shape[1] != 2:
+        raise VFaceHipError(f"flow must be [pairs, 2, H, W]; got {tuple(flow_px.shape)}")
+    f = flow_px.to(dtype=torch.float32).contiguous()
+    P, _, H, W = f.shape
+    out = torch.empty(P, 2, H // factor, W // factor, dtype=torch.float32, device=f.device)
+    rc = load().vface_flow_to_latent(_p(f), _p(out), P, H, W, factor, _stream())
+    _check(rc, "vface_flow_to_latent")
+    return out
 
 
 def attn1_workspace_bytes(B: int, n: int, d: int, chunks: int) -> int:

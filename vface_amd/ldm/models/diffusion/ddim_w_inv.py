@@ -61,6 +61,9 @@ class DDIMSampler(object):
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
         self.hook_plan = HookPlan()
+        # what to do with a flow field at pixel resolution (what the reference's own script produces): None =
+        # raise like the reference's warp_image does; "area" = bring it to the latent map with vface_flow_to_latent
+        self.flow_resample = None
 
     def register_buffer(self, name, attr):
         # the reference forces .to("cuda") here (:149-153); buffers follow the model's device instead
@@ -136,6 +139,10 @@ class DDIMSampler(object):
         time_range = np.flip(timesteps)
         total_steps = timesteps.shape[0]
         flow_dev = _dev_flow(flow, device)
+        if flow_dev is not None and tuple(flow_dev.shape[-2:]) != tuple(shape[-2:]) and self.flow_resample == "area":
+            fh, fw = flow_dev.shape[-2] // shape[-2], flow_dev.shape[-1] // shape[-1]
+            if fh == fw and fh >= 1 and (fh * shape[-2], fw * shape[-1]) == tuple(flow_dev.shape[-2:]):
+                flow_dev = hip.flow_to_latent(flow_dev, fh)
         if flow_dev is not None and tuple(flow_dev.shape[-2:]) != tuple(shape[-2:]):
             # the shipped script feeds 512x512 RAFT flow to a 64x64 map and dies in warp_image
             raise RuntimeError(f"The size of the flow field {tuple(flow_dev.shape[-2:])} must match the latent map "

@@ -2,9 +2,9 @@
 
 Same class names, constructor signatures, attributes (``heads``, ``dim_head``, ``scale``, ``to_q`` ...) and
 state-dict keys as the reference (attention.py:37-64, 152-289), so ``last.ckpt`` loads unchanged and
-``register_spa_attn_injection`` finds the same ``attn1`` modules in the same order.  The modules only own
-parameters: compute runs in hand-written gfx950 kernels (``vface_amd.engine`` / ``vface_amd.hip``); calling
-them with CPU tensors raises.
+``register_spa_attn_injection`` finds the same ``attn1`` modules in the same order.  The modules own
+parameters; every ``forward`` runs hand-written gfx950 kernels (``vface_amd.engine`` / ``vface_amd.module_exec`` /
+``vface_amd.hip``); calling them with CPU tensors raises.
 """
 from __future__ import annotations
 
@@ -33,6 +33,10 @@ class GEGLU(nn.Module):
         super().__init__()
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
+    def forward(self, x):
+        from ...module_exec import geglu_forward
+        return geglu_forward(self, x)
+
 
 class FeedForward(nn.Module):
     """attention.py:47-64 with ``glu=True`` (the only form the UNet builds)."""
@@ -44,6 +48,10 @@ class FeedForward(nn.Module):
         if not glu:
             raise NotImplementedError("the VFace UNet uses gated feed-forward only (attention.py:228)")
         self.net = nn.Sequential(GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out))
+
+    def forward(self, x):
+        from ...module_exec import feedforward_forward
+        return feedforward_forward(self, x)
 
 
 class CrossAttention(nn.Module):
@@ -88,7 +96,8 @@ class CrossAttention(nn.Module):
 
 
 class BasicTransformerBlock(nn.Module):
-    """attention.py:224-243 (parameters only; executed by ``UNetEngine._st``)."""
+    """attention.py:224-243.  Inside the UNet the block runs as part of ``UNetEngine._st``; called directly,
+    ``forward(x [B, n, d], context [B, 1, ctx])`` runs the same kernel sequence (``vface_amd.module_exec``)."""
 
     def __init__(self, dim, n_heads, d_head, dropout=0., context_dim=None, gated_ff=True, checkpoint=True,
                  sep_head_att=False):
@@ -102,9 +111,14 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.checkpoint = checkpoint
 
+    def forward(self, x, context=None):
+        from ...module_exec import transformer_block_forward
+        return transformer_block_forward(self, x, context)
+
 
 class SpatialTransformer(nn.Module):
-    """attention.py:246-289 (parameters only; executed by ``UNetEngine._st``)."""
+    """attention.py:246-289.  Inside the UNet the layer runs through ``UNetEngine._st``; called directly,
+    ``forward(x [N, C, H, W], context [N, 1, ctx])`` runs the same kernel sequence (``vface_amd.module_exec``)."""
 
     def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0., context_dim=None, sep_head_att=False,
                  head_splits=None):
@@ -118,3 +132,7 @@ class SpatialTransformer(nn.Module):
         self.transformer_blocks = nn.ModuleList(
             [BasicTransformerBlock(inner, n_heads, d_head, dropout=dropout, context_dim=context_dim)])
         self.proj_out = nn.Conv2d(inner, in_channels, kernel_size=1, stride=1, padding=0)
+
+    def forward(self, x, context=None):
+        from ...module_exec import spatial_transformer_forward
+        return spatial_transformer_forward(self, x, context)

@@ -3,7 +3,7 @@
 (``input_blocks.i.j...``, ``middle_block.j...``, ``output_blocks.i.j...``, ``time_embed``, ``out``), for the
 spatial-transformer configuration of ``project_ffhq.yaml:33-56``.
 
-The modules own parameters only.  ``UNetModel.forward`` (openaimodel.py:860-907) runs on MI355X through
+``UNetModel.forward`` (openaimodel.py:860-907) runs on MI355X through
 ``vface_amd.engine.UNetEngine``; there is no CPU path.
 """
 from __future__ import annotations
@@ -23,7 +23,18 @@ class TimestepBlock(nn.Module):
 
 
 class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
-    """openaimodel.py:74-88 (container; the engine dispatches by layer type)."""
+    """openaimodel.py:74-88.  Inside ``UNetModel.forward`` the engine dispatches by layer type; called directly, the same
+    type dispatch of ``(emb, context)`` as the reference."""
+
+    def forward(self, x, emb, context=None):
+        for layer in self:
+            if isinstance(layer, TimestepBlock):
+                x = layer(x, emb)
+            elif isinstance(layer, SpatialTransformer):
+                x = layer(x, context)
+            else:
+                x = layer(x)
+        return x
 
 
 class Upsample(nn.Module):
@@ -36,6 +47,10 @@ class Upsample(nn.Module):
             raise NotImplementedError("conv_resample=False is not part of the VFace configuration")
         self.conv = conv_nd(dims, self.channels, self.out_channels, 3, padding=padding)
 
+    def forward(self, x):
+        from ....module_exec import conv_forward
+        return conv_forward(self, x, "up")
+
 
 class Downsample(nn.Module):
     """openaimodel.py:134-160: 3x3 conv, stride 2, padding 1."""
@@ -46,6 +61,10 @@ class Downsample(nn.Module):
         if not use_conv:
             raise NotImplementedError("conv_resample=False is not part of the VFace configuration")
         self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
+
+    def forward(self, x):
+        from ....module_exec import conv_forward
+        return conv_forward(self, x, "down")
 
 
 class ResBlock(TimestepBlock):
@@ -66,6 +85,11 @@ class ResBlock(TimestepBlock):
                                         conv_nd(dims, self.out_channels, self.out_channels, 3, padding=1))
         self.skip_connection = (nn.Identity() if self.out_channels == channels
                                 else conv_nd(dims, channels, self.out_channels, 1))
+
+    def forward(self, x, emb):
+        """openaimodel.py:243-275 on ``x`` [N, C, H, W], ``emb`` [N, emb_channels]."""
+        from ....module_exec import resblock_forward
+        return resblock_forward(self, x, emb)
 
 
 class UNetModel(nn.Module):

@@ -59,6 +59,10 @@ def build_parser() -> argparse.ArgumentParser:
                         "synthetic images (:456-457) and the samples are decoded to pixels (:596-600)")
     p.add_argument("--fusion", type=str, default="flow_fix", help="hook mode on the input-block attn1 modules")
     p.add_argument("--no_inversion", action="store_true", help="use random recon latents instead of DDIM inversion")
+    p.add_argument("--flow_pixels", action="store_true",
+                   help="hand the sampler the flow at PIXEL resolution, as the reference's return_flow produces it "
+                        "(temporal_flow.py:163-188), and let it be resampled to the latent map (area mean / 8, vface_flow_to_latent) "
+                        "instead of failing like the reference does (SURVEY F8)")
     p.add_argument("--flow_gate", choices=["reference", "flow_hw"], default="reference",
                    help="which attention maps the flow smoothing touches: 'reference' = exactly pnp_utils.py:201 (the 4096-token "
                         "maps of a 512x512 clip, nothing at any other resolution); 'flow_hw' = the level whose token count equals "
@@ -111,6 +115,7 @@ def run_synthetic(opt) -> dict:
     sampler = DDIMSampler(model)
     sampler.hook_plan = HookPlan(fusion=opt.fusion, enabled=opt.fusion != "none")
     sampler.flow_gate = opt.flow_gate
+    sampler.flow_resample = "area" if opt.flow_pixels else None
     h, w = opt.H // opt.f, opt.W // opt.f
     F_ = opt.n_samples
     os.makedirs(opt.Base_dir, exist_ok=True)
@@ -125,7 +130,10 @@ def run_synthetic(opt) -> dict:
         else:
             z_inp = d(synth.synth_normal(tag("inp"), (F_, opt.C, h, w)) * 0.18215)
         mask = d(synth.synth_mask(F_, h, w))
-        flow = [f[None] for f in synth.synth_flow(F_ - 1, h, w, seed=opt.seed + batch_id)]
+        if opt.flow_pixels:   # a pixel-resolution field whose latent resample is a +-2-cell motion
+            flow = [f[None] * opt.f for f in synth.synth_flow(F_ - 1, opt.H, opt.W, seed=opt.seed + batch_id)]
+        else:
+            flow = [f[None] for f in synth.synth_flow(F_ - 1, h, w, seed=opt.seed + batch_id)]
         kw = {"inpaint_image": z_inp, "inpaint_mask": mask}
         inv_store = {}
         if opt.no_inversion:
