@@ -238,3 +238,35 @@ def test_vae_encode_sample_decode_match_reference(tag, res, nb):
         assert rel_l2(z, g[f"{tag}.z_sample"]) < 1e-5
         dec = ovae.decode(sd, spec, g[f"{tag}.z_sample"] / 0.18215)
         assert rel_l2(dec, g[f"{tag}.dec"]) < 1e-5
+
+
+def test_cuda_form_indices_fixture_and_flow_to_latent():
+    """Round-2 additions: the oracle's CUDA-form division rule reproduces the committed (emulated) index fixture and differs
+    from the CPU form exactly where floor() sits on an integer; the latent flow resample is the area mean / factor."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from cases import make_flows
+    g = load_golden("warp_cuda_form")
+    gc = load_golden("warp")
+    nd = 0
+    for name, fl in make_flows(64, 64).items():
+        x0, y0 = oflow.gather_indices(torch.from_numpy(fl), cuda_recip_div=True)
+        assert torch.equal(x0, g[f"x0_{name}"]) and torch.equal(y0, g[f"y0_{name}"]), name
+        nd += int(((x0 != gc[f"x0_{name}"]) | (y0 != gc[f"y0_{name}"])).sum())
+    assert nd > 500
+    f = torch.arange(2 * 2 * 16 * 16, dtype=torch.float32).reshape(2, 2, 16, 16)
+    out = oflow.flow_to_latent(f, 8)
+    assert out.shape == (2, 2, 2, 2)
+    assert torch.allclose(out[1, 0, 1, 1], f[1, 0, 8:, 8:].mean() / 8)
+
+
+def test_lowp_fixture_is_the_references_own_error_floor():
+    """tests/golden/lowp.npz: the reference under fp16 autocast and with fp16-rounded weights only, against its fp32 output.
+    These numbers are what the whole-network GPU bounds are argued from; pin them."""
+    lp, fu, ti = load_golden("lowp"), load_golden("full_unet"), load_golden("tiny_unet")
+    for mode in ("plain", "flow_fix", "replace"):
+        e_auto, e_w = rel_l2(lp[f"full.{mode}_autocast_f16"], fu[mode]), rel_l2(lp[f"full.{mode}_w16"], fu[mode])
+        assert 1.4e-3 < e_auto < 1.8e-3 and 9.0e-4 < e_w < 1.05e-3, (mode, e_auto, e_w)
+    for mode, key in (("plain", "plain"), ("flow_fix", "in_flow_fix"), ("replace", "in_replace")):
+        e_auto, e_w = rel_l2(lp[f"tiny.{mode}_autocast_f16"], ti[key]), rel_l2(lp[f"tiny.{mode}_w16"], ti[key])
+        assert 1.8e-3 < e_auto < 2.3e-3 and 1.0e-3 < e_w < 1.2e-3, (mode, e_auto, e_w)
