@@ -77,59 +77,64 @@ def self_launch(a):
 
 
 class ConvTimer:
-    """HIP-event timing of every launch of the dominant kernel inside the timed region."""
+    """HIP-event timing of every convolution launch inside the timed region, by kernel: `patch3` = conv_patch_kernel<3x3>
+    (the dominant kernel of the step: conv.hip), `patch2` = its 2x2 parity-phase form (four launches per call), `im2col` =
+    gemm.hip's implicit GEMM (stride 2, the 8x8 level, the 9->320 and 320->4 convolutions)."""
 
     def __init__(self):
-        self.events, self.flops, self.on, self.extra_launches = [], 0.0, False, 0
+        self.cls = {k: {"events": [], "flops": 0.0, "launches": 0} for k in ("patch3", "patch2", "im2col")}
+        self.on = False
+
+    def _timed(self, key, flops, launches, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        c = self.cls[key]
+        c["events"].append((e0, e1)); c["flops"] += flops; c["launches"] += launches
 
     def wrap(self, hip):
-        orig = hip.conv3x3
         timer = self
+        orig = hip.conv3x3
 
         def conv3x3(x, wt, out, *, nimg, H, W, cin, cout, stride=1, upsample=False, **kw):
+            call = lambda: orig(x, wt, out, nimg=nimg, H=H, W=W, cin=cin, cout=cout, stride=stride, upsample=upsample, **kw)
             if not timer.on:
-                return orig(x, wt, out, nimg=nimg, H=H, W=W, cin=cin, cout=cout, stride=stride, upsample=upsample, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig(x, wt, out, nimg=nimg, H=H, W=W, cin=cin, cout=cout, stride=stride, upsample=upsample, **kw)
-            e1.record()
+                return call()
             VH, VW = (2 * H, 2 * W) if upsample else (H, W)
             OH, OW = (VH - 1) // stride + 1, (VW - 1) // stride + 1
-            timer.events.append((e0, e1))
-            timer.flops += 2.0 * nimg * OH * OW * cout * 9 * cin
+            patch = hip.conv_uses_patch_kernel(H, W, cin, cout, 3, stride, upsample, kw.get("flags", 0)) and not (kw.get("flags", 0) & hip.EPI_OUT_F32)
+            timer._timed("patch3" if patch else "im2col", 2.0 * nimg * OH * OW * cout * 9 * cin, 1, call)
         hip.conv3x3 = conv3x3
         orig_up = hip.upsample2x_conv3x3
 
         def upsample2x_conv3x3(x, wt, out, *, nimg, H, W, cin, cout, **kw):
-            # the same kernel, four parity-phase launches of a 2x2 window on the low-resolution input: their FLOPs are
-            # counted as executed (4 taps), not as the 9-tap form they replace
+            # four parity-phase launches of a 2x2 window on the low-resolution input: FLOPs counted as executed (4 taps),
+            # not as the 9-tap form they replace
+            call = lambda: orig_up(x, wt, out, nimg=nimg, H=H, W=W, cin=cin, cout=cout, **kw)
             if not timer.on:
-                return orig_up(x, wt, out, nimg=nimg, H=H, W=W, cin=cin, cout=cout, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig_up(x, wt, out, nimg=nimg, H=H, W=W, cin=cin, cout=cout, **kw)
-            e1.record()
-            timer.events.append((e0, e1))
-            timer.extra_launches += 3
-            timer.flops += 4 * 2.0 * nimg * H * W * cout * 4 * cin
+                return call()
+            patch = hip.conv_uses_patch_kernel(H, W, cin, cout, 2, 1, False, kw.get("flags", 0))
+            timer._timed("patch2" if patch else "im2col", 4 * 2.0 * nimg * H * W * cout * 4 * cin, 4, call)
         hip.upsample2x_conv3x3 = upsample2x_conv3x3
         orig_p1 = hip.conv3x3_plus_1x1
 
         def conv3x3_plus_1x1(x, x2, wt, out, *, nimg, H, W, cin, c2, cout, **kw):
+            call = lambda: orig_p1(x, x2, wt, out, nimg=nimg, H=H, W=W, cin=cin, c2=c2, cout=cout, **kw)
             if not timer.on:
-                return orig_p1(x, x2, wt, out, nimg=nimg, H=H, W=W, cin=cin, c2=c2, cout=cout, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig_p1(x, x2, wt, out, nimg=nimg, H=H, W=W, cin=cin, c2=c2, cout=cout, **kw)
-            e1.record()
-            timer.events.append((e0, e1))
-            timer.flops += 2.0 * nimg * H * W * cout * (9 * cin + c2)
+                return call()
+            patch = hip.conv_uses_patch_kernel(H, W, cin, cout, 3, 1, False, kw.get("flags", 0)) and c2 % 64 == 0
+            timer._timed("patch3" if patch else "im2col", 2.0 * nimg * H * W * cout * (9 * cin + c2), 1, call)
         hip.conv3x3_plus_1x1 = conv3x3_plus_1x1
 
     def summary(self):
-        ms = sum(a.elapsed_time(b) for a, b in self.events)
-        n = len(self.events) + self.extra_launches
-        return n, ms, self.flops
+        out = {}
+        for k, c in self.cls.items():
+            ms = sum(a.elapsed_time(b) for a, b in c["events"])
+            out[k] = {"launches": c["launches"], "ms": ms, "flops": c["flops"],
+                      "tflops": c["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                      "mean_launch_us": ms * 1e3 / max(c["launches"], 1)}
+        return out
 
 
 def usable_cores():
@@ -315,7 +320,9 @@ def main():
         log(f"inversion: {inv_ms:.2f} ms/step (2F = {2 * F_} unhooked sample-forwards)")
     log(f"timed {a.steps} steps: {ms_step:.2f} ms/step (host enqueue {r['enqueue_ms']:.2f} ms/step)")
     fps = (F_ * world) / (a.ddim_steps * ms_step / 1e3)
-    n_launch, conv_ms, conv_flops = timer.summary()
+    conv = timer.summary()
+    conv_ms = sum(c["ms"] for c in conv.values())
+    conv_flops = sum(c["flops"] for c in conv.values())
     unet_gflop = {64: 796.94, 96: 2137.52, 32: 176.34}.get(h)   # BASELINE.md 2, per sample-forward
 
     # the other single-GPU BASELINE configurations, same process and build, outside the timed region of the headline run
@@ -334,7 +341,9 @@ def main():
             log(f"  {e['ms_step']:.2f} ms/step = {extras[-1]['frames_per_s']:.2f} frames/s")
 
     if rank == 0:
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        dom = conv["patch3"] if conv["patch3"]["launches"] else max(conv.values(), key=lambda c: c["ms"])
+        achieved = dom["tflops"]
+        all_conv = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         unet_tflops = 3 * F_ * unet_gflop * 1e9 / (ms_step * 1e-3) / 1e12 if unet_gflop else None
         # HBM-side bytes per conv launch are NOT measured in this run: they come from separate rocprofv3 --pmc passes of this
         # same command (tools/traffic.sh: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md "HBM");
@@ -344,8 +353,10 @@ def main():
         cands = sorted(f for f in os.listdir(prof) if f.endswith("_hbm_traffic.json")) if os.path.isdir(prof) else []
         if cands and F_ == 8 and h == 64 and a.fusion == "replace" and a.dtype == "fp16":
             tf = os.path.join(prof, cands[-1])
-            traffic = json.load(open(tf))["_conv_all"]["hbm_bytes_per_launch"]
-            traffic_src = (f"QUOTED from profiles/{cands[-1]} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+            tj = json.load(open(tf))
+            key = next((k for k in tj if k.startswith("conv_patch_kernel") and ", 3, 3" in k), "_conv_all")
+            traffic = tj[key]["hbm_bytes_per_launch"]
+            traffic_src = (f"QUOTED from profiles/{cands[-1]} [{key}] (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                            "command on the build it names), not measured in this run")
         out = {
             "metric": "swapped frames/sec at 512x512, 50-step DDIM", "value": fps, "unit": "frames/s",
@@ -369,11 +380,18 @@ def main():
                         "sampling only, as BASELINE's metric",
                 "frames_per_s_sampling_plus_inversion": (F_ * world) / (a.ddim_steps * (ms_step + inv_ms) / 1e3)},
             "extra": extras,
-            "roofline": {"bound": "mfma", "kernel": "implicit-GEMM 3x3 conv launches (conv3x3 / conv3x3_plus_1x1 / upsample phases)",
+            # the dominant kernel of the step (largest share of kernel time in profiles/*_kernel_stats.csv): conv_patch_kernel<3,3>,
+            # the patch-staged stride-1 3x3 convolution (incl. the launches that carry a ResBlock's fused 1x1 shortcut)
+            "roofline": {"bound": "mfma", "kernel": "conv_patch_kernel<T, NT, 3, 3> (conv.hip: patch-staged 3x3 convolution)",
                          "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "launches": n_launch, "mean_launch_us": conv_ms * 1e3 / max(n_launch, 1),
-                         "share_of_step_time": conv_ms / (el * 1e3)},
+                         "launches": dom["launches"], "mean_launch_us": dom["mean_launch_us"],
+                         "share_of_step_time": dom["ms"] / (el * 1e3),
+                         "note": "peak is the datasheet 2.5 PFLOP/s; an MFMA-only loop of this tile shape sustains 1.5 PFLOP/s on "
+                                 "this chip (it clocks ~1.6 GHz under matrix load: DESIGN.md 4, profiles/r02_a_conv_patch_ablations.txt)",
+                         "all_conv_launches": {"tflops": all_conv, "frac": all_conv / MFMA_PEAK_TFLOPS, "ms": conv_ms,
+                                               "share_of_step_time": conv_ms / (el * 1e3),
+                                               "by_kernel": {k: {kk: vv for kk, vv in c.items() if kk != "flops"} for k, c in conv.items()}}},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_forwards, a.ddim_steps)

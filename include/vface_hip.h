@@ -77,6 +77,14 @@ typedef struct vface_stream32 {
     int64_t ldr32;
     float* out32;
     int64_t ldo32;
+    /* Convolutions only -- GroupNorm + SiLU fused into the operand path (openaimodel.py:201-205,225-232 `GroupNorm32 -> SiLU ->
+     * conv`): in_scale_shift = fp32 [nimg][ld_scale_shift][2] pairs (a, b) per (image, input channel), from
+     * vface_groupnorm_coeffs_from_cols; the matrix cores then see act(x * a + b) (act = SiLU if in_silu, else identity),
+     * rounded once to the 16-bit type, zero padding applied AFTER the normalisation as in the reference.  Needs a launch
+     * that runs the patch-staged kernel (vface_conv_uses_patch_kernel); otherwise VFACE_ERR_SHAPE.  NULL = off. */
+    const float* in_scale_shift;
+    int64_t ld_scale_shift;
+    int in_silu;
 } vface_stream32;
 
 /* C[M][N] (+)= A[M][K] * Wt[N][K]^T with fused epilogue.
@@ -111,6 +119,12 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
                   const void* residual, int64_t ldr, void* Y, int64_t ldy, const void* zeros, int flags, int dtype,
                   float* colstats, int64_t ld_colstats, void* workspace, int64_t workspace_bytes, void* stream,
                   const vface_stream32* s32);
+
+/* Which kernel a vface_conv3x3 / vface_conv3x3_plus_1x1 (window = 3) / vface_upsample2x_conv3x3_phase (window = 2) launch of this
+ * geometry runs: 1 = the patch-staged kernel (conv.hip: stride 1, H and W multiples of 16, Cin % 64 == 0, Cout % 160 == 0 or
+ * % 128 == 0, 16-bit output, and a grid that is deep enough at the nominal 24-sample batch, or VFACE_TUNE_PATCH), 0 = the
+ * im2col-style implicit GEMM (gemm.hip).  For measurement harnesses (bench.py prices the two kernels separately). */
+int vface_conv_uses_patch_kernel(int H, int W, int Cin, int Cout, int window, int stride, int upsample, int flags);
 
 /* Y = conv3x3(X) + X2 W2^T + bias: the second convolution of a ResBlock together with the block's 1x1 shortcut
  * (openaimodel.py:228-232, 274 `skip_connection(x) + h`; diffusionmodules/model.py:137-141 `nin_shortcut`), accumulated in
@@ -161,6 +175,10 @@ int vface_groupnorm_stats(const void* x, int64_t ldx, int nimg, int hw, int C, i
 /* The same statistics from producer-side column sums (colstats of vface_gemm / vface_conv3x3); needs hw % 64 == 0. */
 int vface_groupnorm_finalize_cols(const float* colstats, int64_t ld_colstats, int nimg, int hw, int C, int groups, float eps,
                                   float* stats, void* stream);
+/* The same statistics folded with the affine parameters into per-(image, channel) pairs ab[img][c] = (a, b), a = rstd * gamma[c],
+ * b = beta[c] - mean * a -- what vface_stream32.in_scale_shift takes (fp32 [nimg][C][2]). */
+int vface_groupnorm_coeffs_from_cols(const float* colstats, int64_t ld_colstats, int nimg, int hw, int C, int groups, float eps,
+                                     const float* gamma, const float* beta, float* ab, void* stream);
 /* y = (x - mean) * rstd * gamma + beta, then SiLU if `silu` (openaimodel.py:201-205,225-232).  in_f32 (here and in
  * vface_groupnorm_stats): x is the fp32 residual-stream copy (ldx in floats); y is always 16-bit. */
 int vface_groupnorm_apply(const void* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,

@@ -28,8 +28,9 @@ from vface_amd.utils import synth  # noqa: E402
 class Emu:
     """rounding switches: w16 (weights), act16 (branch activations = MFMA operands), stream16 (residual carriers)."""
 
-    def __init__(self, sd, w16=True, act16=True, stream16=True, half=torch.float16, w16_filter=None):
+    def __init__(self, sd, w16=True, act16=True, stream16=True, half=torch.float16, w16_filter=None, gn_in16=False):
         self.half = half
+        self.gn_in16 = gn_in16     # GroupNorm-apply fused into the conv's operand path reads the 16-bit copy of the stream
         q = lambda t: t.to(half).float()
         self.a = q if act16 else (lambda t: t)
         self.s = q if stream16 else (lambda t: t)
@@ -49,7 +50,16 @@ def conv(c, x16, p, stride=1, pad=1):
 
 def res(c, l, x, emb_all):
     p = l.prefix
-    a = c.a(F.silu(F.group_norm(x, 32, c.f(p + ".in_layers.0.weight"), c.f(p + ".in_layers.0.bias"), 1e-5)))
+    if c.gn_in16:   # statistics from the fp32 values (producer epilogue), normalisation applied to the rounded copy
+        xr = c.a(x)
+        N, C = x.shape[:2]
+        xg = x.reshape(N, 32, -1)
+        mu, var = xg.mean(-1), xg.var(-1, unbiased=False)
+        y = ((xr.reshape(N, 32, -1) - mu[..., None]) * torch.rsqrt(var[..., None] + 1e-5)).reshape(x.shape)
+        y = y * c.f(p + ".in_layers.0.weight")[None, :, None, None] + c.f(p + ".in_layers.0.bias")[None, :, None, None]
+        a = c.a(F.silu(y))
+    else:
+        a = c.a(F.silu(F.group_norm(x, 32, c.f(p + ".in_layers.0.weight"), c.f(p + ".in_layers.0.bias"), 1e-5)))
     e = F.linear(emb_all, c.w(p + ".emb_layers.1.weight"), c.f(p + ".emb_layers.1.bias"))   # fp32 row bias
     h1 = c.a(conv(c, a, p + ".in_layers.2") + e[:, :, None, None])
     a2 = c.a(F.silu(F.group_norm(h1, 32, c.f(p + ".out_layers.0.weight"), c.f(p + ".out_layers.0.bias"), 1e-5)))
@@ -164,6 +174,7 @@ def main():
             ("reference autocast rounding points (oracle half=)", None),
             ("HIP path today: w16 + act16 + stream16", dict(w16=True, act16=True, stream16=True)),
             ("fp32 residual stream: w16 + act16", dict(w16=True, act16=True, stream16=False)),
+            ("  + ResBlock in-GN fused into conv1 (reads the 16-bit copy)", dict(w16=True, act16=True, stream16=False, gn_in16=True)),
             ("weights only", dict(w16=True, act16=False, stream16=False)),
             ("activations only (16-bit stream)", dict(w16=False, act16=True, stream16=True)),
             ("activations only (fp32 stream)", dict(w16=False, act16=True, stream16=False)),

@@ -762,3 +762,38 @@ def test_flow_to_latent_matches_oracle():
         got = h.flow_to_latent(fl.to(DEV), f).cpu()
         ref = oflow.flow_to_latent(fl, f)
         assert got.shape == ref.shape and (got - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,H,W,nimg,silu", [(64, 160, 16, 16, 2, True), (320, 320, 32, 32, 3, True), (128, 128, 16, 48, 2, False)])
+def test_conv_patch_kernel_fused_groupnorm_silu(dt, cin, cout, H, W, nimg, silu):
+    """GroupNorm-apply (+ SiLU) in the patch-staged convolution's operand path (north-star "GroupNorm+SiLU+conv fused";
+    openaimodel.py:201-205): equals -- BIT FOR BIT -- the separate normalisation pass followed by the plain convolution on
+    the same 16-bit input (same a, b, same arithmetic, zero padding applied after the normalisation), and torch."""
+    h = hip()
+    from vface_amd.packing import pack_conv3x3
+    x = rnd((nimg, cin, H, W), 1, dt) * 1.5 + 0.3
+    w = rnd((cout, cin, 3, 3), 2, dt, 1 / math.sqrt(9 * cin))
+    b = rnd((cout,), 3, torch.float32, 0.1)
+    gm, bt = 1 + 0.2 * rnd((cin,), 4, torch.float32), 0.2 * rnd((cin,), 5, torch.float32)
+    xn = x.permute(0, 2, 3, 1).reshape(-1, cin).contiguous().to(DEV)
+    # column statistics of x as a producer epilogue would have left them
+    xs = xn.float().reshape(nimg * H * W // 64, 64, cin)
+    cs = torch.stack([xs.sum(1), (xs * xs).sum(1)], -1).contiguous()
+    ab = h.groupnorm_coeffs_from_cols(cs, gm.to(DEV), bt.to(DEV), nimg=nimg, hw=H * W, C_=cin, eps=1e-5)
+    wp = pack_conv3x3(w).to(DEV)
+    fused = torch.zeros(nimg * H * W, cout, dtype=dt, device=DEV)
+    h.conv3x3(xn, wp, fused, nimg=nimg, H=H, W=W, cin=cin, cout=cout, ldx=cin, ldy=cout, bias=b.to(DEV), gn_ab=ab, gn_silu=silu,
+              flags=h.TUNE_PATCH)
+    st = h.groupnorm_stats_from_cols(cs, nimg=nimg, hw=H * W, C_=cin, eps=1e-5)
+    y = torch.empty_like(xn)
+    h.groupnorm_apply(xn, st, gm.to(DEV), bt.to(DEV), y, nimg=nimg, hw=H * W, C_=cin, ldx=cin, ldy=cin, silu=silu)
+    sep = torch.zeros_like(fused)
+    h.conv3x3(y, wp, sep, nimg=nimg, H=H, W=W, cin=cin, cout=cout, ldx=cin, ldy=cout, bias=b.to(DEV), flags=h.TUNE_PATCH)
+    assert torch.equal(fused, sep)
+    xf = xn.float().cpu().reshape(nimg, H, W, cin).permute(0, 3, 1, 2)
+    g = F.group_norm(xf, 32, gm, bt, 1e-5)
+    ref = F.conv2d(F.silu(g) if silu else g, w.float(), b, padding=1).permute(0, 2, 3, 1).reshape(-1, cout)
+    assert rel_l2(fused.cpu().float(), ref) < TOL[dt] * 1.3
+    with pytest.raises(h.VFaceHipError):     # the im2col kernel has no fused form: refuse, never silently skip the normalisation
+        h.conv3x3(xn, wp, sep, nimg=nimg, H=H, W=W, cin=cin, cout=cout, ldx=cin, ldy=cout, gn_ab=ab, gn_silu=silu, flags=h.TUNE_NO_PATCH)

@@ -22,6 +22,7 @@ inline void apply_s32(GemmParams& p, const vface_stream32* s) {
     if (!s) return;
     if (s->residual32) { p.residual = s->residual32; p.ldr = s->ldr32; p.res_f32 = 1; }
     if (s->out32) { p.C32 = s->out32; p.ldc32 = s->ldo32; }
+    if (s->in_scale_shift) { p.gn_ab = s->in_scale_shift; p.ld_gn_ab = s->ld_scale_shift; p.gn_silu = s->in_silu ? 1 : 0; }
 }
 }  // namespace
 
@@ -80,6 +81,18 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
     p.workspace = static_cast<float*>(workspace); p.workspace_bytes = workspace ? workspace_bytes : 0;
     apply_s32(p, s32);
     return vf_launch_gemm(p, dtype, S(stream));
+}
+
+int vface_conv_uses_patch_kernel(int H, int W, int Cin, int Cout, int window, int stride, int upsample, int flags) {
+    if (H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || (window != 2 && window != 3)) return 0;
+    GemmParams p{};
+    p.mode = 1; p.H = H; p.W = W; p.OH = H; p.OW = W; p.Cin = Cin; p.N = Cout; p.stride = stride; p.upsample = upsample ? 1 : 0;
+    p.KH = p.KW = window; p.ntaps = window * window; p.pad = 1; p.pad_x = 1; p.flags = flags;
+    if (stride != 1) return 0;
+    if (flags & (GEMM_NO_PATCH | (0xF << 8))) return 0;
+    const int bn = vf_conv_patch_tile(p);
+    if (!bn) return 0;
+    return (24L * (H / 16) * (W / 16) * (Cout / bn) >= 160 || (flags & GEMM_PATCH)) ? 1 : 0;
 }
 
 int vface_conv3x3_plus_1x1(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* X2, int64_t ldx2, int C2,
@@ -164,6 +177,11 @@ int vface_groupnorm_stats(const void* x, int64_t ldx, int nimg, int hw, int C, i
 int vface_groupnorm_finalize_cols(const float* colstats, int64_t ld_colstats, int nimg, int hw, int C, int groups, float eps,
                                   float* stats, void* stream) {
     return vf_launch_gn_finalize_cols(colstats, ld_colstats, nimg, hw, C, groups, eps, stats, S(stream));
+}
+
+int vface_groupnorm_coeffs_from_cols(const float* colstats, int64_t ld_colstats, int nimg, int hw, int C, int groups, float eps,
+                                     const float* gamma, const float* beta, float* ab, void* stream) {
+    return vf_launch_gn_coeffs_cols(colstats, ld_colstats, nimg, hw, C, groups, eps, gamma, beta, ab, S(stream));
 }
 
 int vface_groupnorm_apply(const void* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,

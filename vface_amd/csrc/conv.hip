@@ -36,7 +36,9 @@ constexpr int TP = 16;                 // output tile: TP x TP pixels of one ima
 
 // DIAG: diagnostic build (flag 0x4000, tools/stamp_conv.py; never used by the engine): s_memtime stamps around the parts of
 // the kernel and of every K-tile period; the sums go to the colstats pointer as [workgroup][wave][8] floats and feed no output.
-template <class TT, int NT, int KH, int KW, bool DIAG = false>
+// GNT: the build with the fused input normalisation (GroupNorm-apply + SiLU on the staged patch); a separate instantiation so
+// the plain convolution keeps its register allocation.
+template <class TT, int NT, int KH, int KW, bool DIAG = false, bool GNT = false>
 __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
@@ -56,6 +58,10 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned char* sB = smem_raw;                          // [NSLOT][BSLOT]   (first: slot offsets stay < 64 KiB)
     unsigned char* sP = smem_raw + NSLOT * BSLOT;          // [2][PATCH_BYTES]
+    // fused input normalisation (3x3 windows only): (a, b) of the 64 channels of a chunk, [2][1 KiB] (512 B used: one 16-B
+    // LDS-DMA instruction of 32 live lanes; the other 32 lanes write zeros behind it)
+    constexpr bool GNF = GNT && KH == 3;
+    unsigned char* sT = sP + 2 * PATCH_BYTES;
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -98,6 +104,8 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rA2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A2 ? p.A2 : p.A), 0, (int)(p.A2 ? p.a2_bytes : 0u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wt), 0, (int)p.w_bytes, 0x00020000);
+    const bool gn = GNF && p.gn_ab != nullptr;
+    const __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gn ? p.gn_ab : (const float*)p.Wt), 0, (int)(gn ? p.gn_ab_bytes : 0u), 0x00020000);
 
     // ---- patch staging map.  Piece j = patch pixels 8j .. 8j+7; lane l -> pixel pp = 8j + (l >> 3), LDS 16-B slot l & 7 of
     // that pixel's 128-B row holds channel chunk (l & 7) ^ (pp & 7) (conflict-free fragment reads at every tap shift).
@@ -160,6 +168,37 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     auto issue_P2 = [&](int u, int i) {
         const unsigned off = poff2[TAIL ? i : 0] + (unsigned)u * 64u * ES;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(sP + ((nchunks + u) & 1) * PATCH_BYTES + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
+    };
+
+    // (a, b) table of channel chunk c -> sT[c & 1]: 64 channels x 2 floats = 512 B, one instruction of wave 7
+    auto issue_T = [&](int c) {
+        if (gn && wave == 7) {
+            const unsigned off = lane < 32 ? (unsigned)((((long)img * p.ld_gn_ab + c * 64) * 2) * 4 + lane * 16) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rT, LDS_PTR(sT + (c & 1) * 1024), 16, off, 0, 0, 0);
+        }
+    };
+    // GroupNorm-apply (+ SiLU) of patch piece i of chunk c, in place in LDS, by the wave that issued it (so its own
+    // counted vmcnt wait is all the ordering the landing needs): y = act(x * a[ch] + b[ch]) with exactly the a, b and
+    // the arithmetic of gn_apply_kernel; lanes whose pixel lies outside the image keep the zeros the hardware wrote --
+    // the convolution pads the NORMALISED activation with zeros (openaimodel.py:201-205)
+    auto transform_P = [&](int c, int i) {
+        const int piece = wave + 8 * i;
+        if (piece < NPIECES && poff[i] != OOB) {
+            unsigned char* a = sP + (c & 1) * PATCH_BYTES + piece * 1024 + lane * 16;
+            const V8 v = *reinterpret_cast<const V8*>(a);
+            const float4* tb = reinterpret_cast<const float4*>(sT + (c & 1) * 1024 + pch * 64);
+            const float4 t0 = tb[0], t1 = tb[1], t2 = tb[2], t3 = tb[3];
+            const float aa[8] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x, t3.z};
+            const float bb[8] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y, t3.w};
+            V8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = to_f32(v[e]) * aa[e] + bb[e];
+                if (p.gn_silu) f = silu_f(f);
+                o[e] = from_f32<E>(f);
+            }
+            *reinterpret_cast<V8*>(a) = o;
+        }
     };
 
     f4_t acc[NT][4];  // [n tile j][pixel row i]
@@ -233,6 +272,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     // start of a K-tile period: everything older than this wave's pieces of weight tile kt+1 has landed (LDS-DMA retires in
     // order): tile kt, and every patch piece issued before it; then the workgroup barrier that publishes them
     auto period_sync = [&](bool more) {
+        if (gn) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's in-place patch transforms are in LDS
         if (DIAG && (p.flags & 0x200000)) { if (!(p.flags & 0x400000)) __builtin_amdgcn_s_barrier(); return; }   // ablation: no DMA wait
         if (more) {
             if (NB_SPLIT == 0 || wave >= NB_SPLIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB_LO) : "memory");
@@ -247,6 +287,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     // ---- prologue: patch of chunk 0 (all pieces), weight tiles 0 and 1
 #pragma unroll
     for (int i = 0; i < PPW; ++i) issue_P(0, i);
+    issue_T(0);
     issue_B(0, 0);
     if (T > 1) issue_B(1, 1 % NSLOT);
 
@@ -260,6 +301,20 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             period_sync(kt + 1 < T);
+            if (GNF && gn) {
+                if (tap == 0 && c == 0) {
+                    // the first chunk's patch: every wave normalises the pieces it issued, then one extra barrier
+#pragma unroll
+                    for (int i = 0; i < PPW; ++i) transform_P(0, i);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                }
+                // later chunks: the piece this wave issued one K tile ago has landed (the counted wait above) -- normalise it.
+                // (Measured: these ~70 vector instructions per piece sit in the period's critical path and cost more than the
+                // separate normalisation pass they replace -- DESIGN 4; the engine keeps the fused form opt-in.)
+                if (tap >= 1 && tap <= PPW && next_window) transform_P(c + 1, tap - 1);
+            }
             // read_h0 first: its LDS latency runs under the MFMAs of the previous tile's second half
             read_h0(pbase, (tap / KW) * PW + (tap % KW), PW, (unsigned)((tap % NSLOT) * BSLOT));
             __builtin_amdgcn_sched_barrier(0);
@@ -273,6 +328,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
                     else if (TAIL && ntail > 0 && i < 4) issue_P2(0, i);
                 }
             }
+            if (GNF && tap == 0 && next_window) issue_T(c + 1);
             if (kt + 2 < T) issue_B(kt + 2, (tap + 2) % NSLOT);
             __builtin_amdgcn_sched_barrier(0);
             if (!late && kt > 0) { mfma_Y(); __builtin_amdgcn_sched_barrier(0); }
@@ -444,13 +500,16 @@ template <class TT, int NT, int KH, int KW>
 int launch_patch(const GemmParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT, TAPS = KH * KW, NSLOT = (TAPS % 3 == 0) ? 3 : 4;
     constexpr int NPIECES = ((TP + KW - 1) * (TP + KH - 1) + 7) / 8;
-    const size_t lds = 2 * (size_t)NPIECES * 1024 + NSLOT * (size_t)BN * 128;
+    const size_t lds = 2 * (size_t)NPIECES * 1024 + NSLOT * (size_t)BN * 128 + (KH == 3 ? 2048 : 0);
     auto kern = conv_patch_kernel<TT, NT, KH, KW>;
     if constexpr (NT == 5 && KH == 3 && sizeof(typename TT::elem) == 2) {
         if (p.flags & 0x4000) kern = conv_patch_kernel<TT, NT, KH, KW, true>;     // diagnostic stamps (tools/stamp_conv.py)
     }
-    static bool attr_set[2] = {false, false};
-    const bool diag = (p.flags & 0x4000) != 0;
+    if constexpr (KH == 3) {
+        if (p.gn_ab) kern = conv_patch_kernel<TT, NT, KH, KW, false, true>;         // fused GroupNorm-apply + SiLU
+    }
+    static bool attr_set[3] = {false, false, false};
+    const int diag = p.gn_ab ? 2 : ((p.flags & 0x4000) ? 1 : 0);
     if (!attr_set[diag]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VF_ERR_LAUNCH;
@@ -479,6 +538,7 @@ int vf_conv_patch_tile(const GemmParams& p) {
     if ((p.flags & (GEMM_GEGLU | GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE)) || (p.N & 7)) return 0;
     if ((p.flags & 0x4000) && !(p.KH == 3 && p.N % 160 == 0 && p.colstats)) return 0;   // diagnostic build: one instantiation
     if (p.A2 && (((p.K - p.K1) & 63) || p.KH != 3)) return 0;
+    if (p.gn_ab && (p.KH != 3 || (p.ld_gn_ab < p.Cin) || ((uintptr_t)p.gn_ab & 15) || (p.flags & 0x4000))) return 0;
     if (p.colstats && ((p.H * p.W) & 63)) return 0;
     if (p.residual && !p.res_f32 && (((uintptr_t)p.residual & 15) || (p.ldr & 7))) return 0;
     if (((uintptr_t)p.C & 15) || (p.C && (p.ldc & 7))) return 0;

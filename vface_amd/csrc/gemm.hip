@@ -913,13 +913,21 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     // input pixel goes through LDS once per channel chunk instead of once per tap.  The choice looks at the PER-SAMPLE
     // geometry only (grid depth taken at the nominal 24-sample batch): the two kernels produce the same output bits but
     // slice the column statistics differently, so a sample's bits must not depend on which other samples share its launch.
+    if (p.gn_ab) {
+        if (p.mode != 1 || p.M <= 0) return VF_ERR_SHAPE;
+        const unsigned long nimg = (unsigned long)(p.M / (p.OH * p.OW));
+        const unsigned long gb = ((nimg - 1) * (unsigned long)p.ld_gn_ab + p.Cin) * 8ul;
+        if (gb >= 0xFFFFFFF0ul) return VF_ERR_SHAPE;
+        p.gn_ab_bytes = (unsigned)gb;
+    }
     if (p.mode == 1 && !((p.flags >> 8) & 0xF) && !(p.flags & GEMM_NO_PATCH)) {
         const int bn = vf_conv_patch_tile(p);
         if (bn) {
-            const long tiles24 = 24L * (p.H / 16) * (p.W / 16) * (p.N / bn);
+            const long tiles24 = 24L * (p.H / 16) * (p.W / 16) * (p.N / bn);   // (the same rule: capi.cpp vface_conv_uses_patch_kernel)
             if (tiles24 >= 160 || (p.flags & GEMM_PATCH)) return vf_launch_conv_patch(p, dtype, stream);
         }
     }
+    if (p.gn_ab) return VF_ERR_SHAPE;   // the fused input normalisation exists in the patch-staged kernel only
     const int variant = pick_variant(p);
     if ((p.res_f32 || p.C32) && variant != 5 && variant != 6) return VF_ERR_SHAPE;
     if (p.mode == 1 && (p.ntaps != 9 || p.out_phase || p.A2) && variant != 5 && variant != 6) return VF_ERR_SHAPE;

@@ -177,6 +177,34 @@ __global__ __launch_bounds__(64) void gn_finalize_cols_kernel(const float* __res
     }
 }
 
+// gn_finalize_cols + the per-channel scale / shift of gn_apply in one launch: ab[img][c] = (rstd * gamma[c], beta[c] - mean * a) --
+// bit for bit the a[j], b[j] gn_apply_kernel forms, so a convolution that applies them to its operand in LDS (conv.hip) sees
+// exactly what the separate normalisation pass would have stored.
+__global__ __launch_bounds__(64) void gn_coeffs_cols_kernel(const float* __restrict__ colstats, long ld, int hw, int C, int groups,
+                                                            float eps, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ ab) {
+    const int img = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+    const int cpg = C / groups, spi = hw / 64;
+    const int total = cpg * spi;
+    double s = 0.0, q = 0.0;
+    for (int i = lane; i < total; i += 64) {
+        const int sl = i / cpg, c = g * cpg + (i - sl * cpg);
+        const float2 v = *reinterpret_cast<const float2*>(colstats + (((long)img * spi + sl) * ld + c) * 2);
+        s += v.x; q += v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    const double count = (double)hw * cpg;
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+        const float a = rstd * gamma[c];
+        *reinterpret_cast<float2*>(ab + ((long)img * C + c) * 2) = make_float2(a, beta[c] - meanf * a);
+    }
+}
+
 template <class TT, bool IN32>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ x, long ldx,
                                                        const float* __restrict__ stats,
@@ -733,6 +761,14 @@ int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int gro
     });
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(nimg), dim3(64), 0, stream, (const float*)partial, nchunks, groups,
                        (double)hw * (C / groups), eps, stats);
+    return ok();
+}
+
+int vf_launch_gn_coeffs_cols(const float* colstats, long ld, int nimg, int hw, int C, int groups, float eps, const float* gamma,
+                             const float* beta, float* ab, hipStream_t stream) {
+    if (!colstats || !gamma || !beta || !ab || nimg <= 0 || hw <= 0 || C <= 0 || groups <= 0) return VF_ERR_ARG;
+    if ((hw & 63) || groups > 64 || C % groups || (ld & 1)) return VF_ERR_SHAPE;
+    hipLaunchKernelGGL(gn_coeffs_cols_kernel, dim3(groups, nimg), dim3(64), 0, stream, colstats, ld, hw, C, groups, eps, gamma, beta, ab);
     return ok();
 }
 

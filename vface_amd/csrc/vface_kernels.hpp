@@ -36,6 +36,12 @@ struct GemmParams {
     int res_f32;
     float* C32;
     long ldc32;
+    // fused input normalisation (patch-staged convolution only): the operand the matrix cores see is
+    // act(x * a[img][ci] + b[img][ci]) with (a, b) fp32 pairs at gn_ab[(img * ld_gn_ab + ci) * 2]; act = SiLU if gn_silu
+    const float* gn_ab;
+    long ld_gn_ab;
+    int gn_silu;
+    unsigned gn_ab_bytes;   // filled by the launcher
     const void* zeros;  // >= 16 zero bytes, 16-B aligned
     int flags;
     unsigned a_bytes, a2_bytes, w_bytes;  // filled by the launcher: extents of the operand views
@@ -77,6 +83,8 @@ int vf_launch_layernorm(const void* x, long ldx, const float* gamma, const float
                         int C, float eps, int in_f32, int dtype, hipStream_t stream);
 int vf_launch_gn_finalize_cols(const float* colstats, long ld, int nimg, int hw, int C, int groups, float eps, float* stats,
                                hipStream_t stream);
+int vf_launch_gn_coeffs_cols(const float* colstats, long ld, int nimg, int hw, int C, int groups, float eps, const float* gamma,
+                             const float* beta, float* ab, hipStream_t stream);
 int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
                        float* stats, int in_f32, int dtype, hipStream_t stream);
 int vf_gn_partial_floats(int nimg, int hw, int C, int groups);

@@ -278,6 +278,13 @@ class UNetEngine:
         # fp32 residual stream: residual sums are carried between kernels in fp32, 16-bit copies exist only
         # where a matrix-core operand needs them.  VFACE_STREAM32=0 restores the all-16-bit activations (A/B switch).
         self.stream32 = os.environ.get("VFACE_STREAM32", "1") != "0"
+        # GroupNorm-apply + SiLU of a ResBlock fused into the patch-staged convolution's operand path (openaimodel.py:201-205,
+        # 225-232 `GroupNorm32 -> SiLU -> conv`): "both" = in_layers and out_layers; "out" = out_layers only (the in_layers
+        # normalisation then reads the fp32 carrier in its own pass instead of the 16-bit copy); "off" (default) = separate
+        # gn_apply passes.  Exact (bit-identical to the separate pass on the same input) but MEASURED SLOWER on this kernel:
+        # the ~70 vector instructions per 1-KiB patch piece sit in the K-tile period's critical path -- 28.22 vs 27.49 ms per
+        # DDIM step (conv 9.46 vs 7.77 ms, gn_apply 0 vs 1.0 ms), DESIGN 4 -- so it is opt-in.
+        self.fuse_gn = os.environ.get("VFACE_FUSE_GN", "off")
         hip.load()
 
     # ------------------------------------------------------------------ weights
@@ -461,7 +468,7 @@ class UNetEngine:
         return Act(y, x.N, x.H, x.W)
 
     def _conv(self, x: Act, w: dict, tgt, stride=1, upsample=False, rowbias=None, residual=None, out_f32=False,
-              stream=True) -> Act:
+              stream=True, gn_ab=None) -> Act:
         """``tgt``: None (allocate) or ``(16-bit out view | None, colstats view | None, fp32 carrier view | None)``.
         ``residual``: an ``Act`` / tensor added in the epilogue.  ``stream=False``: a branch activation (consumed by one
         GEMM / GroupNorm only): 16-bit output, no fp32 carrier."""
@@ -485,22 +492,38 @@ class UNetEngine:
             return Act(out, x.N, OH, OW, cs, o32)
         hip.conv3x3(x.t, w["w"], out, nimg=x.N, H=x.H, W=x.W, cin=w["cinp"], cout=w["cout"], ldx=x.ld,
                     ldy=ldy, stride=stride, upsample=upsample, bias=w["b"], rowbias=rowbias,
-                    flags=hip.EPI_OUT_F32 if out_f32 else 0, colstats=cs, out32=o32,
+                    flags=hip.EPI_OUT_F32 if out_f32 else 0, colstats=cs, out32=o32, gn_ab=gn_ab, gn_silu=gn_ab is not None,
                     **(self._resid(residual) if residual is not None else {}))
         return Act(out, x.N, OH, OW, cs, o32)
 
+    def _gn_fusable(self, x: Act, w: dict, which: str) -> bool:
+        """Can GroupNorm-apply + SiLU of ``x`` ride in the operand path of the 3x3 convolution ``w``?  Needs producer-side
+        column statistics, a 16-bit copy of ``x`` and a launch that runs the patch-staged kernel."""
+        if self.fuse_gn == "off" or (which == "in" and self.fuse_gn != "both"):
+            return False
+        return x.cs is not None and x.t is not None and x.C == w["cinp"] and \
+            hip.conv_uses_patch_kernel(x.H, x.W, w["cinp"], w["cout"], 3, 1, False)
+
     def _res(self, x: Act, p: dict, emb_all: torch.Tensor, out) -> Act:
         """ResBlock._forward (openaimodel.py:255-275), non-updown, no scale-shift."""
-        h = self._gn(x, p["in_gn"], 1e-5, True)
         a, b = p["emb_slice"]
-        h = self._conv(h, p["conv1"], None, rowbias=emb_all[:, a:b], stream=False)
-        h = self._gn(h, p["out_gn"], 1e-5, True)
+        if self._gn_fusable(x, p["conv1"], "in"):
+            ab = hip.groupnorm_coeffs_from_cols(x.cs, p["in_gn"][0], p["in_gn"][1], nimg=x.N, hw=x.hw, C_=x.C, eps=1e-5)
+            h = self._conv(x, p["conv1"], None, rowbias=emb_all[:, a:b], stream=False, gn_ab=ab)
+        else:
+            h = self._gn(x, p["in_gn"], 1e-5, True)
+            h = self._conv(h, p["conv1"], None, rowbias=emb_all[:, a:b], stream=False)
+        gn2 = None
+        if self._gn_fusable(h, p["conv2"], "out"):
+            gn2 = hip.groupnorm_coeffs_from_cols(h.cs, p["out_gn"][0], p["out_gn"][1], nimg=h.N, hw=h.hw, C_=h.C, eps=1e-5)
+        else:
+            h = self._gn(h, p["out_gn"], 1e-5, True)
         if "conv2_skip" in p and os.environ.get("VFACE_NO_SKIP_FUSION") != "1":   # (env: A/B switch for measurements)
             w = p["conv2_skip"]
             o, cs, o32 = self._new_target(x.M, w["cout"], x.hw) if out is None else out
             hip.conv3x3_plus_1x1(h.t, x.t, w["w"], o, nimg=x.N, H=x.H, W=x.W, cin=w["cinp"], c2=w["c2"], cout=w["cout"],
                                  ldx=h.ld, ldx2=x.ld, ldy=o.stride(0) if o is not None else 0, bias=w["b"], colstats=cs,
-                                 out32=o32)
+                                 out32=o32, gn_ab=gn2, gn_silu=gn2 is not None)
             return Act(o, x.N, x.H, x.W, cs, o32)
         if "skip" in p:
             if self.stream32 and p["conv2"]["cout"] % 8 == 0:
@@ -511,7 +534,7 @@ class UNetEngine:
                 self._gemm(x.t, p["skip"], skip, hw=x.H * x.W)
         else:
             skip = x
-        return self._conv(h, p["conv2"], out, residual=skip)
+        return self._conv(h, p["conv2"], out, residual=skip, gn_ab=gn2)
 
     def _attn1(self, xln: torch.Tensor, resid: torch.Tensor, p: dict, cfg: Optional[HookCfg], a2vec: torch.Tensor,
                N: int, n: int, heads: int, hw) -> torch.Tensor:

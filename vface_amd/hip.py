@@ -27,7 +27,8 @@ _i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size
 
 class Stream32(C.Structure):
     """``vface_stream32`` of the header: the optional fp32 residual-stream operands of a GEMM-family call."""
-    _fields_ = [("residual32", _vp), ("ldr32", _i64), ("out32", _vp), ("ldo32", _i64)]
+    _fields_ = [("residual32", _vp), ("ldr32", _i64), ("out32", _vp), ("ldo32", _i64),
+                ("in_scale_shift", _vp), ("ld_scale_shift", _i64), ("in_silu", _i32)]
 
 
 _s32p = C.POINTER(Stream32)
@@ -42,6 +43,7 @@ SIGNATURES = {
     "vface_conv3x3": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp,
                                 _i64, _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _s32p]),
     "vface_splitk_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i32]),
+    "vface_conv_uses_patch_kernel": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "vface_conv3x3_plus_1x1": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _i32,
                                          _vp, _i64, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _s32p]),
     "vface_upsample2x_conv3x3_phase": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32,
@@ -53,6 +55,7 @@ SIGNATURES = {
     "vface_layernorm": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _i32, _i32, _vp]),
     "vface_groupnorm_partial_floats": (C.c_int, [_i32, _i32, _i32, _i32]),
     "vface_groupnorm_stats": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _i32, _vp]),
+    "vface_groupnorm_coeffs_from_cols": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "vface_groupnorm_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vface_flow_warp": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                                   _f32, _i32, _vp, _vp, _i32, _vp]),
@@ -130,16 +133,20 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
-def _s32(residual32: Optional[torch.Tensor], out32: Optional[torch.Tensor]):
+def _s32(residual32: Optional[torch.Tensor], out32: Optional[torch.Tensor], gn_ab: Optional[torch.Tensor] = None,
+         gn_silu: bool = False):
     """The ``vface_stream32`` argument: fp32 residual operand and / or fp32 copy of the output (2-D views, unit column
-    stride); None when neither is given."""
-    if residual32 is None and out32 is None:
+    stride), and for convolutions the fused input normalisation ``gn_ab`` ``[nimg, C, 2]`` fp32; None when nothing is given."""
+    if residual32 is None and out32 is None and gn_ab is None:
         return None
     for t in (residual32, out32):
         if t is not None and (t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1):
             raise VFaceHipError("fp32 residual-stream tensors must be 2-D fp32 views with unit column stride")
+    if gn_ab is not None and (gn_ab.dtype != torch.float32 or gn_ab.dim() != 3 or gn_ab.shape[2] != 2 or not gn_ab.is_contiguous()):
+        raise VFaceHipError("gn_ab must be a contiguous fp32 [nimg, C, 2] tensor (groupnorm_coeffs_from_cols)")
     return C.byref(Stream32(_p(residual32), residual32.stride(0) if residual32 is not None else 0,
-                            _p(out32), out32.stride(0) if out32 is not None else 0))
+                            _p(out32), out32.stride(0) if out32 is not None else 0,
+                            _p(gn_ab), gn_ab.shape[1] if gn_ab is not None else 0, int(gn_silu)))
 
 
 _zeros = {}
@@ -189,7 +196,9 @@ def gemm(a: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, M: int, N: int
 
 def conv3x3(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, H: int, W: int, cin: int, cout: int,
             ldx: int, ldy: int, stride: int = 1, upsample: bool = False, bias=None, rowbias=None, residual=None,
-            ldr: int = 0, flags: int = 0, colstats=None, split_k: bool = True, residual32=None, out32=None):
+            ldr: int = 0, flags: int = 0, colstats=None, split_k: bool = True, residual32=None, out32=None, gn_ab=None,
+            gn_silu: bool = False):
+    """``gn_ab`` (+ ``gn_silu``): GroupNorm-apply (+ SiLU) of the INPUT fused into the patch-staged kernel's operand path."""
     lib = load()
     vh, vw = (2 * H, 2 * W) if upsample else (H, W)
     M = nimg * ((vh - 1) // stride + 1) * ((vw - 1) // stride + 1)
@@ -198,8 +207,14 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, 
                            _p(rowbias), rowbias.stride(0) if rowbias is not None else 0, _p(residual), ldr, _p(out),
                            ldy, _p(zeros_page(x.device)), flags, dtype_code(x.dtype), _p(colstats),
                            colstats.stride(0) // 2 if colstats is not None else 0, _p(ws), ws_bytes, _stream(),
-                           _s32(residual32, out32))
+                           _s32(residual32, out32, gn_ab, gn_silu))
     _check(rc, "vface_conv3x3")
+
+
+def conv_uses_patch_kernel(H: int, W: int, cin: int, cout: int, window: int = 3, stride: int = 1, upsample: bool = False,
+                           flags: int = 0) -> bool:
+    """True if a convolution launch of this geometry runs conv.hip's patch-staged kernel (else gemm.hip's implicit GEMM)."""
+    return bool(load().vface_conv_uses_patch_kernel(H, W, cin, cout, window, stride, int(upsample), flags))
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, B: int, heads: int, n: int,
@@ -240,6 +255,16 @@ def groupnorm_stats_from_cols(colstats: torch.Tensor, *, nimg: int, hw: int, C_:
                                               _stream())
     _check(rc, "vface_groupnorm_finalize_cols")
     return stats
+
+
+def groupnorm_coeffs_from_cols(colstats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, nimg: int, hw: int, C_: int,
+                               groups: int = 32, eps: float = 1e-5) -> torch.Tensor:
+    """Per-(image, channel) scale / shift (a, b) of GroupNorm from producer-side column statistics: fp32 [nimg, C, 2]."""
+    ab = torch.empty(nimg, C_, 2, dtype=torch.float32, device=colstats.device)
+    rc = load().vface_groupnorm_coeffs_from_cols(_p(colstats), colstats.stride(0) // 2, nimg, hw, C_, groups, eps, _p(gamma),
+                                                 _p(beta), _p(ab), _stream())
+    _check(rc, "vface_groupnorm_coeffs_from_cols")
+    return ab
 
 
 def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor,
@@ -378,7 +403,7 @@ def upsample2x_conv3x3(x: torch.Tensor, wt_phases: torch.Tensor, out: torch.Tens
 
 def conv3x3_plus_1x1(x: torch.Tensor, x2: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, H: int, W: int,
                      cin: int, c2: int, cout: int, ldx: int, ldx2: int, ldy: int, bias=None, rowbias=None, flags: int = 0,
-                     colstats=None, split_k: bool = True, out32=None):
+                     colstats=None, split_k: bool = True, out32=None, gn_ab=None, gn_silu: bool = False):
     """out = conv3x3(x) + x2 @ W2^T + bias (a ResBlock's second conv plus its 1x1 shortcut); ``wt``: [cout, 9*cin + c2]."""
     lib = load()
     M, K = nimg * H * W, 9 * cin + c2
@@ -387,5 +412,5 @@ def conv3x3_plus_1x1(x: torch.Tensor, x2: torch.Tensor, wt: torch.Tensor, out: t
                                     rowbias.stride(0) if rowbias is not None else 0, _p(out), ldy, _p(zeros_page(x.device)),
                                     flags, dtype_code(x.dtype), _p(colstats),
                                     colstats.stride(0) // 2 if colstats is not None else 0, _p(ws), ws_bytes, _stream(),
-                                    _s32(None, out32))
+                                    _s32(None, out32, gn_ab, gn_silu))
     _check(rc, "vface_conv3x3_plus_1x1")
