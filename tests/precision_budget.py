@@ -34,6 +34,7 @@ class Emu:
         q = lambda t: t.to(half).float()
         self.a = q if act16 else (lambda t: t)
         self.s = q if stream16 else (lambda t: t)
+        self.si = self.s           # rounding of a transformer block's INTERIOR running sums (t0, t1); default: as the stream
         self.sd = {k: v.float() for k, v in sd.items()}
         self.sdh = {k: (q(v.float()) if (w16 and (w16_filter is None or w16_filter(k))) else v.float()) for k, v in sd.items()}
 
@@ -72,7 +73,7 @@ def st(c, l, x, context, registry, hw0):
     p = l.prefix
     B, C, H, W = x.shape
     g = c.a(F.group_norm(x, 32, c.f(p + ".norm.weight"), c.f(p + ".norm.bias"), 1e-6))
-    t0 = c.s(conv(c, g, p + ".proj_in", pad=0)).permute(0, 2, 3, 1).reshape(B, H * W, C)
+    t0 = c.si(conv(c, g, p + ".proj_in", pad=0)).permute(0, 2, 3, 1).reshape(B, H * W, C)
     tp = p + ".transformer_blocks.0"
     ln = lambda v, q: c.a(F.layer_norm(v, (C,), c.f(f"{tp}.{q}.weight"), c.f(f"{tp}.{q}.bias"), 1e-5))
     cfg = registry.get(f"{tp}.attn1") if registry else None
@@ -97,7 +98,7 @@ def st(c, l, x, context, registry, hw0):
     # attn2 on a single token == to_out(to_v(ctx)) broadcast, fp32 row bias
     a2 = F.linear(c.a(F.linear(c.a(context.reshape(B, -1)), c.w(f"{tp}.attn2.to_v.weight"))),
                   c.w(f"{tp}.attn2.to_out.0.weight"), c.f(f"{tp}.attn2.to_out.0.bias"))
-    t1 = c.s(F.linear(o, c.w(f"{tp}.attn1.to_out.0.weight"), c.f(f"{tp}.attn1.to_out.0.bias")) + a2[:, None, :] + t0)
+    t1 = c.si(F.linear(o, c.w(f"{tp}.attn1.to_out.0.weight"), c.f(f"{tp}.attn1.to_out.0.bias")) + a2[:, None, :] + t0)
     gg = F.linear(ln(t1, "norm3"), c.w(tp + ".ff.net.0.proj.weight"), c.f(tp + ".ff.net.0.proj.bias"))
     aa, gate = gg.chunk(2, dim=-1)
     ff = c.a(aa * F.gelu(gate))
@@ -170,6 +171,12 @@ def main():
         print(f"fp32 oracle: {time.time() - t0:.1f} s", flush=True)
         chk = forward(Emu(sd, False, False, False), spec, x, t, ctx, reg)
         print(f"emulator with every switch off vs oracle: {rel(chk, ref):.2e}", flush=True)
+        def inner16(**kw):
+            e = Emu(sd, half=half, **kw)
+            e.si = lambda t: t.to(half).float()
+            return e
+        y = forward(inner16(w16=True, act16=True, stream16=False), spec, x, t, ctx, reg)
+        print(f"{'fp32 main stream, 16-bit block-interior sums (t0, t1)':55s} {rel(y, ref):.3e}", flush=True)
         rows = [
             ("reference autocast rounding points (oracle half=)", None),
             ("HIP path today: w16 + act16 + stream16", dict(w16=True, act16=True, stream16=True)),

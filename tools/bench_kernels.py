@@ -50,10 +50,15 @@ def main():
             b = torch.zeros(cout, device=DEV)
             fl = 2.0 * N * OH * OH * cout * 9 * cin
             row = f"H{H:3d} {cin:4d}->{cout:4d} s{stride}: "
-            for name, f in cvariants.items():
-                med, best = timeit(lambda: hip.conv3x3(x, w, out, nimg=N, H=H, W=H, cin=cin, cout=cout, ldx=cin, ldy=cout,
-                                                       stride=stride, bias=b, flags=f))
-                row += f"{name} {fl / med / 1e9:6.0f}|{fl / best / 1e9:6.0f}  "
+            res = {n: [] for n in cvariants}
+            for rnd_ in range(3):      # interleaved rounds in one process (guide rule 24)
+                for name, f in cvariants.items():
+                    med, best = timeit(lambda: hip.conv3x3(x, w, out, nimg=N, H=H, W=H, cin=cin, cout=cout, ldx=cin, ldy=cout,
+                                                           stride=stride, bias=b, flags=f), iters=6, warm=2)
+                    res[name].append(med)
+            for name in cvariants:
+                v = sorted(res[name])
+                row += f"{name} {fl / v[1] / 1e9:6.0f}|{fl / v[0] / 1e9:6.0f}  "
             print(row, flush=True)
     if "gemm" in a.what:
         print("== plain GEMM")
