@@ -36,7 +36,7 @@ def main():
     dt = torch.float16
     g = torch.Generator(device="cpu").manual_seed(0)
     rnd = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dt).to(DEV)
-    variants = {"auto": 0, "db128": 0x500, "db160": 0x600}
+    variants = {"auto": 0, "persist": hip.TUNE_PERSISTENT, "db128": 0x500, "db160": 0x600}
     cvariants = {"patch": hip.TUNE_PATCH, "patch_split": hip.TUNE_PATCH | 0x2000, "im2col": hip.TUNE_NO_PATCH}
     if "conv" in a.what:
         print("== conv3x3 implicit GEMM (TFLOP/s median | best), variants:", list(cvariants))
@@ -72,12 +72,18 @@ def main():
             bias = torch.zeros(Nn, device=DEV)
             fl = 2.0 * M * Nn * K
             row = f"{name0:8s} M{M:6d} N{Nn:5d} K{K:5d}: "
-            for name, f in variants.items():
-                if geglu and name in ("db160", "db160nox", "pp160"):
-                    continue
-                ff = f | (hip.EPI_GEGLU if geglu else 0)
-                med, best = timeit(lambda: hip.gemm(x, w, out, M=M, N=Nn, K=K, lda=K, ldc=out.shape[1], bias=bias, flags=ff))
-                row += f"{name} {fl / med / 1e9:6.0f}|{fl / best / 1e9:6.0f}  "
+            res = {n: [] for n in variants}
+            for rnd_ in range(3):
+                for name, f in variants.items():
+                    if geglu and name in ("db160", "db160nox", "pp160"):
+                        continue
+                    ff = f | (hip.EPI_GEGLU if geglu else 0)
+                    med, best = timeit(lambda: hip.gemm(x, w, out, M=M, N=Nn, K=K, lda=K, ldc=out.shape[1], bias=bias, flags=ff), iters=6, warm=2)
+                    res[name].append(med)
+            for name in variants:
+                if res[name]:
+                    v = sorted(res[name])
+                    row += f"{name} {fl / v[1] / 1e9:6.0f}|{fl / v[0] / 1e9:6.0f} ({v[1] * 1e3:.0f} us)  "
             print(row, flush=True)
     if "attn" in a.what:
         print("== attention")

@@ -389,6 +389,15 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
         const long mrow0 = ((long)img * p.H + ty0 + wm * 4) * p.W + tx0;   // output row (pixel index) of (i = 0, r = 0)
         const float* rb = rowbias ? rowbias + (long)img * p.ld_rowbias : nullptr;
+        // bias / row bias of this wave's NT column tiles, requested once up front (see gemm.hip's wide epilogue); kept apart so
+        // the fp32 sum order stays (acc + bias) + rowbias, as in gemm.hip
+        float4 bj[NT], rbj[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int nb = n0 + wn * WN + j * 16 + fq * 4;
+            bj[j] = (bias && nb < p.N) ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rbj[j] = (rb && nb < p.N) ? *reinterpret_cast<const float4*>(rb + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long mbase = mrow0 + (long)i * p.W;
@@ -415,10 +424,9 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
                 for (int j = 0; j < NT; ++j) {
                     const int nb = n0 + wn * WN + j * 16 + fq * 4;
                     float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-                    if (nb < p.N) {
-                        if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                        if (rb) { const float4 b = *reinterpret_cast<const float4*>(rb + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                    }
+                    (void)nb;
+                    if (bias) { v.x += bj[j].x; v.y += bj[j].y; v.z += bj[j].z; v.w += bj[j].w; }
+                    if (rb) { v.x += rbj[j].x; v.y += rbj[j].y; v.z += rbj[j].z; v.w += rbj[j].w; }
                     *reinterpret_cast<float4*>(srow + j * 16) = v;
                 }
             }

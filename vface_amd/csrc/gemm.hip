@@ -292,6 +292,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         float* C32 = p.C32;
         float* colstats = p.colstats;
         const bool want_stats = colstats && !(p.flags & 0x4000);
+        const bool diag = p.flags & 0x4000;                               // ablations (tools/stamp_gemm.py), diagnostic launches only
+        const bool abl_store = diag && (p.flags & 0x200000), abl_bias = diag && (p.flags & 0x400000);
         float* scr = scr_base + wave * (16 * SP);
         const int OW = gg ? WN / 2 : WN;              // output columns of this wave
         const int CH = OW >> 3;                       // 16-byte chunks per output row
@@ -303,6 +305,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         float s8[8], q8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+        // bias and per-sample row bias of this wave's NT column tiles: requested ONCE, up front (stamps: loading them inside
+        // the row loop -- a dependent L2 round trip per 16-row pass -- was 35 % of the epilogue's 16.6 k cycles).  The row
+        // bias is preloaded when the whole 128-row tile belongs to one sample (wave-uniform test), else read per row as before;
+        // the two are kept apart so the fp32 sum order stays (acc + bias) + rowbias.
+        float4 bj[NT], rbj[NT];
+        const bool one_sample = rowbias && (em0 / p.rows_per_sample) == (min(em0 + BM - 1, p.M - 1) / p.rows_per_sample);
+        {
+            const float* rb0 = one_sample ? rowbias + (long)(em0 / p.rows_per_sample) * p.ld_rowbias : nullptr;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int nb = en0 + wn * WN + j * 16 + fq * 4;
+                const bool in = nb < p.N && !abl_bias;
+                bj[j] = (bias && in) ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rbj[j] = (rb0 && in) ? *reinterpret_cast<const float4*>(rb0 + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         // the residual rows of the whole tile are requested up front (never with GEGLU, so the chunk geometry is static):
         // their HBM latency then runs under the LDS transposes instead of once per 16-row pass
         constexpr int LPRC = 64 / (NT * 2), RI = (16 + LPRC - 1) / LPRC;
@@ -335,17 +353,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
             }
             {
                 const int m = em0 + wm * 64 + i * 16 + fr;
-                const float* rb = (rowbias && m < p.M) ? rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+                const float* rb = (rowbias && !one_sample && m < p.M) ? rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
                 float* srow = scr + fr * SP + fq * 4;
                 if (!gg) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
                         const int nb = en0 + wn * WN + j * 16 + fq * 4;
                         float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-                        if (nb < p.N) {
-                            if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                            if (rb) { const float4 b = *reinterpret_cast<const float4*>(rb + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-                        }
+                        if (bias) { v.x += bj[j].x; v.y += bj[j].y; v.z += bj[j].z; v.w += bj[j].w; }
+                        if (one_sample) { v.x += rbj[j].x; v.y += rbj[j].y; v.z += rbj[j].z; v.w += rbj[j].w; }
+                        else if (rb && nb < p.N && !abl_bias) { const float4 b = *reinterpret_cast<const float4*>(rb + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
                         *reinterpret_cast<float4*>(srow + j * 16) = v;
                     }
                 } else if constexpr ((NT & 1) == 0) {
@@ -355,9 +372,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                         float a[4], g[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { a[r] = acc[2 * jj][i][r]; g[r] = acc[2 * jj + 1][i][r]; }
-                        if (bias && nb < p.N) {
-                            const float4 ba = *reinterpret_cast<const float4*>(bias + nb);
-                            const float4 bg = *reinterpret_cast<const float4*>(bias + nb + 16);
+                        (void)nb;
+                        if (bias) {      // bj[2jj] = bias of the value rows, bj[2jj + 1] = of the gate rows (16 further)
+                            const float4 ba = bj[2 * jj], bg = bj[2 * jj + 1];
                             a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
                             g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
                         }
@@ -397,7 +414,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                             const int hw = p.OH * p.OW, img = m / hw, rem = m - img * hw, oy = rem / p.OW, ox = rem - oy * p.OW;
                             orow = ((long)img * 2 * p.OH + 2 * oy + ((p.out_phase >> 1) & 1)) * (2 * p.OW) + 2 * ox + (p.out_phase & 1);
                         }
-                        if (Cout) *reinterpret_cast<V8*>(Cout + orow * p.ldc + ncol) = o;
+                        if (Cout && !abl_store) *reinterpret_cast<V8*>(Cout + orow * p.ldc + ncol) = o;
+                        if (abl_store) asm volatile("" ::"v"(o));
                         if (C32) {
                             float* d32 = C32 + orow * p.ldc32 + ncol;
                             *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
