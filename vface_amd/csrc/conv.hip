@@ -27,6 +27,7 @@
 //   and per-accumulator MFMA order as gemm.hip, so results are BIT-IDENTICAL to that kernel's (tests rely on it).
 // * Epilogue: the wide (LDS-transposed, 16 B per lane) epilogue of gemm.hip: bias + per-sample row bias + residual
 //   (16-bit or the fp32 stream) summed in fp32, single rounding, optional fp32 carrier, per-64-pixel column statistics.
+#include <type_traits>
 #include "common.hpp"
 #include "vface_kernels.hpp"
 
@@ -38,7 +39,10 @@ constexpr int TP = 16;                 // output tile: TP x TP pixels of one ima
 // the kernel and of every K-tile period; the sums go to the colstats pointer as [workgroup][wave][8] floats and feed no output.
 // GNT: the build with the fused input normalisation (GroupNorm-apply + SiLU on the staged patch); a separate instantiation so
 // the plain convolution keeps its register allocation.
-template <class TT, int NT, int KH, int KW, bool DIAG = false, bool GNT = false>
+// RM: the residual form of the epilogue (0 none, 1 16-bit, 2 the fp32 stream) as an instantiation of its own -- three copies of
+// the epilogue inside one kernel cost 19 spilled registers, some reloaded inside the K loop; -1 = chosen at run time (the
+// diagnostic and fused-normalisation builds, which the engine's default path does not launch).
+template <class TT, int NT, int KH, int KW, bool DIAG = false, bool GNT = false, int RM = -1>
 __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
@@ -367,13 +371,16 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     // ---- wide epilogue (see gemm.hip): per pixel row i, transpose the wave's 16 x WN accumulator rows through LDS in
     // fp32, sum bias / row bias / residual, round once, 16 B per lane
     __syncthreads();
-    {
+    // RMODE: the residual form as a compile-time constant (0 none, 1 16-bit, 2 the fp32 stream), every load of the epilogue
+    // requested up front and retired by one explicit wait -- see gemm.hip's wide epilogue for the measurement behind this
+    auto epilogue = [&](auto rmode_tag) {
+        constexpr int RMODE = decltype(rmode_tag)::value;
         constexpr int WN = NT * 16;
         constexpr int SP = WN + 4;
         const float* bias = p.bias;
         const float* rowbias = p.rowbias;
-        const E* res = p.res_f32 ? nullptr : reinterpret_cast<const E*>(p.residual);
-        const float* res32 = p.res_f32 ? reinterpret_cast<const float*>(p.residual) : nullptr;
+        const E* res = RMODE == 1 ? reinterpret_cast<const E*>(p.residual) : nullptr;
+        const float* res32 = RMODE == 2 ? reinterpret_cast<const float*>(p.residual) : nullptr;
         E* Cout = reinterpret_cast<E*>(p.C);
         float* C32 = p.C32;
         float* colstats = p.colstats;
@@ -383,92 +390,119 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         constexpr int RI = (16 + LPR - 1) / LPR;
         const bool act = lane < LPR * CH;
         const int rch = lane % CH, rrow = lane / CH;
-        const int ncol = n0 + wn * WN + rch * 8;
+        const int ncol = n0 + wn * WN + rch * 8;  // (< N: the launch takes whole channel tiles only)
         float s8[8], q8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
         const long mrow0 = ((long)img * p.H + ty0 + wm * 4) * p.W + tx0;   // output row (pixel index) of (i = 0, r = 0)
         const float* rb = rowbias ? rowbias + (long)img * p.ld_rowbias : nullptr;
-        // bias / row bias of this wave's NT column tiles, requested once up front (see gemm.hip's wide epilogue); kept apart so
-        // the fp32 sum order stays (acc + bias) + rowbias, as in gemm.hip
+        // bias / row bias of this wave's NT column tiles, requested once up front (see gemm.hip's wide epilogue)
         float4 bj[NT], rbj[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int nb = n0 + wn * WN + j * 16 + fq * 4;
-            bj[j] = (bias && nb < p.N) ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
-            rbj[j] = (rb && nb < p.N) ? *reinterpret_cast<const float4*>(rb + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bj[j] = bias ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rbj[j] = rb ? *reinterpret_cast<const float4*>(rb + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        // residual rows: DEPTH pixel rows in flight -- the whole tile where the registers allow, else (NT = 5: up to 24
+        // registers per pixel row) two, the row i + 2 requested as soon as row i has been summed, a full pass ahead of its use
+        constexpr int DEPTH = (NT == 5 && RMODE != 0) ? 2 : 4;
+        V8 r16[RMODE == 1 ? DEPTH : 1][RI];
+        float4 r32[RMODE == 2 ? DEPTH : 1][RI][2];
+        auto load_res = [&](int i, int slot) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long mbase = mrow0 + (long)i * p.W;
-            // residual rows of this pixel row, requested before the transpose
-            V8 r16[RI];
-            float4 r32[RI][2];
-            if (res || res32) {
-#pragma unroll
-                for (int it = 0; it < RI; ++it) {
-                    const int r = rrow + it * LPR;
-                    if (act && r < 16 && ncol < p.N) {
-                        if (res) r16[it] = *reinterpret_cast<const V8*>(res + (mbase + r) * p.ldr + ncol);
-                        else {
-                            const float* rp = res32 + (mbase + r) * p.ldr + ncol;
-                            r32[it][0] = *reinterpret_cast<const float4*>(rp);
-                            r32[it][1] = *reinterpret_cast<const float4*>(rp + 4);
-                        }
+            for (int it = 0; it < RI; ++it) {
+                const int r = rrow + it * LPR;
+                const long off = (mrow0 + (long)i * p.W + r) * p.ldr + ncol;
+                const bool in = act && r < 16;
+                if constexpr (RMODE == 1) {
+                    r16[slot][it] = V8{};
+                    if (in) r16[slot][it] = *reinterpret_cast<const V8*>(res + off);
+                } else if constexpr (RMODE == 2) {
+                    r32[slot][it][0] = r32[slot][it][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (in) {
+                        r32[slot][it][0] = *reinterpret_cast<const float4*>(res32 + off);
+                        r32[slot][it][1] = *reinterpret_cast<const float4*>(res32 + off + 4);
                     }
                 }
             }
+        };
+        if constexpr (RMODE != 0) {
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) load_res(i, i);
+        }
+        // bias, then row bias, summed into the accumulators -- (acc + bias) + rowbias, as in gemm.hip; absent terms are zeros
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[j][i][0] = (acc[j][i][0] + bj[j].x) + rbj[j].x; acc[j][i][1] = (acc[j][i][1] + bj[j].y) + rbj[j].y;
+                acc[j][i][2] = (acc[j][i][2] + bj[j].z) + rbj[j].z; acc[j][i][3] = (acc[j][i][3] + bj[j].w) + rbj[j].w;
+            }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): from here on only stores are in flight
+        // Output rows: one pointer per lane (pixel rrow of the wave's first image row) + a wave-uniform offset per (i, it).  A
+        // launch that is one output-parity phase of conv(nearest x2 upsample) writes pixel (oy, ox) of its grid to pixel
+        // (2 oy + py, 2 ox + px) of the 2H x 2W output: image rows are 4W pixels apart there, pixels 2.
+        const bool phased = p.out_phase != 0;
+        const long brow = phased ? ((long)img * 2 * p.H + 2 * (ty0 + wm * 4) + ((p.out_phase >> 1) & 1)) * (2 * p.W) + 2 * (tx0 + rrow) + (p.out_phase & 1)
+                                 : mrow0 + rrow;
+        const long step_i = phased ? 4L * p.W : (long)p.W;
+        const int step_r = phased ? 2 : 1;
+        E* pC = Cout + brow * p.ldc + ncol;
+        float* pC32 = C32 + brow * p.ldc32 + ncol;
+        const float* lrd = scr + rch * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             {
                 float* srow = scr + fr * SP + fq * 4;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    const int nb = n0 + wn * WN + j * 16 + fq * 4;
-                    float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-                    (void)nb;
-                    if (bias) { v.x += bj[j].x; v.y += bj[j].y; v.z += bj[j].z; v.w += bj[j].w; }
-                    if (rb) { v.x += rbj[j].x; v.y += rbj[j].y; v.z += rbj[j].z; v.w += rbj[j].w; }
-                    *reinterpret_cast<float4*>(srow + j * 16) = v;
-                }
+                for (int j = 0; j < NT; ++j)
+                    *reinterpret_cast<float4*>(srow + j * 16) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
             }
-            // LDS operations of one wave execute in order: the reads below see the writes above
-            if (act) {
+            // LDS operations of one wave execute in order: the reads below see the writes above.  Every lane reads (rows clamped
+            // into the scratch), only the stores are predicated: the RI x 2 reads of the pass go out back to back.
+            float4 x[RI][2];
 #pragma unroll
-                for (int it = 0; it < RI; ++it) {
-                    const int r = rrow + it * LPR;
-                    if (r < 16 && ncol < p.N) {
-                        const float4 x0 = *reinterpret_cast<const float4*>(scr + r * SP + rch * 8);
-                        const float4 x1 = *reinterpret_cast<const float4*>(scr + r * SP + rch * 8 + 4);
-                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                        if (res) {
+            for (int it = 0; it < RI; ++it) {
+                const int rc = min(rrow + it * LPR, 15);
+                x[it][0] = *reinterpret_cast<const float4*>(lrd + rc * SP);
+                x[it][1] = *reinterpret_cast<const float4*>(lrd + rc * SP + 4);
+            }
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += to_f32(r16[it][e]);
-                        }
-                        if (res32) {
-                            const float4 a = r32[it][0], b = r32[it][1];
-                            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-                        }
-                        V8 o;
+            for (int it = 0; it < RI; ++it) {
+                if (act && rrow + it * LPR < 16) {
+                    float v[8] = {x[it][0].x, x[it][0].y, x[it][0].z, x[it][0].w, x[it][1].x, x[it][1].y, x[it][1].z, x[it][1].w};
+                    if constexpr (RMODE == 1) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
-                        long orow = mbase + r;
-                        if (p.out_phase) {
-                            // one output-parity phase of conv(nearest x2 upsample): pixel (oy, ox) of the phase grid is pixel
-                            // (2 oy + py, 2 ox + px) of the 2H x 2W output
-                            const int oy = ty0 + wm * 4 + i, ox = tx0 + r;
-                            orow = ((long)img * 2 * p.H + 2 * oy + ((p.out_phase >> 1) & 1)) * (2 * p.W) + 2 * ox + (p.out_phase & 1);
-                        }
-                        if (Cout) *reinterpret_cast<V8*>(Cout + orow * p.ldc + ncol) = o;
+                        for (int e = 0; e < 8; ++e) v[e] += to_f32(r16[i % DEPTH][it][e]);
+                    }
+                    if constexpr (RMODE == 2) {
+                        const float4 a = r32[i % DEPTH][it][0], b = r32[i % DEPTH][it][1];
+                        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+                    }
+                    V8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
+                    const long roff = i * step_i + (long)(it * LPR) * step_r;   // wave-uniform
+                    if (Cout) *reinterpret_cast<V8*>(pC + roff * p.ldc) = o;
+                    if (C32) {
+                        float* d32 = pC32 + roff * p.ldc32;
+                        *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                    if (colstats) {
                         if (C32) {
-                            float* d32 = C32 + orow * p.ldc32 + ncol;
-                            *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
-                            *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                        }
-                        if (colstats) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { const float f = C32 ? v[e] : to_f32(o[e]); s8[e] += f; q8[e] += f * f; }
+                            for (int e = 0; e < 8; ++e) { s8[e] += v[e]; q8[e] = fmaf(v[e], v[e], q8[e]); }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] = fmaf(f, f, q8[e]); }
                         }
                     }
                 }
+            }
+            if constexpr (RMODE != 0 && DEPTH < 4) {
+                if (i + DEPTH < 4) load_res(i + DEPTH, i % DEPTH);
             }
         }
         if (colstats) {
@@ -492,7 +526,11 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
                 if (n < p.N) *reinterpret_cast<float2*>(colstats + (slice * p.ld_colstats + n) * 2) = make_float2(ss, qq);
             }
         }
-    }
+    };
+    if constexpr (RM >= 0) epilogue(std::integral_constant<int, RM>{});
+    else if (p.res_f32) epilogue(std::integral_constant<int, 2>{});
+    else if (p.residual) epilogue(std::integral_constant<int, 1>{});
+    else epilogue(std::integral_constant<int, 0>{});
     if constexpr (DIAG) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long d_t3 = stamp();
@@ -509,19 +547,21 @@ int launch_patch(const GemmParams& p, hipStream_t stream) {
     constexpr int BN = 32 * NT, TAPS = KH * KW, NSLOT = (TAPS % 3 == 0) ? 3 : 4;
     constexpr int NPIECES = ((TP + KW - 1) * (TP + KH - 1) + 7) / 8;
     const size_t lds = 2 * (size_t)NPIECES * 1024 + NSLOT * (size_t)BN * 128 + (KH == 3 ? 2048 : 0);
-    auto kern = conv_patch_kernel<TT, NT, KH, KW>;
+    const int rm = p.res_f32 ? 2 : (p.residual ? 1 : 0);
+    auto kern = rm == 2 ? conv_patch_kernel<TT, NT, KH, KW, false, false, 2>
+              : rm == 1 ? conv_patch_kernel<TT, NT, KH, KW, false, false, 1> : conv_patch_kernel<TT, NT, KH, KW, false, false, 0>;
+    int which = rm;
     if constexpr (NT == 5 && KH == 3 && sizeof(typename TT::elem) == 2) {
-        if (p.flags & 0x4000) kern = conv_patch_kernel<TT, NT, KH, KW, true>;     // diagnostic stamps (tools/stamp_conv.py)
+        if (p.flags & 0x4000) { kern = conv_patch_kernel<TT, NT, KH, KW, true>; which = 3; }   // diagnostic stamps (tools/stamp_conv.py)
     }
     if constexpr (KH == 3) {
-        if (p.gn_ab) kern = conv_patch_kernel<TT, NT, KH, KW, false, true>;         // fused GroupNorm-apply + SiLU
+        if (p.gn_ab) { kern = conv_patch_kernel<TT, NT, KH, KW, false, true>; which = 4; }       // fused GroupNorm-apply + SiLU
     }
-    static bool attr_set[3] = {false, false, false};
-    const int diag = p.gn_ab ? 2 : ((p.flags & 0x4000) ? 1 : 0);
-    if (!attr_set[diag]) {
+    static bool attr_set[5] = {false, false, false, false, false};
+    if (!attr_set[which]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VF_ERR_LAUNCH;
-        attr_set[diag] = true;
+        attr_set[which] = true;
     }
     const int ntm = (p.M / (p.OH * p.OW)) * (p.H / TP) * (p.W / TP), ntn = p.N / BN;
     hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(512), lds, stream, p);

@@ -24,6 +24,8 @@
 // Epilogue (fp32): + bias[n] + rowbias[m / rows_per_sample][n] (time-embedding add of ResBlock :264-271, or
 // the degenerate single-token cross-attention vector), optional GEGLU (attention.py:37-45,
 // weight rows pre-permuted so value / gate tiles alternate), + residual[m][n], store 16-bit or fp32.
+#include <type_traits>
+
 #include "common.hpp"
 #include "vface_kernels.hpp"
 
@@ -32,7 +34,9 @@ namespace {
 constexpr int BM = 128, BK = 64;
 enum { MODE_PLAIN = 0, MODE_CONV_FAST = 1, MODE_CONV_GENERIC = 2 };
 
-template <class TT, int MODE, int NT, bool DB, bool PERSIST>
+// RM: the residual form of the wide epilogue (0 none, 1 16-bit, 2 the fp32 stream) as an instantiation of its own; -1 = chosen
+// at run time (three copies of the epilogue in one kernel: 16-38 spilled registers at NT = 5, kept for the rare forms only)
+template <class TT, int MODE, int NT, bool DB, bool PERSIST, int RM = -1>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0;
+    unsigned long long dbg_t0 = 0, dbg_t1 = 0, dbg_t2 = 0, dbg_e0 = 0, dbg_ew = 0, dbg_er = 0, dbg_es = 0;   // (diagnostic launches only)
     if (p.flags & 0x4000) dbg_t0 = __builtin_amdgcn_s_memtime();
     // XCD-aware tile order (guide T1).  Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2.
     // Every XCD gets a contiguous run of the tile sequence L (bijective for any grid size: q = nwg/8, r = nwg%8),
@@ -279,21 +283,36 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     // fp32 -- so bias / row bias / residual are still summed before the single rounding -- and writes whole 16-byte
     // chunks of consecutive channels per lane: 8-10x fewer, fully coalesced stores; the residual is read the same way.
     // Scratch: 4 waves x 16 rows x (WN + 4) floats (17-21 KB) at `scr_base` (a free stage buffer).
-    auto wide_epilogue = [&](int em0, int en0, float* scr_base) {
+    // RMODE (compile-time residual form: 0 none, 1 16-bit, 2 the fp32 stream) -- three copies of the epilogue instead of run-time
+    // tests inside it: with the tests, hipcc lost count of the loads in flight at every branch join and waited `vmcnt(0)` in
+    // EVERY 16-row pass -- i.e. for the previous pass's STORES to reach memory (stamps: 11-13 k cycles of epilogue body, more
+    // than the whole K loop of the K = 320 GEMMs).  Now every load of the epilogue (bias, row bias, all residual rows of the
+    // tile) is requested up front and retired by ONE explicit `s_waitcnt vmcnt(0)` the compiler's wait-count pass can see;
+    // after it only stores are in flight and nothing waits for them.
+    auto wide_epilogue = [&](auto rmode_tag, int em0, int en0, float* scr_base) {
+        constexpr int RMODE = decltype(rmode_tag)::value;
         constexpr int WN = NT * 16;
         constexpr int SP = WN + 4;   // fp32 scratch row pitch (floats); +16 B keeps rows off the same banks
         const bool gg = p.flags & GEMM_GEGLU;
         const float* bias = p.bias;
         const float* rowbias = p.rowbias;
         // residual: 16-bit, or the fp32 residual-stream carrier (res_f32); output: 16-bit C and / or the fp32 carrier C32
-        const E* res = p.res_f32 ? nullptr : reinterpret_cast<const E*>(p.residual);
-        const float* res32 = p.res_f32 ? reinterpret_cast<const float*>(p.residual) : nullptr;
+        const E* res = RMODE == 1 ? reinterpret_cast<const E*>(p.residual) : nullptr;
+        const float* res32 = RMODE == 2 ? reinterpret_cast<const float*>(p.residual) : nullptr;
         E* Cout = reinterpret_cast<E*>(p.C);
         float* C32 = p.C32;
         float* colstats = p.colstats;
         const bool want_stats = colstats && !(p.flags & 0x4000);
-        const bool diag = p.flags & 0x4000;                               // ablations (tools/stamp_gemm.py), diagnostic launches only
-        const bool abl_store = diag && (p.flags & 0x200000), abl_bias = diag && (p.flags & 0x400000);
+        const bool diag = p.flags & 0x4000;          // diagnostic launches (tools/stamp_gemm.py): s_memtime stamps around the parts
+        auto estamp = [&]() -> unsigned long long {
+            if (!diag) return 0;
+            unsigned long long t;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            return t;
+        };
+        const unsigned long long e_in = estamp();
         float* scr = scr_base + wave * (16 * SP);
         const int OW = gg ? WN / 2 : WN;              // output columns of this wave
         const int CH = OW >> 3;                       // 16-byte chunks per output row
@@ -302,6 +321,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         const int rch = lane % CH, rrow = lane / CH;
         const int ncol = (gg ? ((en0 + wn * WN) >> 1) : (en0 + wn * WN)) + rch * 8;   // first output channel of this lane
         const int nout = gg ? (p.N >> 1) : p.N;
+        // The body below is written for INSTRUCTION COUNT: stamps showed the epilogue at 10-11 k cycles per wave with every
+        // global access ablated -- ~800 executed instructions (64-bit row-address products per store, per-row bounds tests,
+        // one LDS round trip at a time), two waves per SIMD.  Now: one pointer per lane and a wave-uniform row offset per
+        // store; the bounds of the wave's 64-row slab as one uniform limit; the LDS reads of a pass issued together.
+        const int wrow0 = em0 + wm * 64;              // first row of this wave's 64-row slab
+        const int lim = min(p.M - wrow0, 64);         // rows of the slab that exist (uniform; <= 0: none)
+        const bool colok = act && ncol < nout;
         float s8[8], q8[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
@@ -316,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const int nb = en0 + wn * WN + j * 16 + fq * 4;
-                const bool in = nb < p.N && !abl_bias;
+                const bool in = nb < p.N;
                 bj[j] = (bias && in) ? *reinterpret_cast<const float4*>(bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
                 rbj[j] = (rb0 && in) ? *reinterpret_cast<const float4*>(rb0 + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -324,111 +350,147 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         // the residual rows of the whole tile are requested up front (never with GEGLU, so the chunk geometry is static):
         // their HBM latency then runs under the LDS transposes instead of once per 16-row pass
         constexpr int LPRC = 64 / (NT * 2), RI = (16 + LPRC - 1) / LPRC;
-        V8 rres[4][RI];
-        if (res) {
+        // DEPTH tile rows of residual in flight: the whole tile where the registers allow; two (row i + 2 requested once row i
+        // has been summed) for the fp32 stream at NT = 5 (24 registers per tile row); one for the persistent form, which has
+        // none to spare -- the UNet never pairs it with a residual, tools/bench_kernels.py can
+        constexpr int DEPTH = PERSIST ? 1 : ((NT == 5 && RMODE == 2) ? 2 : 4);
+        V8 rres[RMODE == 1 ? DEPTH : 1][RI];
+        float4 r32[RMODE == 2 ? DEPTH : 1][RI][2];
+        auto load_res = [&](int i, int slot) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int it = 0; it < RI; ++it) {
-                    const int r = rrow + it * LPRC;
-                    const int m = em0 + wm * 64 + i * 16 + r;
-                    if (act && r < 16 && m < p.M && ncol < nout) rres[i][it] = *reinterpret_cast<const V8*>(res + (long)m * p.ldr + ncol);
-                }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // fp32 residual rows of this tile row: requested before the transpose below, used after it
-            float4 r32[RI][2];
-            if (res32) {
-#pragma unroll
-                for (int it = 0; it < RI; ++it) {
-                    const int r = rrow + it * LPRC;
-                    const int m = em0 + wm * 64 + i * 16 + r;
-                    if (act && r < 16 && m < p.M && ncol < nout) {
-                        const float* rp = res32 + (long)m * p.ldr + ncol;
-                        r32[it][0] = *reinterpret_cast<const float4*>(rp);
-                        r32[it][1] = *reinterpret_cast<const float4*>(rp + 4);
+            for (int it = 0; it < RI; ++it) {
+                const int r = rrow + it * LPRC;
+                const bool in = colok && r < 16 && i * 16 + r < lim;
+                const long off = (long)(wrow0 + i * 16 + r) * p.ldr + ncol;
+                if constexpr (RMODE == 1) {
+                    rres[slot][it] = V8{};
+                    if (in) rres[slot][it] = *reinterpret_cast<const V8*>(res + off);
+                } else if constexpr (RMODE == 2) {
+                    r32[slot][it][0] = r32[slot][it][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (in) {
+                        r32[slot][it][0] = *reinterpret_cast<const float4*>(res32 + off);
+                        r32[slot][it][1] = *reinterpret_cast<const float4*>(res32 + off + 4);
                     }
                 }
             }
+        };
+        if constexpr (RMODE != 0) {
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) load_res(i, i);
+        }
+        // bias, then row bias, summed into the accumulators here -- (acc + bias) + rowbias, the order of every epilogue of this
+        // file -- so their 2 x NT x 4 registers are free again before the passes start
+        // (unconditional: absent terms were loaded as zeros -- a conditional update of 80 accumulator registers made the
+        //  compiler keep two copies of them)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[j][i][0] = (acc[j][i][0] + bj[j].x) + rbj[j].x; acc[j][i][1] = (acc[j][i][1] + bj[j].y) + rbj[j].y;
+                acc[j][i][2] = (acc[j][i][2] + bj[j].z) + rbj[j].z; acc[j][i][3] = (acc[j][i][3] + bj[j].w) + rbj[j].w;
+            }
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): every load of this epilogue has landed; from here on only stores fly
+        unsigned long long e_t = estamp();
+        dbg_e0 = e_t - e_in;
+        // per-lane output pointers at slab row `rrow`; the row of (tile row i, pass it) is a wave-uniform offset from them
+        const bool phased = MODE != MODE_PLAIN && p.out_phase;
+        E* pC = Cout + (long)(wrow0 + rrow) * p.ldc + ncol;
+        float* pC32 = C32 + (long)(wrow0 + rrow) * p.ldc32 + ncol;
+        const float* lrd = scr + rch * 8;             // this lane's chunk column in the scratch
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             {
-                const int m = em0 + wm * 64 + i * 16 + fr;
+                const int m = wrow0 + i * 16 + fr;
                 const float* rb = (rowbias && !one_sample && m < p.M) ? rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
                 float* srow = scr + fr * SP + fq * 4;
                 if (!gg) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        const int nb = en0 + wn * WN + j * 16 + fq * 4;
                         float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-                        if (bias) { v.x += bj[j].x; v.y += bj[j].y; v.z += bj[j].z; v.w += bj[j].w; }
-                        if (one_sample) { v.x += rbj[j].x; v.y += rbj[j].y; v.z += rbj[j].z; v.w += rbj[j].w; }
-                        else if (rb && nb < p.N && !abl_bias) { const float4 b = *reinterpret_cast<const float4*>(rb + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                        if (rowbias && !one_sample) {
+                            const int nb = en0 + wn * WN + j * 16 + fq * 4;
+                            if (rb && nb < p.N) { const float4 b = *reinterpret_cast<const float4*>(rb + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                        }
                         *reinterpret_cast<float4*>(srow + j * 16) = v;
                     }
                 } else if constexpr ((NT & 1) == 0) {
 #pragma unroll
                     for (int jj = 0; jj < NT / 2; ++jj) {
-                        const int nb = en0 + wn * WN + jj * 32 + fq * 4;   // packed index of the value rows; gates at +16
                         float a[4], g[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) { a[r] = acc[2 * jj][i][r]; g[r] = acc[2 * jj + 1][i][r]; }
-                        (void)nb;
-                        if (bias) {      // bj[2jj] = bias of the value rows, bj[2jj + 1] = of the gate rows (16 further)
-                            const float4 ba = bj[2 * jj], bg = bj[2 * jj + 1];
-                            a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
-                            g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
-                        }
+                        // (bias already summed: value rows in the even column tiles, gate rows 16 further in the odd ones)
                         *reinterpret_cast<float4*>(srow + jj * 16) =
                             make_float4(a[0] * gelu_erf_f(g[0]), a[1] * gelu_erf_f(g[1]), a[2] * gelu_erf_f(g[2]), a[3] * gelu_erf_f(g[3]));
                     }
                 }
             }
             // LDS operations of one wave execute in order: the reads below see the writes above, and the next
-            // tile row's writes cannot overtake these reads
-            if (act) {
+            // tile row's writes cannot overtake these reads.  Every lane reads (rows clamped into the scratch), only
+            // the stores are predicated: the RI x 2 reads of the pass go out back to back.
+            { const unsigned long long t = estamp(); dbg_ew += t - e_t; e_t = t; }
+            float4 x[RI][2];
 #pragma unroll
-                for (int it = 0; it < 8; ++it) {
-                    const int r = rrow + it * LPR;
-                    if (r >= 16) break;
-                    const int m = em0 + wm * 64 + i * 16 + r;
-                    if (m < p.M && ncol < nout) {
-                        const float4 x0 = *reinterpret_cast<const float4*>(scr + r * SP + rch * 8);
-                        const float4 x1 = *reinterpret_cast<const float4*>(scr + r * SP + rch * 8 + 4);
-                        float v[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-                        if (res) {
-                            const V8 r8 = rres[i][it < RI ? it : 0];
+            for (int it = 0; it < RI; ++it) {       // (RI passes without GEGLU; its narrower rows need fewer: r < 16 cuts them)
+                const int rc = min(rrow + it * LPR, 15);
+                x[it][0] = *reinterpret_cast<const float4*>(lrd + rc * SP);
+                x[it][1] = *reinterpret_cast<const float4*>(lrd + rc * SP + 4);
+            }
+            if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = estamp(); dbg_er += t - e_t; e_t = t; }
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] += to_f32(r8[e]);
-                        }
-                        if (res32) {
-                            const float4 a = r32[it < RI ? it : 0][0], b = r32[it < RI ? it : 0][1];
-                            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-                        }
-                        V8 o;
+            for (int it = 0; it < RI; ++it) {
+                const int r = rrow + it * LPR;
+                const int srow_u = i * 16 + it * LPR;            // wave-uniform part of the slab row
+                if (colok && r < 16 && srow_u + rrow < lim) {
+                    float v[8] = {x[it][0].x, x[it][0].y, x[it][0].z, x[it][0].w, x[it][1].x, x[it][1].y, x[it][1].z, x[it][1].w};
+                    if constexpr (RMODE == 1) {
+                        const V8 r8 = rres[i % DEPTH][it];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
-                        long orow = m;
-                        if (MODE != MODE_PLAIN && p.out_phase) {
-                            // one output-parity phase of conv(nearest x2 upsample): pixel (oy, ox) of the phase grid is
-                            // pixel (2 oy + py, 2 ox + px) of the 2OH x 2OW output
-                            const int hw = p.OH * p.OW, img = m / hw, rem = m - img * hw, oy = rem / p.OW, ox = rem - oy * p.OW;
-                            orow = ((long)img * 2 * p.OH + 2 * oy + ((p.out_phase >> 1) & 1)) * (2 * p.OW) + 2 * ox + (p.out_phase & 1);
+                        for (int e = 0; e < 8; ++e) v[e] += to_f32(r8[e]);
+                    }
+                    if constexpr (RMODE == 2) {
+                        const float4 a = r32[i % DEPTH][it][0], b = r32[i % DEPTH][it][1];
+                        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+                    }
+                    V8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
+                    if (!phased) {
+                        if (Cout) *reinterpret_cast<V8*>(pC + (long)srow_u * p.ldc) = o;
+                        if (C32) {
+                            float* d32 = pC32 + (long)srow_u * p.ldc32;
+                            *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
                         }
-                        if (Cout && !abl_store) *reinterpret_cast<V8*>(Cout + orow * p.ldc + ncol) = o;
-                        if (abl_store) asm volatile("" ::"v"(o));
+                    } else {
+                        // one output-parity phase of conv(nearest x2 upsample): pixel (oy, ox) of the phase grid is
+                        // pixel (2 oy + py, 2 ox + px) of the 2OH x 2OW output
+                        const int m = wrow0 + srow_u + rrow;
+                        const int hw = p.OH * p.OW, img = m / hw, rem = m - img * hw, oy = rem / p.OW, ox = rem - oy * p.OW;
+                        const long orow = ((long)img * 2 * p.OH + 2 * oy + ((p.out_phase >> 1) & 1)) * (2 * p.OW) + 2 * ox + (p.out_phase & 1);
+                        if (Cout) *reinterpret_cast<V8*>(Cout + orow * p.ldc + ncol) = o;
                         if (C32) {
                             float* d32 = C32 + orow * p.ldc32 + ncol;
                             *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
                             *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
                         }
-                        if (want_stats) {
-                            // statistics of the values the following GroupNorm will read: the fp32 carrier if there is one
+                    }
+                    if (want_stats) {
+                        // statistics of the values the following GroupNorm will read: the fp32 carrier if there is one
+                        if (C32) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { const float f = C32 ? v[e] : to_f32(o[e]); s8[e] += f; q8[e] += f * f; }
+                            for (int e = 0; e < 8; ++e) { s8[e] += v[e]; q8[e] = fmaf(v[e], v[e], q8[e]); }
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] = fmaf(f, f, q8[e]); }
                         }
                     }
                 }
             }
+            if constexpr (RMODE != 0 && DEPTH < 4) {
+                if (i + DEPTH < 4) load_res(i + DEPTH, i % DEPTH);
+            }
+            { const unsigned long long t = estamp(); dbg_es += t - e_t; e_t = t; }
         }
         if (want_stats) {
             // fold the LPR row-lanes of every channel through the scratch (fixed order: reproducible)
@@ -456,6 +518,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                 }
             }
         }
+    };
+    auto run_wide = [&](int em0, int en0, float* scr_base) {
+        if constexpr (RM >= 0) wide_epilogue(std::integral_constant<int, RM>{}, em0, en0, scr_base);
+        else if (p.res_f32) wide_epilogue(std::integral_constant<int, 2>{}, em0, en0, scr_base);
+        else if (p.residual) wide_epilogue(std::integral_constant<int, 1>{}, em0, en0, scr_base);
+        else wide_epilogue(std::integral_constant<int, 0>{}, em0, en0, scr_base);
     };
 
     if constexpr (PERSIST) {
@@ -491,7 +559,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
                 compute(cur);
             }
             __syncthreads();   // every wave is done reading the last stage: it becomes the epilogue scratch
-            wide_epilogue(em0, en0, reinterpret_cast<float*>(smem + ((g - 1) & 1) * STAGE));
+            {
+                float* scr0 = reinterpret_cast<float*>(smem + ((g - 1) & 1) * STAGE);
+                run_wide(em0, en0, scr0);
+            }
             if (tile >= ntiles) break;
         }
         return;
@@ -566,14 +637,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
 
     if (DB && !(p.flags & GEMM_OUT_F32) && !(p.N & 7) && !(p.flags & GEMM_NARROW_EPILOGUE)) {
         __syncthreads();             // all waves are done with the last K tile: the stage buffers become scratch
-        wide_epilogue(m0, n0, reinterpret_cast<float*>(smem_raw));
+        unsigned long long dbg_tb = 0;
+        if (p.flags & 0x4000) { __builtin_amdgcn_sched_barrier(0); dbg_tb = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
+        run_wide(m0, n0, reinterpret_cast<float*>(smem_raw));
         if (p.flags & 0x4000) {
             __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t3a = __builtin_amdgcn_s_memtime();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long t3 = __builtin_amdgcn_s_memtime();
             if (lane == 0 && p.colstats) {
                 float* d = p.colstats + ((long)blockIdx.x * 4 + wave) * 4;
-                d[0] = (float)(dbg_t1 - dbg_t0); d[1] = (float)(dbg_t2 - dbg_t1); d[2] = (float)(t3 - dbg_t2); d[3] = 1.f;
+                // [prologue, K loop, epilogue incl. the barrier before it and the drain of its stores, barrier wait alone]
+                d[0] = (float)(dbg_t1 - dbg_t0); d[1] = (float)(dbg_t2 - dbg_t1); d[2] = (float)(t3 - dbg_t2);
+                d[3] = (float)(dbg_tb - dbg_t2) + 65536.f * (float)((t3 - t3a) >> 4);   // (packed: barrier wait | store drain / 16)
+                float* e = p.colstats + ((long)gridDim.x * 4 + (long)blockIdx.x * 4 + wave) * 4;
+                e[0] = (float)dbg_e0; e[1] = (float)dbg_ew; e[2] = (float)dbg_er; e[3] = (float)dbg_es;   // epilogue: setup | LDS writes | LDS read wait | convert + store
             }
         }
         return;
@@ -802,13 +880,23 @@ int launch_one(const GemmParams& p, hipStream_t stream) {
     // one-tile-per-workgroup launch unless GEMM_PERSIST asks otherwise)
     const bool persist = DB && p.split_k == 1 && !(p.flags & (GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE | GEMM_NO_PERSIST | 0x4000)) &&
                          !(p.N & 7) && ntiles > persistent_grid() && (MODE != MODE_PLAIN || (p.flags & GEMM_PERSIST));
-    auto kern = persist ? gemm_kernel<TT, MODE, NT, DB, DB> : gemm_kernel<TT, MODE, NT, DB, false>;
-    static bool attr_set[2] = {false, false};
-    if (lds > 64 * 1024 && !attr_set[persist]) {
+    // residual form of the wide epilogue as a kernel of its own for the forms the UNet launches (see gemm_kernel's RM)
+    const int rm = p.res_f32 ? 2 : (p.residual ? 1 : 0);
+    void (*kern)(GemmParams) = nullptr;
+    int which = 0;
+    if constexpr (DB && MODE != MODE_CONV_GENERIC) {
+        if (persist) { which = rm == 0 ? 1 : 2; kern = rm == 0 ? gemm_kernel<TT, MODE, NT, DB, DB, 0> : gemm_kernel<TT, MODE, NT, DB, DB>; }
+        else { which = 3 + rm; kern = rm == 2 ? gemm_kernel<TT, MODE, NT, DB, false, 2> : rm == 1 ? gemm_kernel<TT, MODE, NT, DB, false, 1> : gemm_kernel<TT, MODE, NT, DB, false, 0>; }
+    } else {
+        which = persist ? 2 : 0;
+        kern = persist ? gemm_kernel<TT, MODE, NT, DB, DB> : gemm_kernel<TT, MODE, NT, DB, false>;
+    }
+    static bool attr_set[6] = {false, false, false, false, false, false};
+    if (lds > 64 * 1024 && !attr_set[which]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return VF_ERR_LAUNCH;
-        attr_set[persist] = true;
+        attr_set[which] = true;
     }
     dim3 grid(persist ? persistent_grid() : ntiles * p.split_k);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);

@@ -13,7 +13,9 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvface_hip.so")
+# (VFACE_HIP_LIB: another build of the same library, for A/B timing of two builds in one process tree; still the C ABI,
+#  still no fallback: a path that does not load raises)
+LIB_PATH = os.environ.get("VFACE_HIP_LIB") or os.path.join(_HERE, "lib", "libvface_hip.so")
 
 F16, BF16 = 0, 1
 EPI_GEGLU, EPI_OUT_F32 = 1, 2
