@@ -242,9 +242,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_workload(F_, fusion, n_steps, n_warm, time_convs, inv_steps):
-        """W untimed + exactly K timed DDIM steps of an F-frame clip per GPU; returns per-rank wall seconds etc."""
+    def run_workload(F_, fusion, n_steps, n_warm, time_convs, inv_steps, graph=False):
+        """W untimed + exactly K timed DDIM steps of an F-frame clip per GPU; returns per-rank wall seconds etc.
+        graph=True: the UNet forward of a step replayed from a hipGraph (UNetEngine.step_forward_nhwc) -- no per-launch
+        events can be recorded inside a graph, so the headline run (which carries the live roofline timing) launches kernel
+        by kernel and the graph run is reported beside it."""
         sampler.hook_plan = HookPlan(fusion=fusion, enabled=fusion != "none")
+        ldm.unet.engine.use_graph, ldm.unet.engine._graphs = bool(graph), {}
         shard = FrameShard(rank, world, F_ * world, dist)
         g0 = shard.first  # global index of this rank's first frame
         tag = lambda s_, f: f"bench.{s_}.{g0 + f}"
@@ -334,11 +338,23 @@ def main():
                 continue
             log(f"extra workload: {f2} frames, fusion={fus} ...")
             e = run_workload(f2, fus, a.extra_steps, 2, False, 0)
-            extras.append({"workload": name, "frames_per_gpu": f2, "fusion": fus, "steps": a.extra_steps, "warmup": 2,
+            extras.append({"workload": name, "frames_per_gpu": f2, "fusion": fus, "steps": a.extra_steps, "warmup": 2, "launch": "kernel by kernel",
                            "ms_per_step": e["ms_step"], "host_enqueue_ms_per_step": e["enqueue_ms"],
                            "frames_per_s": f2 / (a.ddim_steps * e["ms_step"] / 1e3),
                            "unet_algorithmic_tflops": 3 * f2 * unet_gflop * 1e9 / (e["ms_step"] * 1e-3) / 1e12})
             log(f"  {e['ms_step']:.2f} ms/step = {extras[-1]['frames_per_s']:.2f} frames/s")
+    # the headline workload once more with the step's UNet forward replayed from a hipGraph (every rank; same K and W)
+    graph_run = None
+    if not a.no_extras:
+        log("headline workload, hipGraph replay ...")
+        e = run_workload(F_, a.fusion, a.steps, a.warmup, False, 0, graph=True)
+        graphed = ldm.unet.engine.use_graph and len(ldm.unet.engine._graphs) > 0
+        ldm.unet.engine.use_graph, ldm.unet.engine._graphs = False, {}
+        graph_run = {"launch": "hipGraph replay of the UNet forward (UNetEngine.step_forward_nhwc)" if graphed else
+                     "kernel by kernel (frame-sharded attention exchanges over RCCL inside the forward: not captured)",
+                     "ms_per_step": e["ms_step"], "host_enqueue_ms_per_step": e["enqueue_ms"], "steps": a.steps, "warmup": a.warmup,
+                     "frames_per_s": (F_ * world) / (a.ddim_steps * e["ms_step"] / 1e3)}
+        log(f"  {e['ms_step']:.2f} ms/step (host enqueue {e['enqueue_ms']:.2f} ms/step)")
 
     if rank == 0:
         dom = conv["patch3"] if conv["patch3"]["launches"] else max(conv.values(), key=lambda c: c["ms"])
@@ -380,6 +396,7 @@ def main():
                         "sampling only, as BASELINE's metric",
                 "frames_per_s_sampling_plus_inversion": (F_ * world) / (a.ddim_steps * (ms_step + inv_ms) / 1e3)},
             "extra": extras,
+            "hipgraph": graph_run,
             # the dominant kernel of the step (largest share of kernel time in profiles/*_kernel_stats.csv): conv_patch_kernel<3,3>,
             # the patch-staged stride-1 3x3 convolution (incl. the launches that carry a ResBlock's fused 1x1 shortcut)
             "roofline": {"bound": "mfma", "kernel": "conv_patch_kernel<T, NT, 3, 3> (conv.hip: patch-staged 3x3 convolution)",

@@ -413,3 +413,70 @@ def test_full_size_config5_share_32_frames_at_768():
     part = _full_run("flow_fix", frames, 22, 10, h, flow_all)
     assert torch.equal(part[:, 2:], whole[:, 24:])
     assert not torch.equal(part[:, 1], whole[:, 23])
+
+
+def test_hipgraph_replay_equals_kernel_by_kernel_launches(small):
+    """a DDIM step's UNet forward captured into a hipGraph (UNetEngine.step_forward_nhwc) and replayed gives
+    the bits of the kernel-by-kernel launch sequence; one capture serves every step of every clip of the same shape and hook
+    plan (new flow / conditioning tensors are copied into the graph's own buffers, the caller's are never written);
+    another hook plan gets its own graph; inversion (hooks off, batch 2F) too."""
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import HookPlan
+    ldm, sampler, sd = small
+    eng = ldm.unet.engine
+    F_, h, w = 2, 32, 32
+    d = lambda v: v.to(DEV)
+    x_T = d(synth.synth_normal("graph.xT", (F_, 4, h, w)))
+    c, uc, tc = (d(synth.synth_normal(f"graph.{k}", (F_, 1, 768))) for k in ("c", "uc", "tc"))
+    inp = d(synth.synth_normal("graph.inpaint", (F_, 4, h, w)) * 0.18215)
+    mask = d(synth.synth_mask(F_, h, w))
+    flow = [synth.synth_flow(F_ - 1, h, w)[i][None] for i in range(F_ - 1)]
+    inv = {int(s): d(synth.synth_normal(f"graph.inv.{int(s)}", (F_, 4, h, w))) for s in oddim.ddim_timesteps(50)}
+
+    def run(plan, steps=4):
+        nonlocal c
+        sampler.hook_plan = plan
+        img, _ = sampler.sample(S=50, batch_size=F_, shape=[4, h, w], conditioning=c, target_conditioning=tc,
+                                inverse_results_dir=inv, verbose=False, unconditional_guidance_scale=3.0,
+                                unconditional_conditioning=uc, eta=0.0, x_T=x_T, flow=flow,
+                                test_model_kwargs={"inpaint_image": inp, "inpaint_mask": mask}, max_steps=steps)
+        return img.clone()
+
+    def invert():
+        x0 = d(synth.synth_normal("graph.z2", (2 * F_, 4, h, w)))
+        xn, _ = sampler.ddim_invert(x=x0, cond=torch.cat([tc, c], 0), S=50, shape=[4, h, w], inverse_dir={}, batch_size=F_,
+                                    test_model_kwargs={"inpaint_image": torch.cat([inp] * 2), "inpaint_mask": torch.cat([mask] * 2)},
+                                    max_steps=2)
+        return xn.clone()
+
+    old_plan, old_flag = sampler.hook_plan, eng.use_graph
+    try:
+        eng.use_graph = False
+        plans = [HookPlan(fusion="flow_fix"), HookPlan(fusion="replace")]
+        eager = [run(p) for p in plans] + [invert()]
+        eng.use_graph, eng._graphs = True, {}
+        g1 = run(plans[0])
+        assert len(eng._graphs) == 1, "one capture must serve every step of the clip"
+        g2 = run(plans[1])
+        assert len(eng._graphs) == 2
+        g1b = run(plans[0])                       # back to the first plan: its graph is still cached and still right
+        assert len(eng._graphs) == 2
+        gi = invert()
+        assert len(eng._graphs) == 3
+        # another clip (other flow fields, other conditioning) through the first plan's graph
+        flow_b = [f * -0.5 for f in flow]
+        c_b = d(synth.synth_normal("graph.c_b", (F_, 1, 768)))
+        flow_keep = [f.clone() for f in flow]
+        flow[:], c_a, c = flow_b, c, c_b
+        g3 = run(plans[0])
+        assert len(eng._graphs) == 3, "a new clip of the same shape must not be captured again"
+        eng.use_graph = False
+        e3 = run(plans[0])
+        eng.use_graph = True
+        flow[:], c = flow_keep, c_a
+        g1c = run(plans[0])
+        assert eng.use_graph, "capture fell back to the eager path"
+        assert torch.equal(g1, eager[0]) and torch.equal(g1b, eager[0]) and torch.equal(g2, eager[1]) and torch.equal(gi, eager[2])
+        assert torch.equal(g3, e3) and not torch.equal(g3, eager[0]) and torch.equal(g1c, eager[0])
+    finally:
+        sampler.hook_plan, eng.use_graph, eng._graphs = old_plan, old_flag, {}
+        sampler.make_schedule(50, ddim_eta=0.0, verbose=False)

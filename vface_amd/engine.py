@@ -285,6 +285,12 @@ class UNetEngine:
         # the ~70 vector instructions per 1-KiB patch piece sit in the K-tile period's critical path -- 28.22 vs 27.49 ms per
         # DDIM step (conv 9.46 vs 7.77 ms, gn_apply 0 vs 1.0 ms), DESIGN 4 -- so it is opt-in.
         self.fuse_gn = os.environ.get("VFACE_FUSE_GN", "off")
+        # hipGraph replay of the UNet forward of a DDIM step (step_forward_nhwc): "1" = capture once per (batch, resolution,
+        # hook configuration, context) and replay; "0" (default) = launch kernel by kernel.  The C ABI is allocation-free and
+        # stream-ordered, so the captured graph is exactly the eager launch sequence.
+        self.use_graph = os.environ.get("VFACE_GRAPH", "0") == "1"
+        self._graphs: "Dict[tuple, dict]" = {}
+        self.graph_capacity = 4
         hip.load()
 
     # ------------------------------------------------------------------ weights
@@ -655,12 +661,16 @@ class UNetEngine:
         hip.silu(emb, emb)
         emb_all = self._new(N, P["emb_all"]["n"], torch.float32)
         self._gemm(emb, P["emb_all"], emb_all, flags=hip.EPI_OUT_F32)
-        # the attn2 vectors depend on the context only: the DDIM loop hands the same tensor object every step, so they are
-        # computed once per clip (the cache holds the tensor itself -- its storage cannot be recycled under us -- and its
-        # version counter, so an in-place edit invalidates it)
+        return emb_all, self.context_projections(context, N)
+
+    def context_projections(self, context: torch.Tensor, N: int) -> torch.Tensor:
+        """Every attn2's ``to_out(to_v(ctx))`` as one fp32 [N, sum c] matrix.  They depend on the context only: the DDIM loop
+        hands the same tensor object every step, so they are computed once per clip (the cache holds the tensor itself --
+        its storage cannot be recycled under us -- and its version counter, so an in-place edit invalidates it)."""
+        P = self._packed
         cached = getattr(self, "_a2_cache", None)
         if cached is not None and cached[0] is context and cached[1] == context._version and cached[2] is P:
-            return emb_all, cached[3]
+            return cached[3]
         ctx = context.reshape(N, -1)
         if ctx.shape[1] != self.unet.context_dim:
             raise hip.VFaceHipError(f"context must be [N, 1, {self.unet.context_dim}] (single token, SURVEY F11); "
@@ -675,7 +685,7 @@ class UNetEngine:
                 a, b = P[prefix]["a2_slice"]
                 self._gemm(v_all[:, a:b], P[prefix]["a2_out"], a2_all[:, a:b], flags=hip.EPI_OUT_F32)
         self._a2_cache = (context, context._version, P, a2_all)
-        return emb_all, a2_all
+        return a2_all
 
     def forward_nhwc(self, x: Act, timesteps: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
         """UNetModel.forward (openaimodel.py:860-907) on an NHWC 16-bit input (channels padded to 8k).
@@ -741,6 +751,111 @@ class UNetEngine:
             h = run(block, inp, tgt)
         h = self._gn(h, P["out.gn"], 1e-5, True)
         return self._conv(h, P["out.conv"], None, out_f32=True).t
+
+    # ------------------------------------------------------------------ hipGraph replay of a step's forward
+    def _hook_signature(self):
+        """(signature, flows): everything the hooked attn1 layers contribute to the launch sequence -- the HookCfg fields and
+        the flow tensors' shapes -- and the distinct flow tensors themselves, in order of first use."""
+        sig, flows = [], []
+        for kind, _, mod in self.unet.layer_table():
+            if kind != "st":
+                continue
+            cfg = getattr(mod.transformer_blocks[0].attn1, "_vface_cfg", None)
+            if cfg is None:
+                sig.append(None)
+                continue
+            fl, fi = cfg.flow, None
+            if fl is not None:
+                fi = next((i for i, f in enumerate(flows) if f is fl), None)
+                if fi is None:
+                    fi = len(flows)
+                    flows.append(fl)
+            sig.append((cfg.switch_on, cfg.chunks, cfg.fusion, cfg.split_ratio_fft, cfg.alpha, cfg.flow_gate,
+                        (fi, tuple(fl.shape)) if fl is not None else None))
+        return tuple(sig), flows
+
+    def step_forward_nhwc(self, x: Act, timesteps: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+        """``forward_nhwc`` for the DDIM loop: with ``use_graph`` the launch sequence of one forward is captured into a
+        hipGraph the first time a (batch, resolution, hook configuration) combination is seen and replayed afterwards -- the
+        same kernels on the same buffers, one host call per step instead of ~1200 (ddim_w_inv.py:299-305 calls the UNet once
+        per step with nothing but x and t changing).  What changes between steps or clips is copied into the graph's own
+        input buffers: x, t every step; the context projections and the flow fields when a new clip brings new tensors.
+        The returned eps is the graph's output buffer: consume it before the next call.  Frame-sharded engines (RCCL
+        point-to-point exchange inside the forward) and any capture failure run the eager path."""
+        if not self.use_graph or self.halo_exchange is not None or x.t32 is not None:
+            return self.forward_nhwc(x, timesteps, context)
+        self._ensure_packed()
+        sig, flows = self._hook_signature()
+        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, sig,
+               tuple(context.shape), torch.cuda.current_stream().cuda_stream)
+        g = self._graphs.get(key)
+        if g is None:
+            g = self._capture(key, x, timesteps, context, flows)
+            if g is None:
+                return self.forward_nhwc(x, timesteps, context)
+        else:
+            self._graphs[key] = self._graphs.pop(key)      # most recently used last
+        cid = (id(context), context._version)
+        if cid != g["ctx_id"]:
+            g["a2"].copy_(self.context_projections(context, x.N))
+            g["ctx_id"], g["ctx_keep"] = cid, context
+        for dst, src in zip(g["flows"], flows):
+            if (id(src), src._version) != g["flow_ids"].get(id(dst)):
+                dst.copy_(src)
+                g["flow_ids"][id(dst)] = (id(src), src._version)
+                g["flow_keep"][id(dst)] = src
+        g["x"].copy_(x.t)
+        g["t"].copy_(timesteps)
+        g["graph"].replay()
+        return g["eps"]
+
+    def _capture(self, key, x: Act, timesteps: torch.Tensor, context: torch.Tensor, flows):
+        xs = torch.empty_like(x.t)
+        ts = timesteps.to(device=self.device, dtype=torch.int64).clone()
+        xs.copy_(x.t)
+        # The graph reads two kinds of buffers that are not produced inside it: the context projections and the flow fields.
+        # It gets PRIVATE copies of both (refreshed in place when a later clip brings other tensors), so neither the caller's
+        # flow tensors nor the eager path's context cache are ever written to.
+        cfgs = []
+        for kind, _, mod in self.unet.layer_table():
+            cfg = getattr(mod.transformer_blocks[0].attn1, "_vface_cfg", None) if kind == "st" else None
+            if cfg is not None and cfg.flow is not None and not any(c is cfg for c in cfgs):
+                cfgs.append(cfg)
+        own_flows = [f.clone() for f in flows]
+        saved_flows = [c.flow for c in cfgs]
+        saved_cache = getattr(self, "_a2_cache", None)
+        try:
+            a2 = self.context_projections(context, x.N).clone()
+            self._a2_cache = (context, context._version, self._packed, a2)
+            for c in cfgs:
+                c.flow = own_flows[next(i for i, f in enumerate(flows) if f is c.flow)]
+            # warm-up on a side stream (the documented capture recipe): fills the folded-weight caches, sets every kernel's
+            # shared-memory attribute, and brings the allocator to its steady state
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self.forward_nhwc(Act(xs, x.N, x.H, x.W), ts, context)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eps = self.forward_nhwc(Act(xs, x.N, x.H, x.W), ts, context)
+        except Exception as e:  # capture is an optimisation of the same launch sequence: the eager path is the same code
+            import warnings
+            warnings.warn(f"vface_amd: hipGraph capture of the UNet forward failed ({type(e).__name__}: {e}); "
+                          "running kernel by kernel")
+            self.use_graph = False
+            return None
+        finally:
+            for c, f in zip(cfgs, saved_flows):
+                c.flow = f
+            self._a2_cache = saved_cache
+        while len(self._graphs) >= self.graph_capacity:
+            self._graphs.pop(next(iter(self._graphs)))
+        g = {"graph": graph, "x": xs, "t": ts, "eps": eps, "a2": a2, "ctx_id": (id(context), context._version),
+             "ctx_keep": context, "flows": own_flows, "flow_ids": {id(d): (id(s_), s_._version) for d, s_ in zip(own_flows, flows)},
+             "flow_keep": {id(d): s_ for d, s_ in zip(own_flows, flows)}, "packed": self._packed}
+        self._graphs[key] = g
+        return g
 
     def forward(self, x: torch.Tensor, timesteps: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
         """NCHW fp32 in, NCHW fp32 out -- the signature of the reference's ``UNetModel.forward``."""

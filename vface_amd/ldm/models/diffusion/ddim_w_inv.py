@@ -218,7 +218,7 @@ class DDIMSampler(object):
         else:
             c_in = torch.cat(list(parts), dim=0)
             self._c_in_cache = (parts, tuple(p._version for p in parts), c_in)
-        eps = eng.forward_nhwc(Act(x_in, 3 * F_, H, W), t_in, c_in)  # fp32 [3F*HW, 4]
+        eps = eng.step_forward_nhwc(Act(x_in, 3 * F_, H, W), t_in, c_in)  # fp32 [3F*HW, 4]
         a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])
         sigma_t, s1m = float(self.ddim_sigmas[index]), float(self.ddim_sqrt_one_minus_alphas[index])
         noise = noise_like(x.shape, device, repeat_noise) * temperature  # drawn even when sigma_t == 0 (:697)
@@ -264,7 +264,7 @@ class DDIMSampler(object):
             ts = torch.full((b,), int(step), device=device, dtype=torch.long)
             x9 = torch.empty(b * H * W, 16, dtype=eng.dtype, device=device)
             hip.nchw_to_nhwc(torch.cat([x, inpaint, mask], 1).contiguous(), x9, N=b, C_=9, hw=H * W, cpad=16)
-            eps = eng.forward_nhwc(Act(x9, b, H, W), ts, cond)
+            eps = eng.step_forward_nhwc(Act(x9, b, H, W), ts, cond)
             a_next = float(ac[int(step)])
             cur = max(0, int(step) - (1000 // len(timesteps)))
             a_cur = float(ac[cur])

@@ -68,6 +68,8 @@ def build_parser() -> argparse.ArgumentParser:
                         "maps of a 512x512 clip, nothing at any other resolution); 'flow_hw' = the level whose token count equals "
                         "h*w of the flow field (needed for the module to act at e.g. 768x768)")
     p.add_argument("--compute_dtype", choices=["fp16", "bf16"], default="fp16")
+    p.add_argument("--hip_graph", action="store_true",
+                   help="replay each DDIM step's UNet forward from a hipGraph (one capture per clip shape and hook plan)")
     p.add_argument("--max_steps", type=int, default=None, help="stop after this many DDIM steps (smoke runs)")
     return p
 
@@ -115,6 +117,8 @@ def run_synthetic(opt) -> dict:
     sampler = DDIMSampler(model)
     sampler.hook_plan = HookPlan(fusion=opt.fusion, enabled=opt.fusion != "none")
     sampler.flow_gate = opt.flow_gate
+    if opt.hip_graph:
+        sampler.model.model.diffusion_model.engine.use_graph = True
     sampler.flow_resample = "area" if opt.flow_pixels else None
     h, w = opt.H // opt.f, opt.W // opt.f
     F_ = opt.n_samples
