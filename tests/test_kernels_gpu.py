@@ -797,3 +797,39 @@ def test_conv_patch_kernel_fused_groupnorm_silu(dt, cin, cout, H, W, nimg, silu)
     assert rel_l2(fused.cpu().float(), ref) < TOL[dt] * 1.3
     with pytest.raises(h.VFaceHipError):     # the im2col kernel has no fused form: refuse, never silently skip the normalisation
         h.conv3x3(xn, wp, sep, nimg=nimg, H=H, W=W, cin=cin, cout=cout, ldx=cin, ldy=cout, gn_ab=ab, gn_silu=silu, flags=h.TUNE_NO_PATCH)
+
+
+# ------------------------------------------------------------------------------------------ plain GEMM through the 256-row tile
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,rps", [(1024, 320, 320, 256), (2048, 640, 1280, 1024), (512, 1280, 128, 256), (768, 960, 320, 256)])
+def test_gemm_256_row_tile_equals_128_row_kernel_bit_for_bit(dt, M, N, K, rps):
+    """VFACE_TUNE_PATCH on a plain GEMM: conv.hip's 256 x BN tile (its "fused 1x1 source" K loop with no window tiles) --
+    same K order per accumulator as gemm.hip, so the same bits: 16-bit output, fp32 carrier, column statistics; bias, per-sample
+    row bias, 16-bit and fp32 residuals."""
+    h = hip()
+    a, w = rnd((M, K), 1, dt).to(DEV), rnd((N, K), 2, dt, 1 / math.sqrt(K)).to(DEV)
+    bias, rb = rnd((N,), 3, torch.float32).to(DEV), rnd((M // rps, N), 5, torch.float32).to(DEV)
+    res16, res32 = rnd((M, N), 4, dt).to(DEV), rnd((M, N), 6, torch.float32).to(DEV)
+    for kw in (dict(), dict(rowbias=rb, rows_per_sample=rps), dict(residual=res16, ldr=N), dict(residual32=res32, want32=True)):
+        outs = []
+        for fl in (0x600 if N % 160 == 0 else 0x500, h.TUNE_PATCH):
+            k2 = dict(kw)
+            want32 = k2.pop("want32", False)
+            o16 = torch.zeros(M, N, dtype=dt, device=DEV)
+            o32 = torch.zeros(M, N, dtype=torch.float32, device=DEV) if want32 else None
+            cs = torch.zeros(M // 64, N, 2, dtype=torch.float32, device=DEV)
+            h.gemm(a, w, o16, M=M, N=N, K=K, lda=K, ldc=N, bias=bias, flags=fl, colstats=cs, split_k=False,
+                   **({"out32": o32} if want32 else {}), **k2)
+            outs.append((o16, o32, cs))
+        ref = a.double() @ w.double().t() + bias.double()
+        if "rowbias" in kw:
+            ref = ref + rb.double().repeat_interleave(rps, 0)
+        if "residual" in kw:
+            ref = ref + res16.double()
+        if "residual32" in kw:
+            ref = ref + res32.double()
+        assert rel_l2(outs[1][0].double().cpu(), ref.cpu()) < (2e-3 if dt == torch.float16 else 1e-2)
+        assert torch.equal(outs[0][0], outs[1][0]), f"16-bit output differs ({list(kw)})"
+        if outs[0][1] is not None:
+            assert torch.equal(outs[0][1], outs[1][1]), "fp32 carrier differs"
+        assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-3), "column statistics differ"

@@ -289,9 +289,17 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     };
 
     // ---- prologue: patch of chunk 0 (all pieces), weight tiles 0 and 1
+    if (nchunks > 0) {
 #pragma unroll
-    for (int i = 0; i < PPW; ++i) issue_P(0, i);
-    issue_T(0);
+        for (int i = 0; i < PPW; ++i) issue_P(0, i);
+        issue_T(0);
+    } else if constexpr (TAIL) {
+        // plain GEMM (vf_launch_gemm_patch): no window at all, every K tile is a tile of the halo-free "1x1 source"
+        if (ntail > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) issue_P2(0, i);
+        }
+    }
     issue_B(0, 0);
     if (T > 1) issue_B(1, 1 % NSLOT);
 
@@ -351,14 +359,14 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         // lane_pp is in units of the window patch's pitch: rebase to the halo-free 16-pixel pitch
         read_h0((unsigned)(NSLOT * BSLOT + ((nchunks + u) & 1) * PATCH_BYTES), wm * 4 * TP - wm * 4 * PW, TP, wb);
         __builtin_amdgcn_sched_barrier(0);
-        if (late) { mfma_Y(); __builtin_amdgcn_sched_barrier(0); }
+        if (late && kt > 0) { mfma_Y(); __builtin_amdgcn_sched_barrier(0); }
         if (u + 1 < ntail) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) issue_P2(u + 1, i);
         }
         if (kt + 2 < T) issue_B(kt + 2, (kt + 2) % NSLOT);
         __builtin_amdgcn_sched_barrier(0);
-        if (!late) { mfma_Y(); __builtin_amdgcn_sched_barrier(0); }
+        if (!late && kt > 0) { mfma_Y(); __builtin_amdgcn_sched_barrier(0); }   // (kt == 0: a plain GEMM's first tile)
         read_h1(wb);
         __builtin_amdgcn_sched_barrier(0);
         mfma_X();
@@ -395,7 +403,9 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
         const long mrow0 = ((long)img * p.H + ty0 + wm * 4) * p.W + tx0;   // output row (pixel index) of (i = 0, r = 0)
-        const float* rb = rowbias ? rowbias + (long)img * p.ld_rowbias : nullptr;
+        // (plain GEMM through this kernel: an "image" is 256 consecutive rows of a sample of rows_per_sample rows)
+        const int smp = p.mode == 0 ? (int)(((long)img * (TP * TP)) / p.rows_per_sample) : img;
+        const float* rb = rowbias ? rowbias + (long)smp * p.ld_rowbias : nullptr;
         // bias / row bias of this wave's NT column tiles, requested once up front (see gemm.hip's wide epilogue)
         float4 bj[NT], rbj[NT];
 #pragma unroll
@@ -593,6 +603,34 @@ int vf_conv_patch_tile(const GemmParams& p) {
     if (p.N % 160 == 0) return 160;
     if (p.N % 128 == 0) return 128;
     return 0;
+}
+
+// Plain GEMM C[M, N] = A[M, K] Wt[N, K]^T through the patch-staged kernel's 256 x BN tile (8 waves, one workgroup per CU): the
+// kernel's "fused 1x1 source" K loop IS a GEMM K loop -- 256 consecutive rows of A per workgroup as a halo-free 16 x 16 "image",
+// no window tiles at all.  Versus gemm.hip's 128-row tile: 28 % fewer L2->LDS bytes per FLOP (measured where it pays: DESIGN 4).
+// 0 = not a shape this form takes; else the channel-tile width.
+int vf_gemm_patch_tile(const GemmParams& p) {
+    if (p.mode != 0 || p.A2 || p.out_phase || p.gn_ab || p.split_k > 1) return 0;
+    if ((p.M % (TP * TP)) || (p.K & 63) || p.K < 128) return 0;
+    if ((p.flags & (GEMM_GEGLU | GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE | 0x4000)) || (p.N & 7)) return 0;
+    if (p.rowbias && (p.rows_per_sample <= 0 || (p.rows_per_sample % (TP * TP)))) return 0;
+    if (p.residual && !p.res_f32 && (((uintptr_t)p.residual & 15) || (p.ldr & 7))) return 0;
+    if (((uintptr_t)p.C & 15) || (p.C && (p.ldc & 7))) return 0;
+    if (p.N % 160 == 0) return 160;
+    if (p.N % 128 == 0) return 128;
+    return 0;
+}
+
+int vf_launch_gemm_patch(const GemmParams& p_in, int dtype, hipStream_t stream) {
+    const int bn = vf_gemm_patch_tile(p_in);
+    if (!bn) return VF_ERR_SHAPE;
+    GemmParams p = p_in;
+    // the geometry the kernel derives its tile origin and output rows from: M / 256 images of 16 x 16 pixels, no window
+    p.H = p.W = p.OH = p.OW = TP; p.Cin = 0; p.K1 = 0; p.KH = p.KW = 3; p.ntaps = 9; p.pad = p.pad_x = 0; p.stride = 1; p.upsample = 0;
+    p.A2 = p.A; p.lda2 = p.lda; p.a2_bytes = p.a_bytes; p.a2_row_mod = 0;
+    if (dtype == VF_DTYPE_F16) return bn == 160 ? launch_patch<F16, 5, 3, 3>(p, stream) : launch_patch<F16, 4, 3, 3>(p, stream);
+    if (dtype == VF_DTYPE_BF16) return bn == 160 ? launch_patch<BF16, 5, 3, 3>(p, stream) : launch_patch<BF16, 4, 3, 3>(p, stream);
+    return VF_ERR_DTYPE;
 }
 
 int vf_launch_conv_patch(const GemmParams& p, int dtype, hipStream_t stream) {

@@ -1033,6 +1033,7 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
             if (tiles24 >= 160 || (p.flags & GEMM_PATCH)) return vf_launch_conv_patch(p, dtype, stream);
         }
     }
+    if (p.mode == 0 && (p.flags & GEMM_PATCH) && !((p.flags >> 8) & 0xF) && vf_gemm_patch_tile(p)) return vf_launch_gemm_patch(p, dtype, stream);
     if (p.gn_ab) return VF_ERR_SHAPE;   // the fused input normalisation exists in the patch-staged kernel only
     const int variant = pick_variant(p);
     if ((p.res_f32 || p.C32) && variant != 5 && variant != 6) return VF_ERR_SHAPE;

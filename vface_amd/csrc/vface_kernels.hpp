@@ -59,6 +59,8 @@ int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 // conv.hip: the patch-staged stride-1 convolution; vf_conv_patch_tile = 0 (not a patch shape) | 160 | 128
 int vf_conv_patch_tile(const GemmParams& p);
 int vf_launch_conv_patch(const GemmParams& p, int dtype, hipStream_t stream);
+int vf_gemm_patch_tile(const GemmParams& p);                                   // plain GEMM through the patch kernel's 256-row tile: 0 | 160 | 128
+int vf_launch_gemm_patch(const GemmParams& p, int dtype, hipStream_t stream);
 bool vf_attention_shared_scores_supported(int dh, int v_sets);
 int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream);
 int vf_launch_gemm_pp(const GemmParams& p, int dtype, int variant, hipStream_t stream);
