@@ -370,7 +370,7 @@ def main():
         if cands and F_ == 8 and h == 64 and a.fusion == "replace" and a.dtype == "fp16":
             tf = os.path.join(prof, cands[-1])
             tj = json.load(open(tf))
-            key = next((k for k in tj if k.startswith("conv_patch_kernel") and ", 3, 3" in k), "_conv_all")
+            key = "_conv_patch3" if "_conv_patch3" in tj else next((k for k in tj if k.startswith("conv_patch_kernel") and ", 3, 3" in k), "_conv_all")
             traffic = tj[key]["hbm_bytes_per_launch"]
             traffic_src = (f"QUOTED from profiles/{cands[-1]} [{key}] (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                            "command on the build it names), not measured in this run")
