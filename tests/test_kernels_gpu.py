@@ -833,3 +833,40 @@ def test_gemm_256_row_tile_equals_128_row_kernel_bit_for_bit(dt, M, N, K, rps):
         if outs[0][1] is not None:
             assert torch.equal(outs[0][1], outs[1][1]), "fp32 carrier differs"
         assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-3), "column statistics differ"
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_epilogue_16_bit_transpose_equals_fp32_transpose_bit_for_bit(dt):
+    """Where nothing reads the fp32 sum (no residual, no carrier) the epilogue rounds BEFORE its LDS transpose: same single
+    rounding, so the same bits and statistics as the fp32 transpose (VFACE_TUNE_F32_TRANSPOSE) -- plain GEMM (both tile
+    widths, ragged M), GEGLU, both convolution kernels, a parity-phase launch."""
+    h = hip()
+    cases = []
+    for (M, N, K, geglu) in [(1000, 320, 320, False), (520, 256, 128, False), (640, 512, 192, True)]:
+        a, w = rnd((M, K), 1, dt).to(DEV), rnd((N, K), 2, dt, 1 / math.sqrt(K)).to(DEV)
+        bias = rnd((N,), 3, torch.float32).to(DEV)
+        No = N // 2 if geglu else N
+        def run(fl, a=a, w=w, bias=bias, M=M, N=N, K=K, No=No, geglu=geglu):
+            o = torch.zeros(M, No, dtype=dt, device=DEV)
+            cs = torch.zeros(M // 64, No, 2, dtype=torch.float32, device=DEV) if (M % 64 == 0 and not geglu) else None
+            h.gemm(a, w, o, M=M, N=N, K=K, lda=K, ldc=No, bias=bias, flags=fl | (h.EPI_GEGLU if geglu else 0), colstats=cs, split_k=False)
+            return o, cs
+        cases.append(run)
+    nimg, H, cin, cout = 3, 16, 128, 320
+    x = rnd((nimg * H * H, cin), 5, dt).to(DEV)
+    from vface_amd.packing import pack_conv3x3
+    wc = pack_conv3x3(rnd((cout, cin, 3, 3), 6, torch.float32, 1 / math.sqrt(9 * cin))).to(dt).to(DEV)
+    bc, rb = rnd((cout,), 7, torch.float32).to(DEV), rnd((nimg, cout), 8, torch.float32).to(DEV)
+    for base in (h.TUNE_PATCH, h.TUNE_NO_PATCH):
+        def run(fl, base=base):
+            o = torch.zeros(nimg * H * H, cout, dtype=dt, device=DEV)
+            cs = torch.zeros(nimg * H * H // 64, cout, 2, dtype=torch.float32, device=DEV)
+            h.conv3x3(x, wc, o, nimg=nimg, H=H, W=H, cin=cin, cout=cout, ldx=cin, ldy=cout, bias=bc, rowbias=rb, flags=base | fl,
+                      colstats=cs, split_k=False)
+            return o, cs
+        cases.append(run)
+    for run in cases:
+        (o1, c1), (o2, c2) = run(0), run(h.TUNE_F32_TRANSPOSE)
+        assert o1.abs().sum() > 0 and torch.equal(o1, o2)
+        if c1 is not None:
+            assert torch.equal(c1, c2)

@@ -461,60 +461,85 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         E* pC = Cout + brow * p.ldc + ncol;
         float* pC32 = C32 + brow * p.ldc32 + ncol;
         const float* lrd = scr + rch * 8;
+        // HALF (no residual, no fp32 carrier): the accumulators are rounded before the transpose and cross LDS as 16-bit values --
+        // see gemm.hip's wide epilogue
+        constexpr int SPH = WN * 2 + 16;
+        using V4 = typename TT::v4;
+        auto passes = [&](auto half_tag) {
+            constexpr bool HALF = decltype(half_tag)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            {
-                float* srow = scr + fr * SP + fq * 4;
+            for (int i = 0; i < 4; ++i) {
+                {
+                    float* srow = scr + fr * SP + fq * 4;
+                    unsigned char* hrow = reinterpret_cast<unsigned char*>(scr) + fr * SPH + fq * 8;
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    *reinterpret_cast<float4*>(srow + j * 16) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-            }
-            // LDS operations of one wave execute in order: the reads below see the writes above.  Every lane reads (rows clamped
-            // into the scratch), only the stores are predicated: the RI x 2 reads of the pass go out back to back.
-            float4 x[RI][2];
-#pragma unroll
-            for (int it = 0; it < RI; ++it) {
-                const int rc = min(rrow + it * LPR, 15);
-                x[it][0] = *reinterpret_cast<const float4*>(lrd + rc * SP);
-                x[it][1] = *reinterpret_cast<const float4*>(lrd + rc * SP + 4);
-            }
-#pragma unroll
-            for (int it = 0; it < RI; ++it) {
-                if (act && rrow + it * LPR < 16) {
-                    float v[8] = {x[it][0].x, x[it][0].y, x[it][0].z, x[it][0].w, x[it][1].x, x[it][1].y, x[it][1].z, x[it][1].w};
-                    if constexpr (RMODE == 1) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += to_f32(r16[i % DEPTH][it][e]);
+                    for (int j = 0; j < NT; ++j) {
+                        if constexpr (HALF) *reinterpret_cast<V4*>(hrow + j * 32) = V4{from_f32<E>(acc[j][i][0]), from_f32<E>(acc[j][i][1]), from_f32<E>(acc[j][i][2]), from_f32<E>(acc[j][i][3])};
+                        else *reinterpret_cast<float4*>(srow + j * 16) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
                     }
-                    if constexpr (RMODE == 2) {
-                        const float4 a = r32[i % DEPTH][it][0], b = r32[i % DEPTH][it][1];
-                        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-                    }
-                    V8 o;
+                }
+                // LDS operations of one wave execute in order: the reads below see the writes above.  Every lane reads (rows clamped
+                // into the scratch), only the stores are predicated: the RI x 2 reads of the pass go out back to back.
+                float4 x[HALF ? 1 : RI][2];
+                V8 xh[HALF ? RI : 1];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
-                    const long roff = i * step_i + (long)(it * LPR) * step_r;   // wave-uniform
-                    if (Cout) *reinterpret_cast<V8*>(pC + roff * p.ldc) = o;
-                    if (C32) {
-                        float* d32 = pC32 + roff * p.ldc32;
-                        *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                for (int it = 0; it < RI; ++it) {
+                    const int rc = min(rrow + it * LPR, 15);
+                    if constexpr (HALF) {
+                        xh[it] = *reinterpret_cast<const V8*>(reinterpret_cast<const unsigned char*>(scr) + rc * SPH + rch * 16);
+                    } else {
+                        x[it][0] = *reinterpret_cast<const float4*>(lrd + rc * SP);
+                        x[it][1] = *reinterpret_cast<const float4*>(lrd + rc * SP + 4);
                     }
-                    if (colstats) {
-                        if (C32) {
+                }
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { s8[e] += v[e]; q8[e] = fmaf(v[e], v[e], q8[e]); }
+                for (int it = 0; it < RI; ++it) {
+                    if (act && rrow + it * LPR < 16) {
+                        float v[8];
+                        V8 o;
+                        if constexpr (HALF) {
+                            o = xh[it];
                         } else {
+                            const float4 x0 = x[it][0], x1 = x[it][1];
+                            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                        }
+                        if constexpr (RMODE == 1) {
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] = fmaf(f, f, q8[e]); }
+                            for (int e = 0; e < 8; ++e) v[e] += to_f32(r16[i % DEPTH][it][e]);
+                        }
+                        if constexpr (RMODE == 2) {
+                            const float4 a = r32[i % DEPTH][it][0], b = r32[i % DEPTH][it][1];
+                            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+                        }
+                        if constexpr (!HALF) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
+                        }
+                        const long roff = i * step_i + (long)(it * LPR) * step_r;   // wave-uniform
+                        if (Cout) *reinterpret_cast<V8*>(pC + roff * p.ldc) = o;
+                        if (!HALF && C32) {
+                            float* d32 = pC32 + roff * p.ldc32;
+                            *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        }
+                        if (colstats) {
+                            if (!HALF && C32) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { s8[e] += v[e]; q8[e] = fmaf(v[e], v[e], q8[e]); }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] = fmaf(f, f, q8[e]); }
+                            }
                         }
                     }
                 }
+                if constexpr (RMODE != 0 && DEPTH < 4) {
+                    if (i + DEPTH < 4) load_res(i + DEPTH, i % DEPTH);
+                }
             }
-            if constexpr (RMODE != 0 && DEPTH < 4) {
-                if (i + DEPTH < 4) load_res(i + DEPTH, i % DEPTH);
-            }
-        }
+        };
+        if (RMODE == 0 && !C32 && !(p.flags & GEMM_F32_TRANSPOSE)) passes(std::integral_constant<bool, RMODE == 0>{});
+        else passes(std::false_type{});
         if (colstats) {
             // fold the LPR row-lanes of every channel through the scratch (fixed order: reproducible).  The wave's 64 pixels
             // (4 image rows x 16) are one statistics slice; slices only have to lie inside one sample and be numbered

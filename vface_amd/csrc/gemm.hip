@@ -397,101 +397,128 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         E* pC = Cout + (long)(wrow0 + rrow) * p.ldc + ncol;
         float* pC32 = C32 + (long)(wrow0 + rrow) * p.ldc32 + ncol;
         const float* lrd = scr + rch * 8;             // this lane's chunk column in the scratch
+        // HALF: no residual and no fp32 carrier -- nothing downstream reads the fp32 sum, so the accumulators are rounded BEFORE
+        // the transpose and go through LDS as 16-bit values: half the bytes through the LDS store path (the largest single
+        // item of the epilogue: stamps), one 16-byte read per output chunk instead of two.  Same values, same single
+        // rounding, same statistics (taken from the rounded values, as before).
+        constexpr int SPH = WN * 2 + 16;              // 16-bit scratch row pitch (bytes; rows stay 16-byte aligned)
+        using V4 = typename TT::v4;
+        auto passes = [&](auto half_tag) {
+            constexpr bool HALF = decltype(half_tag)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            {
-                const int m = wrow0 + i * 16 + fr;
-                const float* rb = (rowbias && !one_sample && m < p.M) ? rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
-                float* srow = scr + fr * SP + fq * 4;
-                if (!gg) {
+            for (int i = 0; i < 4; ++i) {
+                {
+                    const int m = wrow0 + i * 16 + fr;
+                    const float* rb = (rowbias && !one_sample && m < p.M) ? rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+                    float* srow = scr + fr * SP + fq * 4;
+                    unsigned char* hrow = reinterpret_cast<unsigned char*>(scr) + fr * SPH + fq * 8;
+                    if (!gg) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
-                        if (rowbias && !one_sample) {
-                            const int nb = en0 + wn * WN + j * 16 + fq * 4;
-                            if (rb && nb < p.N) { const float4 b = *reinterpret_cast<const float4*>(rb + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                        for (int j = 0; j < NT; ++j) {
+                            float4 v = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+                            if (rowbias && !one_sample) {
+                                const int nb = en0 + wn * WN + j * 16 + fq * 4;
+                                if (rb && nb < p.N) { const float4 b = *reinterpret_cast<const float4*>(rb + nb); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+                            }
+                            if constexpr (HALF) *reinterpret_cast<V4*>(hrow + j * 32) = V4{from_f32<E>(v.x), from_f32<E>(v.y), from_f32<E>(v.z), from_f32<E>(v.w)};
+                            else *reinterpret_cast<float4*>(srow + j * 16) = v;
                         }
-                        *reinterpret_cast<float4*>(srow + j * 16) = v;
-                    }
-                } else if constexpr ((NT & 1) == 0) {
+                    } else if constexpr ((NT & 1) == 0) {
 #pragma unroll
-                    for (int jj = 0; jj < NT / 2; ++jj) {
-                        float a[4], g[4];
+                        for (int jj = 0; jj < NT / 2; ++jj) {
+                            float a[4], g[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { a[r] = acc[2 * jj][i][r]; g[r] = acc[2 * jj + 1][i][r]; }
-                        // (bias already summed: value rows in the even column tiles, gate rows 16 further in the odd ones)
-                        *reinterpret_cast<float4*>(srow + jj * 16) =
-                            make_float4(a[0] * gelu_erf_f(g[0]), a[1] * gelu_erf_f(g[1]), a[2] * gelu_erf_f(g[2]), a[3] * gelu_erf_f(g[3]));
+                            for (int r = 0; r < 4; ++r) { a[r] = acc[2 * jj][i][r]; g[r] = acc[2 * jj + 1][i][r]; }
+                            // (bias already summed: value rows in the even column tiles, gate rows 16 further in the odd ones)
+                            const float4 v = make_float4(a[0] * gelu_erf_f(g[0]), a[1] * gelu_erf_f(g[1]), a[2] * gelu_erf_f(g[2]), a[3] * gelu_erf_f(g[3]));
+                            if constexpr (HALF) *reinterpret_cast<V4*>(hrow + jj * 32) = V4{from_f32<E>(v.x), from_f32<E>(v.y), from_f32<E>(v.z), from_f32<E>(v.w)};
+                            else *reinterpret_cast<float4*>(srow + jj * 16) = v;
+                        }
                     }
                 }
-            }
-            // LDS operations of one wave execute in order: the reads below see the writes above, and the next
-            // tile row's writes cannot overtake these reads.  Every lane reads (rows clamped into the scratch), only
-            // the stores are predicated: the RI x 2 reads of the pass go out back to back.
-            { const unsigned long long t = estamp(); dbg_ew += t - e_t; e_t = t; }
-            float4 x[RI][2];
+                // LDS operations of one wave execute in order: the reads below see the writes above, and the next
+                // tile row's writes cannot overtake these reads.  Every lane reads (rows clamped into the scratch), only
+                // the stores are predicated: the RI x 2 reads of the pass go out back to back.
+                { const unsigned long long t = estamp(); dbg_ew += t - e_t; e_t = t; }
+                float4 x[HALF ? 1 : RI][2];
+                V8 xh[HALF ? RI : 1];
 #pragma unroll
-            for (int it = 0; it < RI; ++it) {       // (RI passes without GEGLU; its narrower rows need fewer: r < 16 cuts them)
-                const int rc = min(rrow + it * LPR, 15);
-                x[it][0] = *reinterpret_cast<const float4*>(lrd + rc * SP);
-                x[it][1] = *reinterpret_cast<const float4*>(lrd + rc * SP + 4);
-            }
-            if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = estamp(); dbg_er += t - e_t; e_t = t; }
-#pragma unroll
-            for (int it = 0; it < RI; ++it) {
-                const int r = rrow + it * LPR;
-                const int srow_u = i * 16 + it * LPR;            // wave-uniform part of the slab row
-                if (colok && r < 16 && srow_u + rrow < lim) {
-                    float v[8] = {x[it][0].x, x[it][0].y, x[it][0].z, x[it][0].w, x[it][1].x, x[it][1].y, x[it][1].z, x[it][1].w};
-                    if constexpr (RMODE == 1) {
-                        const V8 r8 = rres[i % DEPTH][it];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += to_f32(r8[e]);
-                    }
-                    if constexpr (RMODE == 2) {
-                        const float4 a = r32[i % DEPTH][it][0], b = r32[i % DEPTH][it][1];
-                        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-                    }
-                    V8 o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
-                    if (!phased) {
-                        if (Cout) *reinterpret_cast<V8*>(pC + (long)srow_u * p.ldc) = o;
-                        if (C32) {
-                            float* d32 = pC32 + (long)srow_u * p.ldc32;
-                            *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
-                            *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                        }
+                for (int it = 0; it < RI; ++it) {       // (RI passes without GEGLU; its narrower rows need fewer: r < 16 cuts them)
+                    const int rc = min(rrow + it * LPR, 15);
+                    if constexpr (HALF) {
+                        xh[it] = *reinterpret_cast<const V8*>(reinterpret_cast<const unsigned char*>(scr) + rc * SPH + rch * 16);
                     } else {
-                        // one output-parity phase of conv(nearest x2 upsample): pixel (oy, ox) of the phase grid is
-                        // pixel (2 oy + py, 2 ox + px) of the 2OH x 2OW output
-                        const int m = wrow0 + srow_u + rrow;
-                        const int hw = p.OH * p.OW, img = m / hw, rem = m - img * hw, oy = rem / p.OW, ox = rem - oy * p.OW;
-                        const long orow = ((long)img * 2 * p.OH + 2 * oy + ((p.out_phase >> 1) & 1)) * (2 * p.OW) + 2 * ox + (p.out_phase & 1);
-                        if (Cout) *reinterpret_cast<V8*>(Cout + orow * p.ldc + ncol) = o;
-                        if (C32) {
-                            float* d32 = C32 + orow * p.ldc32 + ncol;
-                            *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
-                            *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                        }
+                        x[it][0] = *reinterpret_cast<const float4*>(lrd + rc * SP);
+                        x[it][1] = *reinterpret_cast<const float4*>(lrd + rc * SP + 4);
                     }
-                    if (want_stats) {
-                        // statistics of the values the following GroupNorm will read: the fp32 carrier if there is one
-                        if (C32) {
+                }
+                if (diag) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t = estamp(); dbg_er += t - e_t; e_t = t; }
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { s8[e] += v[e]; q8[e] = fmaf(v[e], v[e], q8[e]); }
+                for (int it = 0; it < RI; ++it) {
+                    const int r = rrow + it * LPR;
+                    const int srow_u = i * 16 + it * LPR;            // wave-uniform part of the slab row
+                    if (colok && r < 16 && srow_u + rrow < lim) {
+                        float v[8];
+                        V8 o;
+                        if constexpr (HALF) {
+                            o = xh[it];      // already rounded: the only values anything downstream reads
                         } else {
+                            const float4 x0 = x[it][0], x1 = x[it][1];
+                            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                        }
+                        if constexpr (RMODE == 1) {
+                            const V8 r8 = rres[i % DEPTH][it];
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] = fmaf(f, f, q8[e]); }
+                            for (int e = 0; e < 8; ++e) v[e] += to_f32(r8[e]);
+                        }
+                        if constexpr (RMODE == 2) {
+                            const float4 a = r32[i % DEPTH][it][0], b = r32[i % DEPTH][it][1];
+                            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+                        }
+                        if constexpr (!HALF) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
+                        }
+                        if (!phased) {
+                            if (Cout) *reinterpret_cast<V8*>(pC + (long)srow_u * p.ldc) = o;
+                            if (!HALF && C32) {
+                                float* d32 = pC32 + (long)srow_u * p.ldc32;
+                                *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
+                                *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                            }
+                        } else {
+                            // one output-parity phase of conv(nearest x2 upsample): pixel (oy, ox) of the phase grid is
+                            // pixel (2 oy + py, 2 ox + px) of the 2OH x 2OW output
+                            const int m = wrow0 + srow_u + rrow;
+                            const int hw = p.OH * p.OW, img = m / hw, rem = m - img * hw, oy = rem / p.OW, ox = rem - oy * p.OW;
+                            const long orow = ((long)img * 2 * p.OH + 2 * oy + ((p.out_phase >> 1) & 1)) * (2 * p.OW) + 2 * ox + (p.out_phase & 1);
+                            if (Cout) *reinterpret_cast<V8*>(Cout + orow * p.ldc + ncol) = o;
+                            if (!HALF && C32) {
+                                float* d32 = C32 + orow * p.ldc32 + ncol;
+                                *reinterpret_cast<float4*>(d32) = make_float4(v[0], v[1], v[2], v[3]);
+                                *reinterpret_cast<float4*>(d32 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                            }
+                        }
+                        if (want_stats) {
+                            // statistics of the values the following GroupNorm will read: the fp32 carrier if there is one
+                            if (!HALF && C32) {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { s8[e] += v[e]; q8[e] = fmaf(v[e], v[e], q8[e]); }
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < 8; ++e) { const float f = to_f32(o[e]); s8[e] += f; q8[e] = fmaf(f, f, q8[e]); }
+                            }
                         }
                     }
                 }
+                if constexpr (RMODE != 0 && DEPTH < 4) {
+                    if (i + DEPTH < 4) load_res(i + DEPTH, i % DEPTH);
+                }
+                { const unsigned long long t = estamp(); dbg_es += t - e_t; e_t = t; }
             }
-            if constexpr (RMODE != 0 && DEPTH < 4) {
-                if (i + DEPTH < 4) load_res(i + DEPTH, i % DEPTH);
-            }
-            { const unsigned long long t = estamp(); dbg_es += t - e_t; e_t = t; }
-        }
+        };
+        if (RMODE == 0 && !C32 && !(p.flags & GEMM_F32_TRANSPOSE)) passes(std::integral_constant<bool, RMODE == 0>{});
+        else passes(std::false_type{});
         if (want_stats) {
             // fold the LPR row-lanes of every channel through the scratch (fixed order: reproducible)
             if (act) {
