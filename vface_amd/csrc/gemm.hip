@@ -987,6 +987,12 @@ int split_for(int M, int N, int K, int flags, int rows_per_sample) {
 
 }  // namespace
 
+// The file is compiled as two translation units so that the two element types build in parallel (half the wall time of
+// `make -j`): VF_GEMM_TU == 1 holds the bf16 instantiations behind vf_launch_gemm_bf16, the default unit everything else.
+int vf_launch_gemm_bf16(const GemmParams& p, int variant, hipStream_t stream);
+#if defined(VF_GEMM_TU) && VF_GEMM_TU == 1
+int vf_launch_gemm_bf16(const GemmParams& p, int variant, hipStream_t stream) { return launch_gemm<BF16>(p, variant, stream); }
+#else
 bool vf_gemm_variants_built() {
 #ifdef VFACE_GEMM_VARIANTS
     return true;
@@ -1084,6 +1090,7 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     if ((variant >= 1 && variant <= 4) || variant == 9 || variant == 10) return VF_ERR_SHAPE;
 #endif
     if (dtype == VF_DTYPE_F16) return launch_gemm<F16>(p, variant, stream);
-    if (dtype == VF_DTYPE_BF16) return launch_gemm<BF16>(p, variant, stream);
+    if (dtype == VF_DTYPE_BF16) return vf_launch_gemm_bf16(p, variant, stream);
     return VF_ERR_DTYPE;
 }
+#endif  // VF_GEMM_TU
