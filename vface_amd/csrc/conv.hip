@@ -625,8 +625,20 @@ int vf_conv_patch_tile(const GemmParams& p) {
     if (p.colstats && ((p.H * p.W) & 63)) return 0;
     if (p.residual && !p.res_f32 && (((uintptr_t)p.residual & 15) || (p.ldr & 7))) return 0;
     if (((uintptr_t)p.C & 15) || (p.C && (p.ldc & 7))) return 0;
-    if (p.N % 160 == 0) return 160;
-    if (p.N % 128 == 0) return 128;
+    const bool ok160 = p.N % 160 == 0, ok128 = p.N % 128 == 0;
+    if (ok160 && ok128 && !(p.flags & (GEMM_PATCH_BN160 | 0x4000))) {
+        // Both widths tile N (640, 1280, 1920 channels): one workgroup per CU, so a launch takes ceil(workgroups / CUs) rounds, and
+        // a 128-wide workgroup takes ~0.8 of a 160-wide one (32 instead of 40 MFMAs per wave and K tile, same fixed costs).
+        // Measured (tools/quantisation_probe.py, 24 samples): 32x32 640->640: 160-wide 384 workgroups = 1.5 rounds 181.6 us,
+        // 128-wide 480 = 1.9 rounds 153.6 us; 16x16 1280->1280: 192 = 0.75 rounds 175.3 us vs 240 = 0.94 rounds 151.8 us.
+        // The grid is taken at the NOMINAL 24-sample batch on 256 CUs -- the width changes the summation order of the column
+        // statistics, so it must not depend on how many samples share the launch (batch invariance).
+        const long t24 = 24L * (p.H / TP) * (p.W / TP);
+        const long r160 = (t24 * (p.N / 160) + 255) / 256, r128 = (t24 * (p.N / 128) + 255) / 256;
+        return (r128 * 4 < r160 * 5) ? 128 : 160;      // r128 * 0.8 < r160
+    }
+    if (ok160) return 160;
+    if (ok128) return 128;
     return 0;
 }
 
