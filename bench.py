@@ -78,11 +78,12 @@ def self_launch(a):
 
 class ConvTimer:
     """HIP-event timing of every convolution launch inside the timed region, by kernel: `patch3` = conv_patch_kernel<3x3>
-    (the dominant kernel of the step: conv.hip), `patch2` = its 2x2 parity-phase form (four launches per call), `im2col` =
-    gemm.hip's implicit GEMM (stride 2, the 8x8 level, the 9->320 and 320->4 convolutions)."""
+    (the dominant kernel of the step: conv.hip), `patch2` = its 2x2 parity-phase form (four launches per call), `patch8x8` =
+    its 8x8 form (four images per workgroup; the time includes the split-K reduce pass), `im2col` = gemm.hip's implicit GEMM
+    (stride 2, the 9->320 and 320->4 convolutions)."""
 
     def __init__(self):
-        self.cls = {k: {"events": [], "flops": 0.0, "launches": 0} for k in ("patch3", "patch2", "im2col")}
+        self.cls = {k: {"events": [], "flops": 0.0, "launches": 0} for k in ("patch3", "patch2", "patch8x8", "im2col")}
         self.on = False
 
     def _timed(self, key, flops, launches, fn):
@@ -103,8 +104,8 @@ class ConvTimer:
                 return call()
             VH, VW = (2 * H, 2 * W) if upsample else (H, W)
             OH, OW = (VH - 1) // stride + 1, (VW - 1) // stride + 1
-            patch = hip.conv_uses_patch_kernel(H, W, cin, cout, 3, stride, upsample, kw.get("flags", 0)) and not (kw.get("flags", 0) & hip.EPI_OUT_F32)
-            timer._timed("patch3" if patch else "im2col", 2.0 * nimg * OH * OW * cout * 9 * cin, 1, call)
+            patch = 0 if (kw.get("flags", 0) & hip.EPI_OUT_F32) else hip.conv_uses_patch_kernel(H, W, cin, cout, 3, stride, upsample, kw.get("flags", 0))
+            timer._timed({1: "patch3", 2: "patch8x8"}.get(patch, "im2col"), 2.0 * nimg * OH * OW * cout * 9 * cin, 1, call)
         hip.conv3x3 = conv3x3
         orig_up = hip.upsample2x_conv3x3
 
@@ -114,7 +115,7 @@ class ConvTimer:
             call = lambda: orig_up(x, wt, out, nimg=nimg, H=H, W=W, cin=cin, cout=cout, **kw)
             if not timer.on:
                 return call()
-            patch = hip.conv_uses_patch_kernel(H, W, cin, cout, 2, 1, False, kw.get("flags", 0))
+            patch = hip.conv_uses_patch_kernel(H, W, cin, cout, 2, 1, False, kw.get("flags", 0)) == 1
             timer._timed("patch2" if patch else "im2col", 4 * 2.0 * nimg * H * W * cout * 4 * cin, 4, call)
         hip.upsample2x_conv3x3 = upsample2x_conv3x3
         orig_p1 = hip.conv3x3_plus_1x1
@@ -123,8 +124,8 @@ class ConvTimer:
             call = lambda: orig_p1(x, x2, wt, out, nimg=nimg, H=H, W=W, cin=cin, c2=c2, cout=cout, **kw)
             if not timer.on:
                 return call()
-            patch = hip.conv_uses_patch_kernel(H, W, cin, cout, 3, 1, False, kw.get("flags", 0)) and c2 % 64 == 0
-            timer._timed("patch3" if patch else "im2col", 2.0 * nimg * H * W * cout * (9 * cin + c2), 1, call)
+            patch = hip.conv_uses_patch_kernel(H, W, cin, cout, 3, 1, False, kw.get("flags", 0)) if c2 % 64 == 0 else 0
+            timer._timed({1: "patch3", 2: "patch8x8"}.get(patch, "im2col"), 2.0 * nimg * H * W * cout * (9 * cin + c2), 1, call)
         hip.conv3x3_plus_1x1 = conv3x3_plus_1x1
 
     def summary(self):

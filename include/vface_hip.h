@@ -51,6 +51,7 @@ extern "C" {
 #define VFACE_TUNE_PERSISTENT 0x20000    /* persistent form for a plain GEMM too (default: implicit convolutions only) */
 #define VFACE_TUNE_NO_PATCH 0x80000      /* convolutions: never the patch-staged kernel (im2col-style staging, one load per tap) */
 #define VFACE_TUNE_PATCH 0x100000        /* convolutions: the patch-staged kernel wherever the shape allows, however small the grid */
+#define VFACE_TUNE_NO_Q8 0x4000000        /* A/B: 3x3 convolutions on 8x8 images stay on the im2col kernel (default: four images per workgroup through the patch-staged kernel + split-K reduce) */
 #define VFACE_TUNE_PATCH_BN160 0x2000000  /* A/B: the patch-staged kernel's 160-channel tile wherever it divides Cout (default: the width whose one-per-CU grid has the cheaper last round) */
 #define VFACE_TUNE_F32_TRANSPOSE 0x1000000 /* A/B: the epilogue's LDS transpose in fp32 even where nothing reads the fp32 sum (default there: 16 bits) */
 /* (VFACE_TUNE_PATCH on vface_gemm: run a plain GEMM with M % 256 == 0, K % 64 == 0, N % 128|160 == 0, no GEGLU / fp32-only output
@@ -127,8 +128,10 @@ int vface_conv3x3(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, c
 
 /* Which kernel a vface_conv3x3 / vface_conv3x3_plus_1x1 (window = 3) / vface_upsample2x_conv3x3_phase (window = 2) launch of this
  * geometry runs: 1 = the patch-staged kernel (conv.hip: stride 1, H and W multiples of 16, Cin % 64 == 0, Cout % 160 == 0 or
- * % 128 == 0, 16-bit output, and a grid that is deep enough at the nominal 24-sample batch, or VFACE_TUNE_PATCH), 0 = the
- * im2col-style implicit GEMM (gemm.hip).  For measurement harnesses (bench.py prices the two kernels separately). */
+ * % 128 == 0, 16-bit output, and a grid that is deep enough at the nominal 24-sample batch, or VFACE_TUNE_PATCH), 2 = its
+ * 8x8 form (3x3 window on 8 x 8 images, Cout % 128 == 0: four images per workgroup, K split over channel chunks, then the
+ * split-K reduce; taken when the caller passes the workspace vface_splitk_workspace_bytes asks for), 0 = the im2col-style
+ * implicit GEMM (gemm.hip).  For measurement harnesses (bench.py prices the two kernels separately). */
 int vface_conv_uses_patch_kernel(int H, int W, int Cin, int Cout, int window, int stride, int upsample, int flags);
 
 /* Y = conv3x3(X) + X2 W2^T + bias: the second convolution of a ResBlock together with the block's 1x1 shortcut

@@ -870,3 +870,55 @@ def test_epilogue_16_bit_transpose_equals_fp32_transpose_bit_for_bit(dt):
         assert o1.abs().sum() > 0 and torch.equal(o1, o2)
         if c1 is not None:
             assert torch.equal(c1, c2)
+
+
+# ------------------------------------------------------------------------------------------ the 8x8 level through the patch kernel
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,nimg,c2", [(256, 256, 6, 0), (128, 384, 5, 0), (256, 128, 24, 128), (512, 256, 7, 64)])
+def test_conv_8x8_four_images_per_workgroup_form(dt, cin, cout, nimg, c2):
+    """3x3 convolutions on 8 x 8 images: four images share a workgroup of the patch-staged kernel (each with its own zero halo
+    in the 20 x 20 patch), K split over channel chunks, epilogue in the split-K reduce.  Against fp64 on the same 16-bit
+    operands (the fp32 carrier), against the im2col kernel (VFACE_TUNE_NO_Q8; a different fp32 summation order), ragged last
+    tiles (nimg % 4 != 0), row bias, fp32 residual, fused 1x1 shortcut, column statistics; batch invariance bit for bit."""
+    h = hip()
+    from vface_amd.packing import pack_conv3x3
+    H = 8
+    assert h.conv_uses_patch_kernel(H, H, cin, cout, 3, 1, False) == 2
+    x = rnd((nimg, cin, H, H), 1, dt)
+    w = rnd((cout, cin, 3, 3), 3, dt, 1 / math.sqrt(9 * cin))
+    b, rb = rnd((cout,), 5, torch.float32, 0.1), rnd((nimg, cout), 6, torch.float32, 0.1)
+    r32 = rnd((nimg * H * H, cout), 7, torch.float32)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + rb.double()[:, :, None, None]
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    if c2:
+        x2 = rnd((nimg, c2, H, H), 2, dt)
+        w2 = rnd((cout, c2), 4, dt, 1 / math.sqrt(c2))
+        ref = ref + torch.einsum("nchw,oc->nohw", x2.double(), w2.double())
+        wt = torch.cat([pack_conv3x3(w), w2], 1).contiguous().to(DEV)
+        x2d = x2.permute(0, 2, 3, 1).contiguous().to(DEV)
+    else:
+        wt = pack_conv3x3(w).to(DEV)
+    ref = ref.permute(0, 2, 3, 1).reshape(nimg * H * H, cout) + (0 if c2 else r32.double())   # (the fused shortcut IS the residual)
+
+    def run(flags, n=nimg):
+        o16 = torch.zeros(n * H * H, cout, dtype=dt, device=DEV)
+        o32 = torch.zeros(n * H * H, cout, dtype=torch.float32, device=DEV)
+        cs = torch.zeros(n, cout, 2, dtype=torch.float32, device=DEV)
+        kw = dict(nimg=n, H=H, W=H, cin=cin, cout=cout, ldx=cin, ldy=cout, bias=b.to(DEV), rowbias=rb[:n].contiguous().to(DEV),
+                  colstats=cs, flags=flags, out32=o32)
+        if c2:
+            h.conv3x3_plus_1x1(xd[:n].contiguous(), x2d[:n].contiguous(), wt, o16, c2=c2, ldx2=c2, **kw)
+        else:
+            h.conv3x3(xd[:n].contiguous(), wt, o16, residual32=r32[:n * H * H].contiguous().to(DEV), **kw)
+        return o16, o32, cs
+
+    o16, o32, cs = run(0)
+    i16, i32, ics = run(h.TUNE_NO_Q8)
+    assert rel_l2(o32.double().cpu(), ref) < 3e-6 and rel_l2(i32.double().cpu(), ref) < 3e-6
+    assert torch.equal(o16, o32.to(dt))                              # one rounding of the fp32 sum
+    assert rel_l2(o32.cpu(), i32.cpu()) < 1e-6
+    ss = o32.reshape(nimg, 64, cout)
+    assert torch.allclose(cs[..., 0], ss.sum(1), rtol=1e-4, atol=1e-3) and torch.allclose(cs[..., 1], (ss * ss).sum(1), rtol=1e-4, atol=1e-3)
+    # a sample's bits do not depend on which other samples share its launch (here: 3 images alone, a ragged tile)
+    p16, p32, pcs = run(0, n=3)
+    assert torch.equal(p16, o16[:3 * 64]) and torch.equal(p32, o32[:3 * 64]) and torch.equal(pcs, cs[:3])

@@ -37,11 +37,11 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(0)
     rnd = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dt).to(DEV)
     variants = {"auto": 0, "f32t": hip.TUNE_F32_TRANSPOSE, "persist": hip.TUNE_PERSISTENT, "patch256": hip.TUNE_PATCH, "db128": 0x500, "db160": 0x600}
-    cvariants = {"patch": hip.TUNE_PATCH, "patch_bn160": hip.TUNE_PATCH | hip.TUNE_PATCH_BN160, "im2col": hip.TUNE_NO_PATCH}
+    cvariants = {"patch": hip.TUNE_PATCH, "patch_bn160": hip.TUNE_PATCH | hip.TUNE_PATCH_BN160 | hip.TUNE_NO_Q8, "im2col": hip.TUNE_NO_PATCH}
     if "conv" in a.what:
         print("== conv3x3 implicit GEMM (TFLOP/s median | best), variants:", list(cvariants))
         for (H, cin, cout, stride) in [(64, 320, 320, 1), (64, 640, 320, 1), (64, 960, 320, 1), (32, 640, 640, 1),
-                                       (32, 1280, 640, 1), (16, 1280, 1280, 1), (16, 2560, 1280, 1), (8, 1280, 1280, 1),
+                                       (32, 1280, 640, 1), (16, 1280, 1280, 1), (16, 2560, 1280, 1), (8, 1280, 1280, 1), (8, 2560, 1280, 1),
                                        (64, 320, 320, 2)]:
             x = rnd(N * H * H, cin)
             w = pack_conv3x3((torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))).to(dt).to(DEV)

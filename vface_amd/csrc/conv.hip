@@ -42,13 +42,17 @@ constexpr int TP = 16;                 // output tile: TP x TP pixels of one ima
 // RM: the residual form of the epilogue (0 none, 1 16-bit, 2 the fp32 stream) as an instantiation of its own -- three copies of
 // the epilogue inside one kernel cost 19 spilled registers, some reloaded inside the K loop; -1 = chosen at run time (the
 // diagnostic and fused-normalisation builds, which the engine's default path does not launch).
-template <class TT, int NT, int KH, int KW, bool DIAG = false, bool GNT = false, int RM = -1>
+// Q8: the 8 x 8-pixel level.  A workgroup's 16 x 16 "tile" is FOUR images (2 x 2 quadrants of 8 x 8 pixels, each staged with
+// its own one-pixel halo: a 20 x 20-pixel patch), K is split over the workgroups of a tile by channel chunks, and the kernel
+// ends with the raw fp32 partial tile -- bias / residual / rounding / statistics run in gemm.hip's splitk_reduce_kernel.
+template <class TT, int NT, int KH, int KW, bool DIAG = false, bool GNT = false, int RM = -1, bool Q8 = false>
 __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
     constexpr int BN = 32 * NT;                    // 160 | 128
     constexpr int TAPS = KH * KW;
-    constexpr int PW = TP + KW - 1, PH = TP + KH - 1, NPIX = PW * PH;
+    static_assert(!Q8 || (KH == 3 && KW == 3 && NT == 4), "the 8x8 form: 3x3 windows, 128-channel tiles");
+    constexpr int PW = Q8 ? 20 : TP + KW - 1, PH = Q8 ? 20 : TP + KH - 1, NPIX = PW * PH;
     constexpr int NPIECES = (NPIX + 7) / 8;        // 1-KiB LDS-DMA pieces per patch (8 pixels x 128 B each)
     constexpr int PATCH_BYTES = NPIECES * 1024;
     constexpr int PPW = (NPIECES + 7) / 8;         // patch pieces per wave (wave w: pieces w, w + 8, ...)
@@ -88,12 +92,14 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     // ---- tile origin: XCD-aware order as in gemm.hip (contiguous run of the tile sequence per XCD; column groups of
     // 8 n-tiles, m-major inside a group)
     const int tiles_x = p.W / TP, tiles_y = p.H / TP, tiles_img = tiles_x * tiles_y;
-    const int ntm = (p.M / (p.OH * p.OW)) * tiles_img, ntn = p.N / BN;
-    int tm, tn;
+    const int nimg_all = p.M / (p.OH * p.OW);
+    const int ntm = Q8 ? (nimg_all + 3) / 4 : nimg_all * tiles_img, ntn = p.N / BN;
+    int tm, tn, sk = 0;
     {
-        const int nwg = ntm * ntn, id = blockIdx.x;
+        const int nwg = ntm * ntn * (Q8 ? p.split_k : 1), id = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
-        const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        if constexpr (Q8) { sk = L / (ntm * ntn); L -= sk * (ntm * ntn); }
         constexpr int GN = 8;
         const int g = L / (GN * ntm);
         const int rem = L - g * (GN * ntm);
@@ -101,8 +107,9 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         tm = rem / gw;
         tn = g * GN + (rem - tm * gw);
     }
-    const int img = tm / tiles_img, trem = tm - img * tiles_img;
-    const int ty0 = (trem / tiles_x) * TP, tx0 = (trem - (trem / tiles_x) * tiles_x) * TP;
+    // (Q8: `img` = the first of the tile's four images; the tile has no origin inside an image)
+    const int img = Q8 ? tm * 4 : tm / tiles_img, trem = Q8 ? 0 : tm - img * tiles_img;
+    const int ty0 = Q8 ? 0 : (trem / tiles_x) * TP, tx0 = Q8 ? 0 : (trem - (trem / tiles_x) * tiles_x) * TP;
     const int n0 = tn * BN;
 
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
@@ -120,6 +127,13 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     for (int i = 0; i < PPW; ++i) {
         const int pp = (wave + 8 * i) * 8 + (lane >> 3);
         const int py = pp / PW, px = pp - py * PW;
+        if constexpr (Q8) {
+            // quadrant (py / 10, px / 10) = image img + 2 qy + qx, its pixel (py % 10 - 1, px % 10 - 1) or the zero halo
+            const int qy = py / 10, qx = px / 10, iy = py - qy * 10 - 1, ix = px - qx * 10 - 1, im = img + qy * 2 + qx;
+            const bool ok = pp < NPIX && (unsigned)iy < 8u && (unsigned)ix < 8u && im < nimg_all;
+            poff[i] = ok ? (unsigned)(((((long)im * 8 + iy) * 8 + ix) * p.lda + pch * 8) * ES) : OOB;
+            continue;
+        }
         const int iy = ty0 - p.pad + py, ix = tx0 - p.pad_x + px;
         const bool ok = pp < NPIX && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         poff[i] = ok ? (unsigned)(((((long)img * p.H + iy) * p.W + ix) * p.lda + pch * 8) * ES) : OOB;
@@ -129,6 +143,11 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         // the 1x1 source is staged as a 16 x 16 "patch" without halo: pixel index pp = ly * 16 + lx, 32 pieces
         const int pp = (wave + 8 * i) * 8 + (lane >> 3);
         const int ly = pp >> 4, lx = pp & 15;
+        if constexpr (Q8) {
+            const int im = img + (ly >> 3) * 2 + (lx >> 3);
+            poff2[i] = (p.A2 && im < nimg_all) ? (unsigned)(((((long)im * 8 + (ly & 7)) * 8 + (lx & 7)) * p.lda2 + pch * 8) * ES) : OOB;
+            continue;
+        }
         poff2[i] = p.A2 ? (unsigned)(((((long)img * p.H + ty0 + ly) * p.W + tx0 + lx) * p.lda2 + pch * 8) * ES) : OOB;
     }
     // ---- weight staging map: piece r = rows 8r .. 8r+7 of the tile, lane l -> row 8r + (l >> 3), chunk (l & 7) ^ swz(row)
@@ -141,16 +160,20 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         boff[i] = (piece < BPIECES && n0 + row < p.N) ? (unsigned)((((long)(n0 + row)) * p.ldw + ch * 8) * ES) : OOB;
     }
 
-    const int nchunks = p.Cin >> 6;
-    const int T1 = nchunks * TAPS;                        // K tiles of the window
-    const int ntail = (TAIL && p.A2) ? ((p.K - p.K1) >> 6) : 0;     // K tiles of the fused 1x1 source
+    const int nchunks_all = p.Cin >> 6;
+    // Q8: this workgroup's share of K = channel chunks [c_begin, nchunks) (the fused 1x1 source goes with the last share)
+    const int c_begin = Q8 ? (int)(((long)sk * nchunks_all) / p.split_k) : 0;
+    const int nchunks = Q8 ? (int)(((long)(sk + 1) * nchunks_all) / p.split_k) : nchunks_all;
+    const int kt0 = c_begin * TAPS;                       // global index of this workgroup's first K tile (weight columns)
+    const int T1 = (nchunks - c_begin) * TAPS;            // K tiles of the window
+    const int ntail = (TAIL && p.A2 && (!Q8 || sk == p.split_k - 1)) ? ((p.K - p.K1) >> 6) : 0;     // K tiles of the fused 1x1 source
     const int T = T1 + ntail;
 
     // weight tile kt -> ring slot `slot` (every K tile is 64 columns = 128 B of every weight row)
     auto issue_B = [&](int kt, int slot) {
         if (DIAG && (p.flags & 0x200000) && kt >= 2) return;     // ablation: no LDS-DMA inside the K loop
         unsigned char* dst = sB + slot * BSLOT;
-        const unsigned koff = (unsigned)kt * 64u * ES;
+        const unsigned koff = (unsigned)(kt0 + kt) * 64u * ES;
 #pragma unroll
         for (int i = 0; i < NB_HI; ++i) {
             if (i < NB_LO || wave < NB_SPLIT) {
@@ -170,7 +193,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     };
     // piece i of the 1x1-source "patch" of tail tile u (patch buffer (nchunks + u) & 1)
     auto issue_P2 = [&](int u, int i) {
-        const unsigned off = poff2[TAIL ? i : 0] + (unsigned)u * 64u * ES;
+        const unsigned off = poff2[TAIL ? i : 0] != OOB ? poff2[TAIL ? i : 0] + (unsigned)u * 64u * ES : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(sP + ((nchunks + u) & 1) * PATCH_BYTES + (wave + 8 * i) * 1024), 16, off, 0, 0, 0);
     };
 
@@ -219,7 +242,8 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         const int row = wn * (BN / 2) + j * 16 + fr;
         wadr[j] = (unsigned)(row * 128 + ((fq ^ ((row >> 1) & 7)) << 4));
     }
-    const int lane_pp = wm * 4 * PW + fr;     // patch pixel of (pixel row 0 of this wave, tap (0,0))
+    // patch pixel of (pixel row 0 of this wave, tap (0,0)); Q8: rows 8.. and columns 8.. lie in the next quadrant, 2 halo pixels on
+    const int lane_pp = Q8 ? (wm * 4 + (wm >= 2 ? 2 : 0)) * PW + fr + (fr >= 8 ? 2 : 0) : wm * 4 * PW + fr;
 
     // ---- the K-tile pipeline.  A K tile is two k32 halves; per half a wave reads 4 + NT fragments (ds_read_b128) and issues
     // 4 x NT MFMAs.  Every wave software-pipelines at HALF-tile granularity across the barrier:
@@ -289,10 +313,10 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     };
 
     // ---- prologue: patch of chunk 0 (all pieces), weight tiles 0 and 1
-    if (nchunks > 0) {
+    if (nchunks > c_begin) {
 #pragma unroll
-        for (int i = 0; i < PPW; ++i) issue_P(0, i);
-        issue_T(0);
+        for (int i = 0; i < PPW; ++i) issue_P(c_begin, i);
+        issue_T(c_begin);
     } else if constexpr (TAIL) {
         // plain GEMM (vf_launch_gemm_patch): no window at all, every K tile is a tile of the halo-free "1x1 source"
         if (ntail > 0) {
@@ -307,17 +331,17 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     // compile-time; per K tile the scalar side only counts)
     const unsigned long long d_t1 = stamp();
     int kt = 0;
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = c_begin; c < nchunks; ++c) {
         const unsigned pbase = (unsigned)(NSLOT * BSLOT + (c & 1) * PATCH_BYTES);
         const bool next_window = c + 1 < nchunks;
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             period_sync(kt + 1 < T);
             if (GNF && gn) {
-                if (tap == 0 && c == 0) {
+                if (tap == 0 && c == c_begin) {
                     // the first chunk's patch: every wave normalises the pieces it issued, then one extra barrier
 #pragma unroll
-                    for (int i = 0; i < PPW; ++i) transform_P(0, i);
+                    for (int i = 0; i < PPW; ++i) transform_P(c_begin, i);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
@@ -357,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         period_sync(kt + 1 < T);
         const unsigned wb = (unsigned)((kt % NSLOT) * BSLOT);
         // lane_pp is in units of the window patch's pitch: rebase to the halo-free 16-pixel pitch
-        read_h0((unsigned)(NSLOT * BSLOT + ((nchunks + u) & 1) * PATCH_BYTES), wm * 4 * TP - wm * 4 * PW, TP, wb);
+        read_h0((unsigned)(NSLOT * BSLOT + ((nchunks + u) & 1) * PATCH_BYTES), wm * 4 * TP + fr - lane_pp, TP, wb);
         __builtin_amdgcn_sched_barrier(0);
         if (late && kt > 0) { mfma_Y(); __builtin_amdgcn_sched_barrier(0); }
         if (u + 1 < ntail) {
@@ -376,6 +400,22 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     mfma_Y();      // the last half tile
     const unsigned long long d_t2 = stamp();
 
+    if constexpr (Q8) {
+        // raw fp32 partial tile of this K share: lane (fr, fq) holds channels fq*4 .. +3 of pixel (row wm*4 + i, column fr)
+        float* part = p.workspace + (long)sk * p.M * p.N;
+        const int im = img + (wm >= 2 ? 2 : 0) + (fr >> 3);
+        if (im < nimg_all) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long m = (long)im * 64 + ((wm * 4 + i) & 7) * 8 + (fr & 7);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    *reinterpret_cast<float4*>(part + m * p.N + n0 + wn * (BN / 2) + j * 16 + fq * 4) =
+                        make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+            }
+        }
+        return;
+    }
     // ---- wide epilogue (see gemm.hip): per pixel row i, transpose the wave's 16 x WN accumulator rows through LDS in
     // fp32, sum bias / row bias / residual, round once, 16 B per lane
     __syncthreads();
@@ -610,6 +650,49 @@ int launch_patch_dtype(const GemmParams& p, int bn, hipStream_t stream) {
     return VF_ERR_SHAPE;
 }
 
+template <class TT>
+int launch_q8(const GemmParams& p, hipStream_t stream) {
+    constexpr int NT = 4, BN = 128, NPIECES = 50;
+    const size_t lds = 2 * (size_t)NPIECES * 1024 + 3 * (size_t)BN * 128 + 2048;
+    auto kern = conv_patch_kernel<TT, NT, 3, 3, false, false, 0, true>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return VF_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int nimg = p.M / 64, ntm = (nimg + 3) / 4, ntn = p.N / BN;
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn * p.split_k), dim3(512), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
+}
+
+}  // namespace
+
+// The 8 x 8 level through the patch-staged kernel (Q8 form): 0 = not such a launch, else the K split (number of fp32 partial
+// tiles per output tile).  Four images per workgroup and N / 128 channel tiles give (nimg / 4) * (N / 128) workgroups -- 60 at
+// the nominal 24-sample batch of the UNet's 1280-channel level -- so K is split over channel chunks until the one-per-CU grid
+// is about one round; the split follows the NOMINAL batch (the fp32 summation order must not depend on the launch's batch).
+int vf_conv_q8_split(const GemmParams& p) {
+    if (p.mode != 1 || p.stride != 1 || p.upsample || p.out_phase || (p.Cin & 63) || p.gn_ab) return 0;
+    if (p.H != 8 || p.W != 8 || p.OH != 8 || p.OW != 8 || p.KH != 3 || p.KW != 3 || p.ntaps != 9 || p.pad != 1 || p.pad_x != 1) return 0;
+    if ((p.flags & (GEMM_GEGLU | GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE | GEMM_NO_PATCH | 0x4000 | (0xF << 8))) || (p.N % 128)) return 0;
+    if (p.A2 && ((p.K - p.K1) & 63)) return 0;
+    if (p.rows_per_sample != 64 && p.rowbias) return 0;
+    const int nchunks = p.Cin >> 6;
+    const long tiles24 = 6L * (p.N / 128);
+    int s = (int)(256 / tiles24);
+    if (s > 8) s = 8;
+    if (s > nchunks / 2) s = nchunks / 2;       // at least two chunks (18 K tiles) per share
+    return s < 1 ? 0 : s;
+}
+
+int vf_launch_conv_q8(const GemmParams& p, int dtype, hipStream_t stream) {
+    if (dtype == VF_DTYPE_F16) return launch_q8<F16>(p, stream);
+    if (dtype == VF_DTYPE_BF16) return launch_q8<BF16>(p, stream);
+    return VF_ERR_DTYPE;
+}
+
+namespace {
 }  // namespace
 
 // 0 = this launch is not a patch-kernel shape; else the channel-tile width (160 | 128) the launch would use

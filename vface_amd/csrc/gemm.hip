@@ -1002,8 +1002,17 @@ bool vf_gemm_variants_built() {
 }
 
 long vf_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_sample) {
-    const int s = split_for(M, N, K, flags, rows_per_sample);
-    return s > 1 ? (long)s * M * N * 4 : 0;
+    int s = split_for(M, N, K, flags, rows_per_sample);
+    if (s < 2) s = 0;
+    if (rows_per_sample == 64 && (N % 128) == 0 && !(flags & (GEMM_GEGLU | GEMM_OUT_F32))) {
+        // a 3x3 convolution on 8x8 images may take the Q8 form (conv.hip: vf_conv_q8_split), which always ends in fp32 partials:
+        // room for the largest split that rule can choose for this N
+        int s8 = (int)(256 / (6L * (N / 128)));
+        if (s8 > 8) s8 = 8;
+        if (s8 < 1) s8 = 1;
+        if (s8 > s) s = s8;
+    }
+    return (long)s * M * N * 4;
 }
 
 int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
@@ -1064,6 +1073,20 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         if (bn) {
             const long tiles24 = 24L * (p.H / 16) * (p.W / 16) * (p.N / bn);   // (the same rule: capi.cpp vface_conv_uses_patch_kernel)
             if (tiles24 >= 160 || (p.flags & GEMM_PATCH)) return vf_launch_conv_patch(p, dtype, stream);
+        }
+    }
+    if (p.mode == 1 && p.workspace && !(p.flags & GEMM_NO_Q8)) {
+        // the 8x8 level: four images per workgroup through the patch-staged kernel, K split over channel chunks, then the
+        // ordinary split-K reduce (which runs the whole epilogue)
+        const int s = vf_conv_q8_split(p);
+        if (s && p.workspace_bytes >= (long)s * p.M * p.N * 4 && !((uintptr_t)p.workspace & 15) && (p.M % 64) == 0 &&
+            !(p.residual && (((uintptr_t)p.residual & 15) || (p.ldr & 7))) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) {
+            p.split_k = s;
+            const int rc = vf_launch_conv_q8(p, dtype, stream);
+            if (rc != VF_OK) return rc;
+            if (dtype == VF_DTYPE_F16) hipLaunchKernelGGL(splitk_reduce_kernel<F16>, dim3((p.M + 63) / 64, (p.N + 255) / 256), dim3(256), 0, stream, p);
+            else hipLaunchKernelGGL(splitk_reduce_kernel<BF16>, dim3((p.M + 63) / 64, (p.N + 255) / 256), dim3(256), 0, stream, p);
+            return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
         }
     }
     if (p.mode == 0 && (p.flags & GEMM_PATCH) && !((p.flags >> 8) & 0xF) && vf_gemm_patch_tile(p)) return vf_launch_gemm_patch(p, dtype, stream);

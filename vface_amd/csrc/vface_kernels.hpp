@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 enum { GEMM_GEGLU = 1, GEMM_OUT_F32 = 2, GEMM_NO_XCD_REMAP = 0x1000, GEMM_NO_SETPRIO = 0x2000, GEMM_NARROW_EPILOGUE = 0x8000, GEMM_NO_PERSIST = 0x10000, GEMM_PERSIST = 0x20000,
-       GEMM_NO_PATCH = 0x80000, GEMM_PATCH = 0x100000, GEMM_PATCH_BN160 = 0x2000000 /* A/B: the patch kernel's 160-wide tile wherever it divides N */, GEMM_F32_TRANSPOSE = 0x1000000 /* A/B: epilogue transposes in fp32 even where 16 bits would do */ };  // (0x40000 = VFACE_CONV_PAD_TRAILING)  // bits 8..11 of flags: forced schedule variant (0 = automatic)
+       GEMM_NO_PATCH = 0x80000, GEMM_PATCH = 0x100000, GEMM_NO_Q8 = 0x4000000 /* A/B: the 8x8 level stays on the im2col kernel */, GEMM_PATCH_BN160 = 0x2000000 /* A/B: the patch kernel's 160-wide tile wherever it divides N */, GEMM_F32_TRANSPOSE = 0x1000000 /* A/B: epilogue transposes in fp32 even where 16 bits would do */ };  // (0x40000 = VFACE_CONV_PAD_TRAILING)  // bits 8..11 of flags: forced schedule variant (0 = automatic)
 
 struct GemmParams {
     int mode;  // 0: plain A[M][K]; 1: implicit 3x3 conv over NHWC
@@ -61,6 +61,8 @@ int vf_conv_patch_tile(const GemmParams& p);
 int vf_launch_conv_patch(const GemmParams& p, int dtype, hipStream_t stream);
 int vf_gemm_patch_tile(const GemmParams& p);                                   // plain GEMM through the patch kernel's 256-row tile: 0 | 160 | 128
 int vf_launch_gemm_patch(const GemmParams& p, int dtype, hipStream_t stream);
+int vf_conv_q8_split(const GemmParams& p);                                      // the 8x8 level through the patch kernel: 0 | K split
+int vf_launch_conv_q8(const GemmParams& p, int dtype, hipStream_t stream);     // (main pass only: the caller runs the split-K reduce)
 bool vf_attention_shared_scores_supported(int dh, int v_sets);
 int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream);
 int vf_launch_gemm_pp(const GemmParams& p, int dtype, int variant, hipStream_t stream);

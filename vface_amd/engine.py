@@ -508,7 +508,7 @@ class UNetEngine:
         if self.fuse_gn == "off" or (which == "in" and self.fuse_gn != "both"):
             return False
         return x.cs is not None and x.t is not None and x.C == w["cinp"] and \
-            hip.conv_uses_patch_kernel(x.H, x.W, w["cinp"], w["cout"], 3, 1, False)
+            hip.conv_uses_patch_kernel(x.H, x.W, w["cinp"], w["cout"], 3, 1, False) == 1
 
     def _res(self, x: Act, p: dict, emb_all: torch.Tensor, out) -> Act:
         """ResBlock._forward (openaimodel.py:255-275), non-updown, no scale-shift."""

@@ -21,6 +21,7 @@ F16, BF16 = 0, 1
 EPI_GEGLU, EPI_OUT_F32 = 1, 2
 CONV_PAD_TRAILING = 0x40000  # conv3x3: zero padding (0,1,0,1) (the VAE encoder's Downsample)
 TUNE_NO_PATCH, TUNE_PATCH = 0x80000, 0x100000  # conv3x3*: never / always (where the shape allows) the patch-staged kernel
+TUNE_NO_Q8 = 0x4000000  # A/B: the 8x8 level stays on the im2col kernel
 TUNE_PATCH_BN160 = 0x2000000  # A/B: patch kernel's 160-wide tile wherever it divides Cout
 TUNE_F32_TRANSPOSE = 0x1000000  # A/B: epilogue transposes through LDS in fp32 even where 16 bits would do
 TUNE_NO_PERSISTENT, TUNE_PERSISTENT = 0x10000, 0x20000  # flags of gemm / conv3x3: force one workgroup per tile / the persistent form
@@ -216,9 +217,10 @@ def conv3x3(x: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, nimg: int, 
 
 
 def conv_uses_patch_kernel(H: int, W: int, cin: int, cout: int, window: int = 3, stride: int = 1, upsample: bool = False,
-                           flags: int = 0) -> bool:
-    """True if a convolution launch of this geometry runs conv.hip's patch-staged kernel (else gemm.hip's implicit GEMM)."""
-    return bool(load().vface_conv_uses_patch_kernel(H, W, cin, cout, window, stride, int(upsample), flags))
+                           flags: int = 0) -> int:
+    """Which kernel a convolution launch of this geometry runs: 1 = conv.hip's patch-staged kernel, 2 = its 8x8 form (four
+    images per workgroup + split-K reduce), 0 = gemm.hip's implicit GEMM."""
+    return int(load().vface_conv_uses_patch_kernel(H, W, cin, cout, window, stride, int(upsample), flags))
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, B: int, heads: int, n: int,
