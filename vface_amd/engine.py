@@ -853,7 +853,9 @@ class UNetEngine:
             self._graphs.pop(next(iter(self._graphs)))
         g = {"graph": graph, "x": xs, "t": ts, "eps": eps, "a2": a2, "ctx_id": (id(context), context._version),
              "ctx_keep": context, "flows": own_flows, "flow_ids": {id(d): (id(s_), s_._version) for d, s_ in zip(own_flows, flows)},
-             "flow_keep": {id(d): s_ for d, s_ in zip(own_flows, flows)}, "packed": self._packed}
+             "flow_keep": {id(d): s_ for d, s_ in zip(own_flows, flows)}, "packed": self._packed,
+             # the split-K workspace the captured launches write to (hip.py grows it by REPLACING the tensor: keep this one alive)
+             "splitk_ws": dict(hip._splitk_ws), "zeros": dict(hip._zeros)}
         self._graphs[key] = g
         return g
 
