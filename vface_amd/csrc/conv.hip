@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
         int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
         if constexpr (Q8) { sk = L / (ntm * ntn); L -= sk * (ntm * ntn); }
-        constexpr int GN = 8;
+        const int GN = p.tile_group > 0 ? p.tile_group : 8;
         const int g = L / (GN * ntm);
         const int rem = L - g * (GN * ntm);
         const int gw = min(GN, ntn - g * GN);
@@ -639,7 +639,19 @@ int launch_patch(const GemmParams& p, hipStream_t stream) {
         attr_set[which] = true;
     }
     const int ntm = (p.M / (p.OH * p.OW)) * (p.H / TP) * (p.W / TP), ntn = p.N / BN;
-    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(512), lds, stream, p);
+    // Column-group width of the tile order.  An XCD (own L2) works through tiles_xcd = ntm * ntn / 8 consecutive tiles = a block
+    // of (tiles_xcd / GN) m-tiles x GN n-tiles, and fetches that block's patches and weight panels once: bytes per XCD =
+    // tiles_xcd / GN * A_mt + GN * W_nt, least at GN = sqrt(tiles_xcd * A_mt / W_nt).  On the 16x16 level (weight panels of 3 MB
+    // against 0.65 MB patches) the old fixed GN = 8 made every XCD fetch 80 % of the weights: 256 MB per launch measured.
+    GemmParams q = p;
+    {
+        const double a_mt = (double)(TP + KW - 1) * (TP + KH - 1) * (p.Cin + (p.A2 ? (p.K - p.K1) : 0)) * 2.0;
+        const double w_nt = (double)BN * p.K * 2.0;
+        const double tiles_xcd = (double)ntm * ntn / 8.0;
+        int gn = (int)(__builtin_sqrt(tiles_xcd * a_mt / w_nt) + 0.5);
+        q.tile_group = gn < 1 ? 1 : (gn > ntn ? ntn : gn);
+    }
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(512), lds, stream, q);
     return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
 }
 

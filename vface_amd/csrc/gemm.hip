@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
         // implicit-conv K tiles already re-use their activation lines inside one workgroup (chunk-major K), and measured
         // faster in plain launch order; plain GEMMs keep the XCD grouping
         if ((p.flags & GEMM_NO_XCD_REMAP) || MODE != MODE_PLAIN) L = id;
-        constexpr int GN = 8;
+        const int GN = p.tile_group > 0 ? p.tile_group : 8;
         const int g = L / (GN * ntm);
         const int rem = L - g * (GN * ntm);
         const int gw = min(GN, ntn - g * GN);
@@ -926,7 +926,20 @@ int launch_one(const GemmParams& p, hipStream_t stream) {
         attr_set[which] = true;
     }
     dim3 grid(persist ? persistent_grid() : ntiles * p.split_k);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    GemmParams q = p;
+    if (MODE == MODE_PLAIN && p.split_k == 1 && !p.tile_group) {
+        // column-group width of the XCD-aware tile order (see conv.hip launch_patch): an XCD's share of the grid is a block of
+        // (tiles_xcd / GN) m-tiles x GN n-tiles; bytes through its L2 are least at GN = sqrt(tiles_xcd * A_mt / W_nt), as long as
+        // the GN weight panels (re-used over many rounds here) stay resident: at most half of the 4 MiB L2
+        const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+        const double a_mt = (double)BM * p.K * 2.0, w_nt = (double)BN * p.K * 2.0;
+        int gn = (int)(__builtin_sqrt((double)ntm * ntn / 8.0 * a_mt / w_nt) + 0.5);
+        const int cap = (int)(2097152.0 / w_nt);
+        if (gn > cap) gn = cap;
+        q.tile_group = gn < 1 ? 1 : (gn > ntn ? ntn : gn);
+        if (p.flags & GEMM_GN8) q.tile_group = 8;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, q);
     if (p.split_k > 1)
         hipLaunchKernelGGL(splitk_reduce_kernel<TT>, dim3((p.M + 63) / 64, (p.N + 255) / 256), dim3(256), 0, stream, p);
     return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
