@@ -51,6 +51,7 @@ extern "C" {
 #define VFACE_TUNE_PERSISTENT 0x20000    /* persistent form for a plain GEMM too (default: implicit convolutions only) */
 #define VFACE_TUNE_NO_PATCH 0x80000      /* convolutions: never the patch-staged kernel (im2col-style staging, one load per tap) */
 #define VFACE_TUNE_PATCH 0x100000        /* convolutions: the patch-staged kernel wherever the shape allows, however small the grid */
+#define VFACE_TUNE_GN8 0x8000000          /* A/B: fixed column groups of 8 n-tiles in the plain GEMM's XCD-aware tile order (default: per-launch width) */
 #define VFACE_TUNE_NO_Q8 0x4000000        /* A/B: 3x3 convolutions on 8x8 images stay on the im2col kernel (default: four images per workgroup through the patch-staged kernel + split-K reduce) */
 #define VFACE_TUNE_PATCH_BN160 0x2000000  /* A/B: the patch-staged kernel's 160-channel tile wherever it divides Cout (default: the width whose one-per-CU grid has the cheaper last round) */
 #define VFACE_TUNE_F32_TRANSPOSE 0x1000000 /* A/B: the epilogue's LDS transpose in fp32 even where nothing reads the fp32 sum (default there: 16 bits) */

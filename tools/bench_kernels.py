@@ -36,7 +36,7 @@ def main():
     dt = torch.float16
     g = torch.Generator(device="cpu").manual_seed(0)
     rnd = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(dt).to(DEV)
-    variants = {"auto": 0, "gn8": 0x8000000, "persist": hip.TUNE_PERSISTENT, "db128": 0x500, "db160": 0x600}
+    variants = {"auto": 0, "gn8": hip.TUNE_GN8, "persist": hip.TUNE_PERSISTENT, "db128": 0x500, "db160": 0x600}
     cvariants = {"patch": hip.TUNE_PATCH, "patch_bn160": hip.TUNE_PATCH | hip.TUNE_PATCH_BN160 | hip.TUNE_NO_Q8, "im2col": hip.TUNE_NO_PATCH}
     if "conv" in a.what:
         print("== conv3x3 implicit GEMM (TFLOP/s median | best), variants:", list(cvariants))

@@ -21,6 +21,7 @@ F16, BF16 = 0, 1
 EPI_GEGLU, EPI_OUT_F32 = 1, 2
 CONV_PAD_TRAILING = 0x40000  # conv3x3: zero padding (0,1,0,1) (the VAE encoder's Downsample)
 TUNE_NO_PATCH, TUNE_PATCH = 0x80000, 0x100000  # conv3x3*: never / always (where the shape allows) the patch-staged kernel
+TUNE_GN8 = 0x8000000  # A/B: fixed 8-wide column groups in the plain GEMM's tile order
 TUNE_NO_Q8 = 0x4000000  # A/B: the 8x8 level stays on the im2col kernel
 TUNE_PATCH_BN160 = 0x2000000  # A/B: patch kernel's 160-wide tile wherever it divides Cout
 TUNE_F32_TRANSPOSE = 0x1000000  # A/B: epilogue transposes through LDS in fp32 even where 16 bits would do
