@@ -837,7 +837,8 @@ class UNetEngine:
                 self.forward_nhwc(Act(xs, x.N, x.H, x.W), ts, context)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # (thread_local: a collective backend's watchdog thread may poll events while this thread captures)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 eps = self.forward_nhwc(Act(xs, x.N, x.H, x.W), ts, context)
         except Exception as e:  # capture is an optimisation of the same launch sequence: the eager path is the same code
             import warnings
