@@ -480,3 +480,31 @@ def test_hipgraph_replay_equals_kernel_by_kernel_launches(small):
     finally:
         sampler.hook_plan, eng.use_graph, eng._graphs = old_plan, old_flag, {}
         sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
+
+
+def test_config1_single_frame_256x256_twenty_steps_vs_oracle(small):
+    """BASELINE configs[0] (the reference's own CPU-runnable case): ONE 256 x 256 frame (32 x 32 latent), the whole 20-step DDIM
+    loop with the shipped hook schedule -- a clip of one frame has no flow field and no neighbour, every hook degenerates to
+    its chunk-0 form -- against the CPU oracle running the same 20 steps."""
+    ldm, sampler, sd = small
+    F_, h, w, S = 1, 32, 32, 20
+    x_T = synth.synth_normal("cfg1.xT", (F_, 4, h, w))
+    c, uc, tc = (synth.synth_normal(f"cfg1.{k}", (F_, 1, 768)) for k in ("c", "uc", "tc"))
+    inp = synth.synth_normal("cfg1.inpaint", (F_, 4, h, w)) * 0.18215
+    mask = synth.synth_mask(F_, h, w)
+    inv = {int(s): synth.synth_normal(f"cfg1.inv.{int(s)}", (F_, 4, h, w)) for s in oddim.ddim_timesteps(S)}
+    d = lambda v: v.to(DEV)
+    try:
+        img, inter = sampler.sample(S=S, batch_size=F_, shape=[4, h, w], conditioning=d(c), target_conditioning=d(tc),
+                                    inverse_results_dir={k: d(v) for k, v in inv.items()}, verbose=False,
+                                    unconditional_guidance_scale=3.0, unconditional_conditioning=d(uc), eta=0.0,
+                                    x_T=d(x_T), flow=[], test_model_kwargs={"inpaint_image": d(inp), "inpaint_mask": d(mask)},
+                                    log_every_t=1000)
+    finally:
+        sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
+    names = ounet.attn1_names(SMALL)
+    ref, _ = oddim.sample(lambda x, t, cc, reg: ounet.unet_forward(sd, SMALL, x, t, cc, reg), names, S, x_T, c, uc, tc, inv, inp, mask,
+                          scale=3.0, eta=0.0, flow=[])
+    err = rel_l2(img.cpu(), ref)
+    print(f"config 1, 20 DDIM steps: rel-L2 {err:.3e}")
+    assert torch.isfinite(img).all() and err < 2e-3
