@@ -232,17 +232,40 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
             a[j] = st[2 * g + 1] * gamma[c];
             b[j] = beta[c] - st[2 * g] * a[j];
         }
-        for (int p = p0 + lanep; p < p1; p += PP) {
-            float v[8];
-            load8<TT, IN32>(x, xb + (long)p * ldx + ch * 8, v);
-            V8 o;
+        // four pixels per trip, their loads issued together: on the small maps (8x8, 16x16 images) a thread's pixel loop was a
+        // chain of dependent load -> store round trips (17-22 us per launch for ~10 MB)
+        if (pix_per_block > 32) {      // large maps: enough workgroups in flight to hide a single load per trip
+            for (int p = p0 + lanep; p < p1; p += PP) {
+                float v[8];
+                load8<TT, IN32>(x, xb + (long)p * ldx + ch * 8, v);
+                V8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                float f = v[j] * a[j] + b[j];
-                if (silu) f = silu_f(f);
-                o[j] = from_f32<E>(f);
+                for (int j = 0; j < 8; ++j) {
+                    float f = v[j] * a[j] + b[j];
+                    if (silu) f = silu_f(f);
+                    o[j] = from_f32<E>(f);
+                }
+                *reinterpret_cast<V8*>(yb + (long)p * ldy + ch * 8) = o;
             }
-            *reinterpret_cast<V8*>(yb + (long)p * ldy + ch * 8) = o;
+            continue;
+        }
+        for (int p = p0 + lanep; p < p1; p += 4 * PP) {
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (p + u * PP < p1) load8<TT, IN32>(x, xb + (long)(p + u * PP) * ldx + ch * 8, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p + u * PP >= p1) break;
+                V8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float f = v[u][j] * a[j] + b[j];
+                    if (silu) f = silu_f(f);
+                    o[j] = from_f32<E>(f);
+                }
+                *reinterpret_cast<V8*>(yb + (long)(p + u * PP) * ldy + ch * 8) = o;
+            }
         }
     }
 }
@@ -780,7 +803,7 @@ int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float*
     // enough workgroups to fill 256 CUs several times over, but long enough pixel loops to amortise the
     // per-thread scale/shift set-up
     int ppb = 128;
-    while (ppb > 16 && (long)nimg * ((hw + ppb - 1) / ppb) < 1024) ppb >>= 1;
+    while (ppb > 4 && (long)nimg * ((hw + ppb - 1) / ppb) < 1024) ppb >>= 1;
     dim3 grid((hw + ppb - 1) / ppb, nimg);
     DISPATCH_DTYPE(dtype, {
         using E = typename TT::elem;
