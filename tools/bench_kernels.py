@@ -85,6 +85,29 @@ def main():
                     v = sorted(res[name])
                     row += f"{name} {fl / v[1] / 1e9:6.0f}|{fl / v[0] / 1e9:6.0f} ({v[1] * 1e3:.0f} us)  "
             print(row, flush=True)
+    if "stream" in a.what:
+        print("== plain GEMM with the fp32 residual stream (residual32 in, out32 and / or 16-bit out)")
+        for (M, Nn, K, name0, want16, want32) in [(N * 4096, 320, 320, "out-proj L0", False, True), (N * 4096, 320, 1280, "ff2 L0", True, False),
+                                                  (N * 4096, 320, 320, "proj_out L0", True, True), (N * 1024, 640, 640, "out-proj L1", False, True),
+                                                  (N * 1024, 640, 2560, "ff2 L1", True, False), (N * 256, 1280, 1280, "out-proj L2", False, True)]:
+            x, w = rnd(M, K), rnd(Nn, K)
+            r32 = torch.randn(M, Nn, device=DEV)
+            o16 = torch.empty(M, Nn, dtype=dt, device=DEV) if want16 else None
+            o32 = torch.empty(M, Nn, device=DEV) if want32 else None
+            bias = torch.zeros(Nn, device=DEV)
+            fl = 2.0 * M * Nn * K
+            byt = M * K * 2 + M * Nn * (4 + (2 if want16 else 0) + (4 if want32 else 0))
+            row = f"{name0:12s} M{M:6d} N{Nn:5d} K{K:5d}: "
+            vs = {"auto": 0}
+            res = {n: [] for n in vs}
+            for rnd_ in range(4):
+                for name, f in vs.items():
+                    med, best = timeit(lambda: hip.gemm(x, w, o16, M=M, N=Nn, K=K, lda=K, ldc=Nn, bias=bias, flags=f, residual32=r32, out32=o32), iters=6, warm=2)
+                    res[name].append(med)
+            for name in vs:
+                v = sorted(res[name])
+                row += f"{name} {v[1] * 1e3:6.1f} us ({byt / v[1] / 1e9:5.2f} TB/s, {fl / v[1] / 1e9:4.0f} TF)  "
+            print(row, flush=True)
     if "attn" in a.what:
         print("== attention")
         for (n, dh) in [(4096, 40), (1024, 80), (256, 160), (64, 160)]:
