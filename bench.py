@@ -12,10 +12,17 @@ Inputs are resident in HBM when the timed region starts.  With --gpus N every ra
 workload on its own frames (weak scaling); `--fusion flow_fix` adds the FSAI + flow path, whose one-neighbour
 boundary exchange runs over RCCL.
 
+With --gpus N > 1 the defaults change to what north_star asks the multi-GPU run to measure: the shipped hook
+schedule (`--fusion flow_fix`) at BASELINE config 4's per-GPU share (16 frames per GPU), so the one-neighbour halo
+exchange over RCCL is inside the timed region, and the line carries `exchange: {mode, bytes_per_step,
+wait_ms_per_step}`.
+
 Also reported on the same JSON line:
-  roofline     -- the dominant kernel (implicit-GEMM 3x3 conv): algorithmic FLOPs per launch / mean launch
-                  duration, timed with HIP events on the launch stream inside the timed region, against the
-                  dense 16-bit MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md).
+  roofline     -- the kernel family with the largest share of the step (by HIP events on the launch stream around
+                  every launch, recorded in an instrumented kernel-by-kernel pass of the same W + K steps right after
+                  the timed region): FLOPs per launch / mean launch duration against the dense 16-bit MFMA peak
+                  (2.5 PFLOP/s, MI355X_MICROARCH.md), with `by_family` = {gemm, conv, attention, norm} so that the
+                  whole-UNet figure can be recomputed from its parts.
   cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference, pinned to reference-generated
                   golden vectors) timed on this box's host cores on a bounded sample: F=1 (batch 3) UNet
                   forwards at 64x64 with the same hook mode, extrapolated to 50 steps per frame.
@@ -39,14 +46,17 @@ def log(msg):
         print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=8, help="frames per GPU")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (default: 8 at --gpus 1 = BASELINE configs[1]; "
+                                                              "16 at --gpus N > 1 = config 4's per-GPU share)")
     ap.add_argument("--res", type=int, default=512)
-    ap.add_argument("--fusion", default="replace", help="replace | fft | flow_fix | none")
+    ap.add_argument("--fusion", default=None, help="replace | fft | flow_fix | none (default: replace at --gpus 1; flow_fix -- the "
+                                                   "shipped schedule, ddim_w_inv.py:303-305, with its halo exchange -- at --gpus N > 1)")
+    ap.add_argument("--exchange", default="p2p", choices=["p2p", "allgather"], help="halo exchange form at --gpus N > 1")
     ap.add_argument("--inv-steps", type=int, default=3, help="DDIM-inversion steps timed after the run (0 = skip)")
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"])
     ap.add_argument("--ddim-steps", type=int, default=50)
@@ -58,7 +68,19 @@ def parse():
     ap.add_argument("--eager", action="store_true",
                     help="timed region launches kernel by kernel (default: the UNet forward of a step replayed from a hipGraph, "
                          "falling back to kernel-by-kernel launches by itself where a graph cannot be captured)")
-    return ap.parse_args()
+    return resolve_defaults(ap.parse_args(argv))
+
+
+def resolve_defaults(a):
+    """Workload defaults by GPU count.  One GPU: BASELINE configs[1] -- 8 frames, structure injection
+    ("replace").  N > 1: the shipped schedule, "flow_fix" (REFace/ldm/models/diffusion/ddim_w_inv.py:303-305), 16 frames per
+    GPU (config 4's share) -- the only workload whose data path has an exchange step (temporal_flow.py:222-237: frame i+1 reads
+    frame i), so a scaling curve from it measures the RCCL halo exchange north_star names."""
+    if a.fusion is None:
+        a.fusion = "replace" if a.gpus == 1 else "flow_fix"
+    if a.frames is None:
+        a.frames = 8 if a.gpus == 1 else 16
+    return a
 
 
 def self_launch(a):
@@ -79,23 +101,31 @@ def self_launch(a):
     return subprocess.call(cmd, env=env)
 
 
-class ConvTimer:
-    """HIP-event timing of every convolution launch inside the timed region, by kernel: `patch3` = conv_patch_kernel<3x3>
-    (the dominant kernel of the step: conv.hip), `patch2` = its 2x2 parity-phase form (four launches per call), `patch8x8` =
-    its 8x8 form (four images per workgroup; the time includes the split-K reduce pass), `im2col` = gemm.hip's implicit GEMM
-    (stride 2, the 9->320 and 320->4 convolutions)."""
+class FamilyTimer:
+    """HIP-event timing (on the launch stream) of every launch of the instrumented pass, by kernel family:
+      conv       by kernel: `patch3` = conv_patch_kernel<3x3> (conv.hip), `patch2` = its 2x2 parity-phase form (four launches
+                 per call), `patch8x8` = its 8x8 form (four images per workgroup; the time includes the split-K reduce pass),
+                 `im2col` = gemm.hip's implicit GEMM (stride 2, the 9->320 and 320->4 convolutions);
+      gemm       gemm_kernel<T, MODE_PLAIN, ..>: every Linear / 1x1 conv (sub-classes: `ff1` = the GEGLU projection, `n320` = the
+                 level-0 projections with N = 320, `other`); FLOPs = 2 M N K as executed (incl. the folded FSAI K = 2d);
+      attention  attn_kernel<T, DH, ..> by head dim; FLOPs = the ALGORITHMIC 4 n nk dh per (output sample, head) --
+                 the shared-score form executes fewer;
+      norm       layernorm / groupnorm apply+finalize: HBM-bound, reported in GB/s of algorithmic bytes."""
 
     def __init__(self):
-        self.cls = {k: {"events": [], "flops": 0.0, "launches": 0} for k in ("patch3", "patch2", "patch8x8", "im2col")}
+        self.cls = {}
         self.on = False
 
-    def _timed(self, key, flops, launches, fn):
+    def _timed(self, fam, key, flops, launches, fn, nbytes=0.0):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        c = self.cls[key]
-        c["events"].append((e0, e1)); c["flops"] += flops; c["launches"] += launches
+        c = self.cls.setdefault((fam, key), {"events": [], "flops": 0.0, "launches": 0, "bytes": 0.0})
+        c["events"].append((e0, e1)); c["flops"] += flops; c["launches"] += launches; c["bytes"] += nbytes
+
+    def reset(self):
+        self.cls = {}
 
     def wrap(self, hip):
         timer = self
@@ -108,7 +138,7 @@ class ConvTimer:
             VH, VW = (2 * H, 2 * W) if upsample else (H, W)
             OH, OW = (VH - 1) // stride + 1, (VW - 1) // stride + 1
             patch = 0 if (kw.get("flags", 0) & hip.EPI_OUT_F32) else hip.conv_uses_patch_kernel(H, W, cin, cout, 3, stride, upsample, kw.get("flags", 0))
-            timer._timed({1: "patch3", 2: "patch8x8"}.get(patch, "im2col"), 2.0 * nimg * OH * OW * cout * 9 * cin, 1, call)
+            timer._timed("conv", {1: "patch3", 2: "patch8x8"}.get(patch, "im2col"), 2.0 * nimg * OH * OW * cout * 9 * cin, 1, call)
         hip.conv3x3 = conv3x3
         orig_up = hip.upsample2x_conv3x3
 
@@ -119,7 +149,7 @@ class ConvTimer:
             if not timer.on:
                 return call()
             patch = hip.conv_uses_patch_kernel(H, W, cin, cout, 2, 1, False, kw.get("flags", 0)) == 1
-            timer._timed("patch2" if patch else "im2col", 4 * 2.0 * nimg * H * W * cout * 4 * cin, 4, call)
+            timer._timed("conv", "patch2" if patch else "im2col", 4 * 2.0 * nimg * H * W * cout * 4 * cin, 4, call)
         hip.upsample2x_conv3x3 = upsample2x_conv3x3
         orig_p1 = hip.conv3x3_plus_1x1
 
@@ -128,16 +158,69 @@ class ConvTimer:
             if not timer.on:
                 return call()
             patch = hip.conv_uses_patch_kernel(H, W, cin, cout, 3, 1, False, kw.get("flags", 0)) if c2 % 64 == 0 else 0
-            timer._timed({1: "patch3", 2: "patch8x8"}.get(patch, "im2col"), 2.0 * nimg * H * W * cout * (9 * cin + c2), 1, call)
+            timer._timed("conv", {1: "patch3", 2: "patch8x8"}.get(patch, "im2col"), 2.0 * nimg * H * W * cout * (9 * cin + c2), 1, call)
         hip.conv3x3_plus_1x1 = conv3x3_plus_1x1
+        orig_gemm = hip.gemm
+
+        def gemm(a, wt, out, *, M, N, K, **kw):
+            call = lambda: orig_gemm(a, wt, out, M=M, N=N, K=K, **kw)
+            if not timer.on:
+                return call()
+            key = "ff1" if (kw.get("flags", 0) & hip.EPI_GEGLU) else ("n320" if (N == 320 and M >= 4096) else "other")
+            timer._timed("gemm", key, 2.0 * M * N * K, 1, call)
+        hip.gemm = gemm
+        orig_attn = hip.attention
+
+        def attention(q, k, v, out, *, B, heads, n, nk, dh, v_sets=1, **kw):
+            call = lambda: orig_attn(q, k, v, out, B=B, heads=heads, n=n, nk=nk, dh=dh, v_sets=v_sets, **kw)
+            if not timer.on:
+                return call()
+            timer._timed("attention", f"dh{dh}" + (f"_shared{v_sets}" if v_sets > 1 else ""),
+                         4.0 * n * nk * dh * heads * B * max(v_sets, 1), 1, call)
+        hip.attention = attention
+        orig_ln = hip.layernorm
+
+        def layernorm(x, gamma, beta, out, *, M, C_, **kw):
+            call = lambda: orig_ln(x, gamma, beta, out, M=M, C_=C_, **kw)
+            if not timer.on:
+                return call()
+            timer._timed("norm", "layernorm", 0.0, 1, call, nbytes=float(M) * C_ * (x.element_size() + out.element_size()))
+        hip.layernorm = layernorm
+        orig_gna = hip.groupnorm_apply
+
+        def groupnorm_apply(x, stats, gamma, beta, out, *, nimg, hw, C_, **kw):
+            call = lambda: orig_gna(x, stats, gamma, beta, out, nimg=nimg, hw=hw, C_=C_, **kw)
+            if not timer.on:
+                return call()
+            timer._timed("norm", "groupnorm_apply", 0.0, 1, call, nbytes=float(nimg) * hw * C_ * (x.element_size() + out.element_size()))
+        hip.groupnorm_apply = groupnorm_apply
+        orig_gnc = hip.groupnorm_stats_from_cols
+
+        def groupnorm_stats_from_cols(colstats, *, nimg, hw, C_, **kw):
+            if not timer.on:
+                return orig_gnc(colstats, nimg=nimg, hw=hw, C_=C_, **kw)
+            box = []
+            timer._timed("norm", "groupnorm_finalize", 0.0, 1, lambda: box.append(orig_gnc(colstats, nimg=nimg, hw=hw, C_=C_, **kw)),
+                         nbytes=float(nimg) * (hw // 64) * C_ * 8)
+            return box[0]
+        hip.groupnorm_stats_from_cols = groupnorm_stats_from_cols
+        orig_fw = hip.flow_warp
+
+        def flow_warp(src, dst, flow, *, F, h, w, C_, **kw):
+            call = lambda: orig_fw(src, dst, flow, F=F, h=h, w=w, C_=C_, **kw)
+            if not timer.on:
+                return call()
+            timer._timed("norm", "flow_warp", 0.0, 1, call, nbytes=float(F) * h * w * C_ * 2 * 6)
+        hip.flow_warp = flow_warp
 
     def summary(self):
         out = {}
-        for k, c in self.cls.items():
+        for (fam, k), c in self.cls.items():
             ms = sum(a.elapsed_time(b) for a, b in c["events"])
-            out[k] = {"launches": c["launches"], "ms": ms, "flops": c["flops"],
-                      "tflops": c["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
-                      "mean_launch_us": ms * 1e3 / max(c["launches"], 1)}
+            out.setdefault(fam, {})[k] = {"launches": c["launches"], "ms": ms, "flops": c["flops"], "bytes": c["bytes"],
+                                          "tflops": c["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0,
+                                          "gbps": c["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0,
+                                          "mean_launch_us": ms * 1e3 / max(c["launches"], 1)}
         return out
 
 
@@ -193,6 +276,33 @@ def cpu_baseline(n_forwards, ddim_steps):
                       f"forward, x{ddim_steps} steps per clip of {F_} frames"}
 
 
+def traffic_from_profiles(prefixes, workload_ok):
+    """HBM-side bytes per launch of the kernels whose names start with one of `prefixes`, QUOTED from the newest committed
+    profiles/*_hbm_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command: tools/traffic.sh;
+    2 x FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md "HBM") -- never measured in this run, and only
+    when that summary was collected on the SAME kernel sources this run is built from (`_build.source_sha16`): a stale
+    summary yields null and says why."""
+    from vface_amd.utils.buildinfo import source_sha16
+    prof = os.path.join(ROOT, "profiles")
+    cands = sorted(f for f in os.listdir(prof) if f.endswith("_hbm_traffic.json")) if os.path.isdir(prof) else []
+    if not cands:
+        return None, "no profiles/*_hbm_traffic.json"
+    if not workload_ok:
+        return None, "the committed traffic summaries are of the default workload (8 frames, 512x512, replace, fp16) only"
+    tj = json.load(open(os.path.join(prof, cands[-1])))
+    have, want = (tj.get("_build") or {}).get("source_sha16"), source_sha16()
+    if have != want:
+        return None, (f"profiles/{cands[-1]} was collected on kernel sources {have or 'unrecorded'}, this run is built from "
+                      f"{want}: not quoted (re-run tools/traffic.sh)")
+    sel = [v for k, v in tj.items() if not k.startswith("_") and any(k.startswith(pf) for pf in prefixes)]
+    n = sum(v["launches"] for v in sel)
+    if not n:
+        return None, f"profiles/{cands[-1]} has no kernel named {prefixes}"
+    return (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in sel) / n,
+            f"QUOTED from profiles/{cands[-1]} {list(prefixes)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+            f"command on kernel sources {want}), not measured in this run")
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -227,18 +337,17 @@ def main():
 
     hip.load()
     log(f"building the 859.5M-parameter UNet with synthetic weights (rank {rank}/{world}) ...")
-    timer = ConvTimer()
+    timer = FamilyTimer()
     timer.wrap(hip)
     dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
-    h = a.res // 8
     ldm = LatentDiffusion(dict(FFHQ_UNET_CONFIG, compute_dtype=dt))
     synth.fill_module_(ldm.unet, seed=0)
     ldm = ldm.to(dev)
     sampler = DDIMSampler(ldm)
-    if h != 64:
-        sampler.flow_gate = "flow_hw"   # the reference's gate (4096 tokens) only ever fires at 512 x 512
     sampler.make_schedule(a.ddim_steps, ddim_eta=0.0, verbose=False)
     steps = [int(s) for s in sampler.ddim_timesteps[::-1]]
+    eng = ldm.unet.engine
+    UNET_GFLOP = {64: 796.94, 96: 2137.52, 32: 176.34}   # BASELINE.md 2 / SURVEY 8d, per sample-forward, by latent size
 
     def fence():
         torch.cuda.synchronize()
@@ -246,14 +355,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_workload(F_, fusion, n_steps, n_warm, time_convs, inv_steps, graph=False):
-        """W untimed + exactly K timed DDIM steps of an F-frame clip per GPU; returns per-rank wall seconds etc.
-        graph=True: the UNet forward of a step replayed from a hipGraph (UNetEngine.step_forward_nhwc) -- no per-launch
-        events can be recorded inside a graph, so the headline run (which carries the live roofline timing) launches kernel
-        by kernel and the graph run is reported beside it."""
+    def run_workload(F_, fusion, n_steps, n_warm, instrument, inv_steps, graph=True, res=None):
+        """W untimed + exactly K timed DDIM steps of an F-frame clip per GPU at resolution `res`; returns per-rank wall
+        seconds etc.  graph=True: the UNet forward of a step replayed from a hipGraph (UNetEngine.step_forward_nhwc: the
+        product default) -- no per-launch events can be recorded inside a graph, so `instrument=True` (events around every
+        launch, by family) goes with graph=False."""
+        h = (res or a.res) // 8
+        # the reference's flow gate (4096 tokens) only ever fires at 512 x 512: other resolutions use the generalised one
+        sampler.flow_gate = "reference" if h == 64 else "flow_hw"
         sampler.hook_plan = HookPlan(fusion=fusion, enabled=fusion != "none")
-        ldm.unet.engine.use_graph, ldm.unet.engine._graphs = bool(graph), {}
-        shard = FrameShard(rank, world, F_ * world, dist)
+        eng.use_graph, eng._graphs, eng._graph_failed = bool(graph), {}, set()
+        eng.decompose_attn1 = bool(instrument)
+        shard = FrameShard(rank, world, F_ * world, dist, mode=a.exchange)
         g0 = shard.first  # global index of this rank's first frame
         tag = lambda s_, f: f"bench.{s_}.{g0 + f}"
         stack = lambda s_, shape: torch.stack([synth.synth_normal(tag(s_, f), shape) for f in range(F_)]).to(dev)
@@ -263,8 +376,8 @@ def main():
         mask = synth.synth_mask(F_, h, h).to(dev)
         inv = {s_: stack(f"inv{s_}", (4, h, h)) for s_ in steps}  # device-resident recon latents
         flow = None
-        eng = ldm.unet.engine
         eng.halo_exchange, eng.halo_flow = None, None
+        eng.exchange_events = [] if (world > 1 and fusion == "flow_fix") else None
         if fusion == "flow_fix":
             gflow = synth.synth_flow(F_ * world - 1, h, h)  # one field per consecutive global frame pair
             flow = shard.local_flow(gflow).to(dev)
@@ -287,7 +400,9 @@ def main():
                 img = one_step(img, i)
             img = x_T
             fence()
-            timer.on = time_convs
+            if eng.exchange_events is not None:
+                eng.exchange_events.clear()
+            timer.on = instrument
             t0 = time.perf_counter()
             for i in range(n_steps):
                 img = one_step(img, i)
@@ -296,6 +411,17 @@ def main():
             el = time.perf_counter() - t0
             timer.on = False
         assert torch.isfinite(img).all(), "non-finite latents"
+        graphed = bool(eng.use_graph and eng._graphs)
+        nseg = max((len(g["segments"]) for g in eng._graphs.values()), default=0)
+        exch = None
+        if world > 1 and fusion == "flow_fix":
+            wait_ms = sum(e0.elapsed_time(e1) for e0, e1 in eng.exchange_events) / max(n_steps, 1)
+            # level-0 maps: n = h*h tokens, d = model_channels = 320 -> one [n, 2d] 16-bit slab per hooked layer (2 of them)
+            exch = {"mode": a.exchange, "bytes_per_step": shard.slab_bytes_per_step(h * h, 320),
+                    "wait_ms_per_step": wait_ms, "exchanges_per_step": len(eng.exchange_events) / max(n_steps, 1),
+                    "note": "bytes this rank sends per DDIM step (one [n, 2d] fp16 slab per hooked level-0 layer, one hop down the "
+                            "chain; none from the last rank); wait = HIP events around the finish_exchange calls on rank 0's "
+                            "successor-facing stream, i.e. how long the launch stream stalls for the neighbour's slab"}
         # DDIM inversion (ddim_w_inv.py:360-490; SURVEY 8d asks for it separately): hooks off, batch 2F = [target ; source],
         # no guidance -- 50 such steps per clip precede sampling unless the latents are cached.  Timed outside the step loop.
         inv_ms = None
@@ -318,67 +444,92 @@ def main():
             tt = torch.tensor([el], device="cpu" if rehearse else dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
-        return {"ms_step": el / n_steps * 1e3, "enqueue_ms": t_enq / n_steps * 1e3, "inv_ms": inv_ms, "elapsed": el}
+        launch = ("kernel by kernel" if not graphed else
+                  ("hipGraph replay of the UNet forward of each step (UNetEngine.step_forward_nhwc)" if nseg <= 1 else
+                   f"hipGraph replay in {nseg} segments cut at the halo exchanges, the RCCL send / recv / wait calls issued from the host "
+                   "between them (engine._GraphSegments)"))
+        eng.exchange_events = None
+        return {"ms_step": el / n_steps * 1e3, "enqueue_ms": t_enq / n_steps * 1e3, "inv_ms": inv_ms, "elapsed": el,
+                "launch": launch, "exchange": exch, "h": h}
 
     F_ = a.frames
+    h = a.res // 8
     log("weights resident; warm-up ...")
-    # Timed region: W + K DDIM steps with NO instrumentation inside -- the UNet forward of a step replayed from a hipGraph
-    # (one host call instead of ~1200; VERDICT r1 #9/#10: no per-launch event records in the region `value` is timed over).
-    # The per-launch HIP events behind `roofline` are recorded in a second, kernel-by-kernel pass of the same W + K steps
-    # right after it (events cannot be recorded inside a captured graph); that pass's own step time is reported beside.
+    # Timed region: W + K DDIM steps with NO instrumentation inside -- the UNet forward of a step replayed from a hipGraph,
+    # the product default (one host call instead of ~1200).  The per-launch HIP events behind `roofline` are recorded in a
+    # second, kernel-by-kernel pass of the same W + K steps right after it (events cannot be recorded inside a captured
+    # graph); that pass's own step time is reported beside.
     r = run_workload(F_, a.fusion, a.steps, a.warmup, False, a.inv_steps, graph=not a.eager)
-    graphed = ldm.unet.engine.use_graph and len(ldm.unet.engine._graphs) > 0
-    launch_mode = ("hipGraph replay of the UNet forward of each step (UNetEngine.step_forward_nhwc)" if graphed else
-                   "kernel by kernel" + ("" if a.eager else " (no graph captured: frame-sharded exchange inside the forward, or capture failed)"))
+    launch_mode = r["launch"] + ("" if (a.eager or r["launch"] != "kernel by kernel") else " (no graph captured: capture failed)")
     ms_step, inv_ms = r["ms_step"], r["inv_ms"]
     if inv_ms is not None:
         log(f"inversion: {inv_ms:.2f} ms/step (2F = {2 * F_} unhooked sample-forwards)")
     log(f"timed {a.steps} steps: {ms_step:.2f} ms/step (host enqueue {r['enqueue_ms']:.2f} ms/step; {launch_mode})")
-    log("instrumented pass (kernel by kernel, HIP events around every convolution launch) ...")
+    log("instrumented pass (kernel by kernel, HIP events around every GEMM / conv / attention / norm launch) ...")
+    timer.reset()
     ri = run_workload(F_, a.fusion, a.steps, a.warmup, True, 0, graph=False)
     el = ri["elapsed"]
     log(f"  {ri['ms_step']:.2f} ms/step (host enqueue {ri['enqueue_ms']:.2f} ms/step)")
     fps = (F_ * world) / (a.ddim_steps * ms_step / 1e3)
-    conv = timer.summary()
-    conv_ms = sum(c["ms"] for c in conv.values())
-    conv_flops = sum(c["flops"] for c in conv.values())
-    unet_gflop = {64: 796.94, 96: 2137.52, 32: 176.34}.get(h)   # BASELINE.md 2, per sample-forward
+    fam = timer.summary()
+    unet_gflop = UNET_GFLOP.get(h)
 
     # the other single-GPU BASELINE configurations, same process and build, outside the timed region of the headline run
     extras = []
-    if world == 1 and not a.no_extras and h == 64:
-        for name, f2, fus in (("BASELINE configs[2]: 32-frame 512x512 clip + frequency-spectrum attention interpolation", 32, "fft"),
-                              ("shipped hook schedule (ddim_w_inv.py:303-305), config 4's per-GPU share: 16 frames + flow_fix", 16, "flow_fix")):
-            if f2 == F_ and fus == a.fusion:
+    if world == 1 and not a.no_extras and a.res == 512:
+        for name, f2, fus, res2 in (
+                ("BASELINE configs[2]: 32-frame 512x512 clip + frequency-spectrum attention interpolation", 32, "fft", 512),
+                ("shipped hook schedule (ddim_w_inv.py:303-305), config 4's per-GPU share: 16 frames + flow_fix", 16, "flow_fix", 512),
+                ("BASELINE configs[4]'s per-GPU share: 32 frames at 768x768 (96x96 latents, n = 9216 tokens at level 0), all three "
+                 "modules (flow_fix, flow gate generalised to the flow field's h*w: the reference's n == 4096 gate never fires "
+                 "at this size)", 32, "flow_fix", 768)):
+            if f2 == F_ and fus == a.fusion and res2 == a.res:
                 continue
-            log(f"extra workload: {f2} frames, fusion={fus} ...")
-            e = run_workload(f2, fus, a.extra_steps, 2, False, 0, graph=not a.eager)
-            eg = ldm.unet.engine.use_graph and len(ldm.unet.engine._graphs) > 0
-            extras.append({"workload": name, "frames_per_gpu": f2, "fusion": fus, "steps": a.extra_steps, "warmup": 2,
-                           "launch": "hipGraph replay" if eg else "kernel by kernel",
+            log(f"extra workload: {f2} frames at {res2}x{res2}, fusion={fus} ...")
+            e = run_workload(f2, fus, a.extra_steps if res2 == 512 else max(3, a.extra_steps // 2), 2, False, 0, graph=not a.eager, res=res2)
+            extras.append({"workload": name, "frames_per_gpu": f2, "fusion": fus, "res": res2, "latent": [e["h"], e["h"]],
+                           "steps": a.extra_steps if res2 == 512 else max(3, a.extra_steps // 2), "warmup": 2,
+                           "launch": "hipGraph replay" if e["launch"] != "kernel by kernel" else "kernel by kernel",
                            "ms_per_step": e["ms_step"], "host_enqueue_ms_per_step": e["enqueue_ms"],
                            "frames_per_s": f2 / (a.ddim_steps * e["ms_step"] / 1e3),
-                           "unet_algorithmic_tflops": 3 * f2 * unet_gflop * 1e9 / (e["ms_step"] * 1e-3) / 1e12})
-            log(f"  {e['ms_step']:.2f} ms/step = {extras[-1]['frames_per_s']:.2f} frames/s")
-    ldm.unet.engine.use_graph, ldm.unet.engine._graphs = False, {}     # (frees the captured graphs' activation pools)
+                           "unet_algorithmic_tflops": 3 * f2 * UNET_GFLOP[e["h"]] * 1e9 / (e["ms_step"] * 1e-3) / 1e12})
+            log(f"  {e['ms_step']:.2f} ms/step = {extras[-1]['frames_per_s']:.2f} frames/s "
+                f"({extras[-1]['unet_algorithmic_tflops']:.0f} TFLOP/s algorithmic)")
+    eng.use_graph, eng._graphs = False, {}     # (frees the captured graphs' activation pools)
     if rank == 0:
-        dom = conv["patch3"] if conv["patch3"]["launches"] else max(conv.values(), key=lambda c: c["ms"])
-        achieved = dom["tflops"]
-        all_conv = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        step_ms_i = el * 1e3                     # the instrumented pass, all K steps
         unet_tflops = 3 * F_ * unet_gflop * 1e9 / (ms_step * 1e-3) / 1e12 if unet_gflop else None
-        # HBM-side bytes per conv launch are NOT measured in this run: they come from separate rocprofv3 --pmc passes of this
-        # same command (tools/traffic.sh: 2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md "HBM");
-        # the committed summary is quoted only for the workload it was collected on, otherwise null.
-        traffic, traffic_src = None, None
-        prof = os.path.join(ROOT, "profiles")
-        cands = sorted(f for f in os.listdir(prof) if f.endswith("_hbm_traffic.json")) if os.path.isdir(prof) else []
-        if cands and F_ == 8 and h == 64 and a.fusion == "replace" and a.dtype == "fp16":
-            tf = os.path.join(prof, cands[-1])
-            tj = json.load(open(tf))
-            key = "_conv_patch3" if "_conv_patch3" in tj else next((k for k in tj if k.startswith("conv_patch_kernel") and ", 3, 3" in k), "_conv_all")
-            traffic = tj[key]["hbm_bytes_per_launch"]
-            traffic_src = (f"QUOTED from profiles/{cands[-1]} [{key}] (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                           "command on the build it names), not measured in this run")
+
+        def fam_total(name):
+            d = fam.get(name, {})
+            ms = sum(c["ms"] for c in d.values())
+            fl = sum(c["flops"] for c in d.values())
+            by = sum(c["bytes"] for c in d.values())
+            n = sum(c["launches"] for c in d.values())
+            o = {"launches": n, "ms": ms, "ms_per_step": ms / a.steps, "share_of_step_time": ms / step_ms_i if step_ms_i else 0.0,
+                 "by_kernel": {k: {kk: vv for kk, vv in c.items() if kk not in ("flops", "bytes") and not (kk == "gbps" and not c["bytes"])
+                                   and not (kk == "tflops" and not c["flops"])} for k, c in sorted(d.items())}}
+            if fl:
+                o["tflops"] = fl / (ms * 1e-3) / 1e12 if ms else 0.0
+                o["frac"] = o["tflops"] / MFMA_PEAK_TFLOPS
+                o["tflop_per_step"] = fl / a.steps / 1e12
+            if by:
+                o["gbps"] = by / (ms * 1e-3) / 1e9 if ms else 0.0
+                o["frac_of_8TBps"] = o["gbps"] / 8000.0
+            return o
+
+        by_family = {k: fam_total(k) for k in ("gemm", "conv", "attention", "norm")}
+        by_family["gemm"]["kernel"] = "gemm_kernel<T, MODE_PLAIN, NT, DB, PERSIST, RM> (gemm.hip): every Linear / 1x1 conv; FLOPs as executed (2 M N K)"
+        by_family["conv"]["kernel"] = "conv_patch_kernel<T, NT, KH, KW, ..> (conv.hip) + gemm_kernel<T, MODE_CONV_*> (im2col); FLOPs as executed"
+        by_family["attention"]["kernel"] = "attn_kernel<T, DH, QT, G, LAZY> (attention.hip); algorithmic FLOPs 4 n nk dh per (output sample, head)"
+        by_family["norm"]["kernel"] = "layernorm_kernel, gn_apply_kernel, gn_finalize_cols, flow_warp_kernel (pointwise.hip): HBM-bound, algorithmic bytes"
+        covered = sum(by_family[k]["ms"] for k in by_family)
+        mfma_fams = ("gemm", "conv", "attention")
+        dom = max(mfma_fams, key=lambda k: by_family[k]["ms"])
+        d = by_family[dom]
+        prefixes = {"gemm": ("gemm_kernel<F16, 0,", "gemm_kernel<BF16, 0,"), "conv": ("conv_patch_kernel", "gemm_kernel<F16, 1,", "gemm_kernel<F16, 2,"),
+                    "attention": ("attn_kernel",)}[dom]
+        traffic, traffic_src = traffic_from_profiles(prefixes, F_ == 8 and h == 64 and a.fusion == "replace" and a.dtype == "fp16" and world == 1)
         out = {
             "metric": "swapped frames/sec at 512x512, 50-step DDIM", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
@@ -390,34 +541,37 @@ def main():
                        "frames_per_gpu": F_, "latent": [h, h], "fusion": a.fusion,
                        "world_size": world, "backend": backend, "launch": launch_mode,
                        "unet_algorithmic_tflops_per_gpu": unet_tflops,
+                       "unet_algorithmic_frac_of_mfma_peak": unet_tflops / MFMA_PEAK_TFLOPS if unet_tflops else None,
                        "host_enqueue_ms_per_step": r["enqueue_ms"],
                        # north_star also asks for the rate as a fraction of the attention-GEMM roofline: the attn1 QKV
                        # projections + QK^T + PV are 160.9 GFLOP per sample-forward at 64x64 = 24.1 TFLOP per
                        # swapped frame; at the 2.5 PFLOP/s dense peak that alone would allow 103.6 frames/s per GPU
                        "attention_gemm_roofline_frac": (fps / world) * 24.135e12 / (MFMA_PEAK_TFLOPS * 1e12) if h == 64 else None},
+            "exchange": r["exchange"],
             "inversion": None if inv_ms is None else {
                 "ms_per_step": inv_ms, "steps_timed": a.inv_steps,
                 "note": "DDIM inversion step (hooks off, batch 2F, no guidance), outside the timed region; `value` is "
                         "sampling only, as BASELINE's metric",
                 "frames_per_s_sampling_plus_inversion": (F_ * world) / (a.ddim_steps * (ms_step + inv_ms) / 1e3)},
             "extra": extras,
-            "instrumented_pass": {"launch": "kernel by kernel, HIP events around every convolution launch (what `roofline` is computed from)",
-                                  "ms_per_step": ri["ms_step"], "host_enqueue_ms_per_step": ri["enqueue_ms"], "steps": a.steps, "warmup": a.warmup},
-            # the dominant kernel of the step (largest share of kernel time in profiles/*_kernel_stats.csv): conv_patch_kernel<3,3>,
-            # the patch-staged stride-1 3x3 convolution (incl. the launches that carry a ResBlock's fused 1x1 shortcut)
-            "roofline": {"bound": "mfma", "kernel": "conv_patch_kernel<T, NT, 3, 3> (conv.hip: patch-staged 3x3 convolution)",
-                         "achieved": achieved, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                         "launches": dom["launches"], "mean_launch_us": dom["mean_launch_us"],
-                         "share_of_step_time": dom["ms"] / (el * 1e3),
-                         "timing": "HIP events on the launch stream around every launch of this kernel, recorded in the instrumented pass: the same "
+            "instrumented_pass": {"launch": "kernel by kernel, HIP events around every GEMM / convolution / attention / norm launch (what `roofline` "
+                                            "is computed from; vface_attn1_forward's launches issued call by call, bit-identical)",
+                                  "ms_per_step": ri["ms_step"], "host_enqueue_ms_per_step": ri["enqueue_ms"], "steps": a.steps, "warmup": a.warmup,
+                                  "event_covered_share": covered / step_ms_i if step_ms_i else None},
+            # the kernel family with the largest share of the step's kernel time (by family the plain GEMM, not the
+            # convolution, is the largest and the furthest below the roofline); the others are in by_family
+            "roofline": {"bound": "mfma", "kernel": d["kernel"], "family": dom,
+                         "achieved": d["tflops"], "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": d["tflops"] / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "launches": d["launches"], "mean_launch_us": d["ms"] * 1e3 / max(d["launches"], 1),
+                         "share_of_step_time": d["share_of_step_time"],
+                         "timing": "HIP events on the launch stream around every launch of this family, recorded in the instrumented pass: the same "
                                    "W + K steps launched kernel by kernel right after the timed region (events cannot be recorded inside a "
                                    "captured graph); share_of_step_time is relative to that pass",
-                         "note": "peak is the datasheet 2.5 PFLOP/s; an MFMA-only loop of this tile shape sustains 1.5 PFLOP/s on "
-                                 "this chip (it clocks ~1.6 GHz under matrix load: DESIGN.md 4, profiles/r02_a_conv_patch_ablations.txt)",
-                         "all_conv_launches": {"tflops": all_conv, "frac": all_conv / MFMA_PEAK_TFLOPS, "ms": conv_ms,
-                                               "share_of_step_time": conv_ms / (el * 1e3),
-                                               "by_kernel": {k: {kk: vv for kk, vv in c.items() if kk != "flops"} for k, c in conv.items()}}},
+                         "note": "peak is the datasheet 2.5 PFLOP/s; an MFMA-only loop sustains ~1.5 PFLOP/s on this chip (it clocks ~1.6 GHz "
+                                 "under matrix load: DESIGN.md 4).  whole-UNet check: sum over by_family of ms_per_step = the kernel time of a step; "
+                                 "config.unet_algorithmic_tflops_per_gpu = 3F x 796.94 GFLOP / ms_per_step",
+                         "by_family": by_family},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.cpu_forwards, a.ddim_steps)

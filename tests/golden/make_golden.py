@@ -411,7 +411,7 @@ def gen_vae():
     from ldm.modules.diffusionmodules.model import Decoder, Encoder
     from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
     import builtins
-    out = {}
+    out, lowp = {}, {}
     for tag, dd, res, nb in (("small", dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32,
                                             ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0), 32, 2),
                              ("ffhq", dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
@@ -436,7 +436,23 @@ def gen_vae():
             dec = m.decoder(m.post_quant_conv(z_samp / 0.18215))
         out[f"{tag}.moments"], out[f"{tag}.z_mode"], out[f"{tag}.z_sample"], out[f"{tag}.dec"] = moments, z_mode, z_samp, dec
         out[f"{tag}.n_params"] = float(sum(p.numel() for p in m.parameters()))
+        # The reference's own LOW-PRECISION behaviour on the same inputs (the evidence the GPU test's whole-network bound
+        # rests on, as lowp.npz is for the UNet): under torch.autocast(fp16) -- what the entry point runs the first stage in
+        # (VFace_inference_batch.py:407-408 wraps encode / decode too) -- and in fp32 arithmetic with fp16-rounded parameters.
+        def run(mm):
+            mo = mm.quant_conv(mm.encoder(x)).float()
+            po = DiagonalGaussianDistribution(mo)
+            return po.mode() * 0.18215, (po.mean + po.std * noise) * 0.18215, mm.decoder(mm.post_quant_conv(z_samp / 0.18215)).float()
+        with torch.no_grad():
+            with torch.autocast("cpu", dtype=torch.float16):
+                a_mode, a_samp, a_dec = run(m)
+            _round_weights_(m)
+            w_mode, w_samp, w_dec = run(m)
+        for k, v in (("z_mode_autocast_f16", a_mode), ("z_sample_autocast_f16", a_samp), ("dec_autocast_f16", a_dec),
+                     ("z_mode_w16", w_mode), ("z_sample_w16", w_samp), ("dec_w16", w_dec)):
+            lowp[f"{tag}.{k}"] = v.float()
     save("vae", **out)
+    save("vae_lowp", **lowp)
 
 
 if __name__ == "__main__":

@@ -159,3 +159,103 @@ def test_bench_self_launches_one_rank_per_gpu(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_lightning_style_checkpoint_loads_with_and_without_vae(tmp_path):
+    """ADVICE r2: ``--ckpt`` must take the reference's real ``last.ckpt`` layout (VFace_inference_batch.py:118-135): a
+    pytorch_lightning 1.4 checkpoint = state_dict of the WHOLE LatentDiffusion (UNet + first stage + conditioning encoders)
+    plus ``callbacks`` keyed by a callback CLASS and other non-tensor entries.  Loads with and without the first stage built;
+    a checkpoint that misses a UNet parameter raises."""
+    import sys
+    import types
+    from vface_amd.ldm.models.autoencoder import FFHQ_VAE_CONFIG
+    from vface_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from vface_amd.scripts.VFace_inference_batch import load_checkpoint
+    from vface_amd.utils import synth
+    ucfg = dict(image_size=32, in_channels=9, out_channels=4, model_channels=32, attention_resolutions=[4, 2, 1],
+                num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                transformer_depth=1, context_dim=768, legacy=False)
+    vcfg = dict(FFHQ_VAE_CONFIG, ddconfig=dict(FFHQ_VAE_CONFIG["ddconfig"], ch=32, resolution=32))
+    src = LatentDiffusion(ucfg, first_stage_config=vcfg)
+    synth.fill_module_(src.unet, seed=3)
+    synth.fill_module_(src.first_stage_model, seed=3, prefix="vae.")
+    sd = dict(src.state_dict())
+    assert any(k.startswith("model.diffusion_model.") for k in sd) and any(k.startswith("first_stage_model.") for k in sd)
+    sd["cond_stage_model.mapper.weight"] = torch.zeros(4, 4)          # conditioning encoders: outside the path
+    sd["learnable_vector"] = torch.zeros(1, 1, 768)
+    sd["face_ID_model.facenet.input_layer.0.weight"] = torch.zeros(2, 2)
+    # a module that exists only while the checkpoint is WRITTEN (as pytorch_lightning does on the training machine)
+    fake = types.ModuleType("pytorch_lightning_fake_callbacks")
+
+    class ModelCheckpoint:
+        pass
+    ModelCheckpoint.__module__ = fake.__name__
+    ModelCheckpoint.__qualname__ = "ModelCheckpoint"
+    fake.ModelCheckpoint = ModelCheckpoint
+    sys.modules[fake.__name__] = fake
+    path = str(tmp_path / "last.ckpt")
+    try:
+        torch.save({"epoch": 3, "global_step": 1234, "pytorch-lightning_version": "1.4.2", "state_dict": sd,
+                    "callbacks": {ModelCheckpoint: {"best_model_score": torch.tensor(0.5), "best_model_path": "x"}},
+                    "hyper_parameters": ModelCheckpoint()}, path)
+    finally:
+        del sys.modules[fake.__name__]
+    for with_vae in (False, True):
+        dst = LatentDiffusion(ucfg, first_stage_config=vcfg if with_vae else None)
+        msg = load_checkpoint(dst, path, with_vae=with_vae)
+        assert "matched every parameter" in msg
+        for k, v in dst.state_dict().items():
+            assert torch.equal(v, sd[k]), k
+    # a checkpoint without one UNet tensor must not run on default-initialised weights
+    bad = {k: v for k, v in sd.items() if k != "model.diffusion_model.out.2.weight"}
+    torch.save({"state_dict": bad}, path)
+    with pytest.raises(RuntimeError, match="missing"):
+        load_checkpoint(LatentDiffusion(ucfg), path)
+    torch.save({"state_dict": {"something.else": torch.zeros(1)}}, path)
+    with pytest.raises(RuntimeError, match="not an LDM checkpoint"):
+        load_checkpoint(LatentDiffusion(ucfg), path)
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    return bench
+
+
+def test_bench_multi_gpu_command_line_defaults_to_the_shipped_schedule():
+    """VERDICT r2 next #4: the driver's `bench.py --gpus N --steps K --warmup W` with N > 1 must time the workload that HAS
+    the halo exchange -- the shipped schedule (flow_fix, ddim_w_inv.py:303-305) at config 4's per-GPU share (16 frames) --
+    while N = 1 stays BASELINE configs[1] (8 frames, replace); explicit flags win."""
+    bench = _bench_module()
+    for n in (2, 4, 8):
+        a = bench.parse(["--gpus", str(n), "--steps", "20", "--warmup", "5"])
+        assert (a.fusion, a.frames, a.exchange) == ("flow_fix", 16, "p2p")
+    a = bench.parse(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    assert (a.fusion, a.frames) == ("replace", 8)
+    a = bench.parse(["--gpus", "8", "--fusion", "replace", "--frames", "8", "--exchange", "allgather"])
+    assert (a.fusion, a.frames, a.exchange) == ("replace", 8, "allgather")
+
+
+def test_bench_refuses_a_traffic_summary_from_other_kernel_sources(tmp_path, monkeypatch):
+    """roofline.traffic is quoted from profiles/*_hbm_traffic.json only when that summary records the kernel sources this
+    tree is built from (VERDICT r2 weak #10: it used to go stale silently)."""
+    import json
+    from vface_amd.utils.buildinfo import source_sha16
+    bench = _bench_module()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    body = {"gemm_kernel<F16, 0, 5, true, false, 2>": {"launches": 10, "hbm_bytes_per_launch": 100.0},
+            "gemm_kernel<F16, 0, 4, true, false, 0>": {"launches": 30, "hbm_bytes_per_launch": 300.0},
+            "conv_patch_kernel<F16, 5, 3, 3, false, false, 0, false>": {"launches": 5, "hbm_bytes_per_launch": 7.0}}
+    (prof / "r99_hbm_traffic.json").write_text(json.dumps(dict(body, _build={"source_sha16": "0" * 16})))
+    t, why = bench.traffic_from_profiles(("gemm_kernel<F16, 0,",), True)
+    assert t is None and "not quoted" in why
+    (prof / "r99_hbm_traffic.json").write_text(json.dumps(body))          # no build record at all
+    assert bench.traffic_from_profiles(("gemm_kernel<F16, 0,",), True)[0] is None
+    (prof / "r99_hbm_traffic.json").write_text(json.dumps(dict(body, _build={"source_sha16": source_sha16()})))
+    t, why = bench.traffic_from_profiles(("gemm_kernel<F16, 0,",), True)
+    assert t == (10 * 100.0 + 30 * 300.0) / 40 and "QUOTED" in why
+    assert bench.traffic_from_profiles(("gemm_kernel<F16, 0,",), False)[0] is None     # another workload: never quoted

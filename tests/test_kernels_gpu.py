@@ -3,6 +3,8 @@ same op on the same (16-bit-rounded) inputs, and against the reference-generated
 Tolerances: rel-L2 <= 1e-3 for fp16 outputs (the north-star bound), looser and stated for bf16."""
 import math
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -26,8 +28,10 @@ def rnd(shape, seed, dt, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dt)
 
 
-VARIANTS = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]  # 0 = automatic schedule; 1..8 forced (include/vface_hip.h)
-EXPERIMENTAL = (1, 2, 3, 4, 9, 10)              # built by `make VARIANTS=1` only
+EXPERIMENTAL = (1, 2, 3, 4, 9, 10)              # csrc/experiments/: built by `make VARIANTS=1` only, never shipped
+# 0 = automatic schedule; 5..8 forced product schedules (include/vface_hip.h).  The experimental schedules are collected
+# only when asked for (VFACE_EXPERIMENTS=1 with a `make VARIANTS=1` library), so a product run has no permanent skips.
+VARIANTS = [0, 5, 6, 7, 8] + (list(EXPERIMENTAL) if os.environ.get("VFACE_EXPERIMENTS") == "1" else [])
 
 
 def need_variant(h, variant):
@@ -76,7 +80,7 @@ def test_gemm_strided_views_rowbias_dual_source():
     assert got[:, :32].abs().max() == 0 and got[:, 32 + N:].abs().max() == 0  # nothing outside the view
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 5, 7, 9])
+@pytest.mark.parametrize("variant", [v for v in (0, 1, 3, 5, 7, 9) if v in VARIANTS])
 def test_gemm_geglu(variant):
     h = hip()
     need_variant(h, variant)

@@ -135,6 +135,7 @@ def test_two_rank_flow_fix_equals_unsharded(tmp_path):
         pr.join(600)
         assert pr.exitcode == 0
     total = 4
+    failures = []
     res = [torch.load(os.path.join(outdir, f"w2_r{r}.pt")) for r in range(2)]
     for d in res:
         rank, f0, fc, out = d["rank"], d["f0"], d["fc"], d["out"]
@@ -144,12 +145,77 @@ def test_two_rank_flow_fix_equals_unsharded(tmp_path):
         print(f"rank {rank}: max diff {diff.max():.3e}; per (chunk, frame): {per.tolist()}")
         if not torch.equal(out, ref):
             # Two processes TIME-SLICING one GPU is not the production layout (one process per GPU), and on this pool it
-            # is not bit-stable: with a second process keeping the GPU busy, a kernel launched after an attention kernel
-            # occasionally (a few launches in a thousand) reads one 256-byte row of its input wrong -- seen with back-to-back
-            # launches of the same kernel on the same, verifiably correct, input (tools/dbg_concurrent5.py; never with
-            # the GPU to ourselves: test_bitwise_reproducible_and_batch_invariant, the full-size clip tests).  A real
-            # sharding error moves whole frames by O(1); accept nothing beyond isolated pixels at the 1e-2 level.
+            # was not bit-stable in round 1: with a second process keeping the GPU busy, a kernel launched after an attention
+            # kernel occasionally read one 256-byte row of its input as zeros (never with the GPU to ourselves:
+            # test_bitwise_reproducible_and_batch_invariant, the loop-back test above, the full-size clip tests).  A real
+            # sharding error moves whole frames by O(1) and FAILS here; isolated pixels are reported as an expected failure
+            # (non-strict xfail), never as a pass: a green run of this test means bit-identical.
             bad_pix = (diff.amax(1) > 0).sum().item()       # (sample, y, x) positions that differ in any channel
             err = (out - ref).norm() / ref.norm()
-            print(f"rank {rank}: NOT bit-identical under GPU time-slicing: {bad_pix} pixel(s), rel-L2 {err:.2e}")
-            assert bad_pix <= 16 and err < 1e-4 and diff.max() < 5e-2, f"rank {rank}: max diff {diff.max()}, {bad_pix} pixels"
+            msg = f"rank {rank}: NOT bit-identical under GPU time-slicing: {bad_pix} pixel(s), rel-L2 {err:.2e}, max diff {diff.max():.3e}"
+            print(msg)
+            assert bad_pix <= 16 and err < 1e-4 and diff.max() < 5e-2, msg
+            failures.append(msg)
+    if failures:
+        pytest.xfail("; ".join(failures))
+
+
+def test_segmented_hipgraph_replay_of_sharded_forward_equals_unsharded():
+    """hipGraph replay of a FRAME-SHARDED forward: the forward is captured as graph segments cut at
+    the two exchanges (engine._GraphSegments), the send / receive / wait calls run from the host between segment replays.
+    Every shard's replayed eps must equal the unsharded kernel-by-kernel run bit for bit -- on the capturing call and on a
+    pure replay -- and the capture must really be 5 segments (2 hooked level-0 layers x (start, finish))."""
+    from vface_amd import hip
+    from vface_amd.engine import Act
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler
+    from vface_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from vface_amd.ldm.models.pnp_utils import register_spa_attn_injection as reg
+    from vface_amd.parallel import LoopbackShard
+    from vface_amd.utils import synth
+    dev = "cuda:0"
+    total, world, h, w = 5, 2, 32, 32
+    ldm = LatentDiffusion(_cfg())
+    synth.fill_module_(ldm.unet, seed=0)
+    ldm = ldm.to(dev)
+    sampler = DDIMSampler(ldm)
+    sampler.flow_gate = "flow_hw"
+    gflow = synth.synth_flow(total - 1, h, w)
+    eng = ldm.unet.engine
+
+    def step(shard, graph):
+        x, ctx = _shard_inputs(total, h, w, shard.first, shard.count, dev)
+        tt = torch.full((3 * shard.count,), 481, dtype=torch.long, device=dev)
+        shard.install(eng, gflow, dev)
+        flow = shard.local_flow(gflow)
+        key = ("flows", shard.rank, shard.world)
+        if key not in keep:      # the same flow tensors on every call of a shard, as the DDIM loop hands them
+            keep[key] = [f[None].to(dev) for f in flow]
+        reg(sampler, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True)
+        reg(sampler, 1, switch_on=True, input_blocks=True, middle_block=False, output_blocks=False, chunks=3,
+            flow=keep[key], block_indices=list(range(9)), fusion="flow_fix", split_ratio_fft=0.8, alpha=0.8)
+        N, C, H, W = x.shape
+        cpad = (C + 7) // 8 * 8
+        xin = torch.empty(N * H * W, cpad, dtype=eng.dtype, device=dev)
+        hip.nchw_to_nhwc(x.float().contiguous(), xin, N=N, C_=C, hw=H * W, cpad=cpad)
+        eng.use_graph = graph
+        shard.begin_forward()
+        return eng.step_forward_nhwc(Act(xin, N, H, W), tt, ctx).clone().reshape(N, H * W, -1)
+
+    keep = {}
+    old = eng.use_graph, eng._graphs
+    try:
+        eng._graphs = {}
+        full = step(LoopbackShard(0, 1, total, {}), False)
+        store = {}
+        shards = [LoopbackShard(r, world, total, store) for r in range(world)]
+        for call in range(2):           # call 0 captures (warm-up + capture pass + first replay), call 1 only replays
+            for sh in shards:
+                out = step(sh, True)
+                ref = torch.cat([full[c * total + sh.first:c * total + sh.first + sh.count] for c in range(3)])
+                assert torch.equal(out, ref), f"call {call} rank {sh.rank}: max diff {(out - ref).abs().max().item():.3e}"
+        assert not eng._graph_failed, "capture fell back to kernel-by-kernel launches"
+        segs = sorted(len(g["segments"]) for g in eng._graphs.values())
+        assert segs == [5, 5], segs
+    finally:
+        eng.use_graph, eng._graphs = old
+        eng.halo_exchange = None

@@ -101,7 +101,7 @@ def test_small_unet_hook_modes_vs_oracle(small, mode):
     ref = ounet.unet_forward(sd, SMALL, x, t, ctx, _oracle_registry(mode, flow))
     err = rel_l2(got, ref)
     print(f"{mode}: rel-L2 {err:.3e}")
-    assert err < 2e-3, (mode, err)
+    assert err < SMALL_BOUND, (mode, err)
 
 
 def test_cpu_tensors_fail_loudly(small):
@@ -206,10 +206,17 @@ def test_full_unet_vs_reference_golden(mode):
     e_auto, e_w16 = rel_l2(lp[f"full.{mode}_autocast_f16"], g[mode]), rel_l2(lp[f"full.{mode}_w16"], g[mode])
     print(f"full UNet {mode}: rel-L2 vs reference {err:.3e}  (reference under fp16 autocast {e_auto:.3e}; reference with "
           f"fp16-rounded weights only {e_w16:.3e})")
+    # north_star: "within 1e-3 relative fp16".  The reference's fp16 arithmetic is its autocast run: the distance between
+    # this build and THAT output is printed and bounded too (two fp16 evaluations of one network differ by about the sum of
+    # their rounding noises: measured 1.9e-3 = sqrt(1.18e-3^2 + 1.59e-3^2), i.e. the two errors are uncorrelated)
+    e_vs_auto = rel_l2(got, lp[f"full.{mode}_autocast_f16"])
+    print(f"full UNet {mode}: rel-L2 vs the reference's fp16-autocast output {e_vs_auto:.3e}")
     assert err < e_auto, (err, e_auto)        # closer to fp32 than the reference's own shipped arithmetic
     assert err < FULL_BOUND, err
+    assert e_vs_auto < (err ** 2 + e_auto ** 2) ** 0.5 * 1.05, (e_vs_auto, err, e_auto)
 
 
+SMALL_BOUND = 1.5e-3   # small UNet / DDIM loop / config 1: measured 1.36-1.39e-3 / 5.1e-4 / 9.4e-4 (the reference's own autocast: 2.06e-3)
 FULL_BOUND = 1.35e-3   # measured 1.2e-3 with the fp32 residual stream (1.45e-3 without); the fp16-weight floor is 9.6e-4
 _FULL = {}
 
@@ -247,7 +254,7 @@ def test_ddim_three_steps_and_inversion_vs_oracle(small):
                               steps_limit=3)
     err = rel_l2(img.cpu(), ref)
     print(f"ddim 3 steps: rel-L2 {err:.3e}")
-    assert err < 2e-3
+    assert err < SMALL_BOUND
     assert len(inter["x_inter"]) == 4
     # inversion, 2 steps, hooks off, stores the target half device-resident
     x0 = synth.synth_normal("ddim.z2", (2 * F_, 4, h, w))
@@ -258,8 +265,10 @@ def test_ddim_three_steps_and_inversion_vs_oracle(small):
                                                    "inpaint_mask": d(torch.cat([mask] * 2))}, max_steps=2)
     rxn, rsaved = oddim.invert(lambda x, t, cc, reg: ounet.unet_forward(sd, SMALL, x, t, cc, None), 50, x0, cond2,
                                torch.cat([inp] * 2), torch.cat([mask] * 2), batch_size=F_, steps_limit=2)
-    assert rel_l2(xn.cpu(), rxn) < 2e-3
-    assert sorted(store) == [1, 21] and rel_l2(store[21].cpu(), rsaved[21]) < 2e-3
+    e_inv, e_saved = rel_l2(xn.cpu(), rxn), rel_l2(store[21].cpu(), rsaved[21])
+    print(f"ddim inversion 2 steps: rel-L2 {e_inv:.3e} (saved latent {e_saved:.3e})")
+    assert e_inv < SMALL_BOUND
+    assert sorted(store) == [1, 21] and e_saved < SMALL_BOUND
 
 
 def test_flow_resolution_mismatch_raises_like_reference(small):
@@ -474,7 +483,8 @@ def test_hipgraph_replay_equals_kernel_by_kernel_launches(small):
         eng.use_graph = True
         flow[:], c = flow_keep, c_a
         g1c = run(plans[0])
-        assert eng.use_graph, "capture fell back to the eager path"
+        assert eng.use_graph and not eng._graph_failed, "capture fell back to the eager path"
+        assert all(g["bytes"] > 0 for g in eng._graphs.values()) and sum(g["bytes"] for g in eng._graphs.values()) <= eng.graph_budget_bytes
         assert torch.equal(g1, eager[0]) and torch.equal(g1b, eager[0]) and torch.equal(g2, eager[1]) and torch.equal(gi, eager[2])
         assert torch.equal(g3, e3) and not torch.equal(g3, eager[0]) and torch.equal(g1c, eager[0])
     finally:
@@ -507,4 +517,70 @@ def test_config1_single_frame_256x256_twenty_steps_vs_oracle(small):
                           scale=3.0, eta=0.0, flow=[])
     err = rel_l2(img.cpu(), ref)
     print(f"config 1, 20 DDIM steps: rel-L2 {err:.3e}")
-    assert torch.isfinite(img).all() and err < 2e-3
+    assert torch.isfinite(img).all() and err < SMALL_BOUND
+
+
+def test_config1_full_unet_single_frame_256x256_twenty_steps_vs_oracle():
+    """BASELINE configs[0] on the REAL model: the 859.5 M-parameter UNet (project_ffhq.yaml:33-56), ONE 256 x 256 frame
+    (32 x 32 latent, F = 1: batch [uncond ; cond ; recon] = 3), the whole 20-step DDIM loop with the shipped hook schedule,
+    against the CPU oracle running the same 20 steps (60 sample-forwards of ~0.8 s).  At this resolution the UNet's bottom
+    level is 4 x 4 pixels: 3x3 convolutions at 1280 / 2560 channels on 16-pixel images and attention over n = 16 tokens at
+    head dim 160 (middle block), n = 64 / 256 / 1024 above it -- shape classes no other test reaches
+    (openaimodel.py:860-907; ddim_w_inv.py:254-355 with S = 20, SURVEY F12: inversion steps = sampling steps)."""
+    import os
+    import time
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler
+    ldm = _full_model()
+    sampler = DDIMSampler(ldm)
+    spec = ounet.UNetSpec()
+    sd = {k: v.float().cpu() for k, v in ldm.unet.state_dict().items()}
+    F_, h, w, S = 1, 32, 32, 20
+    x_T = synth.synth_normal("cfg1f.xT", (F_, 4, h, w))
+    c, uc, tc = (synth.synth_normal(f"cfg1f.{k}", (F_, 1, 768)) for k in ("c", "uc", "tc"))
+    inp = synth.synth_normal("cfg1f.inpaint", (F_, 4, h, w)) * 0.18215
+    mask = synth.synth_mask(F_, h, w)
+    inv = {int(s): synth.synth_normal(f"cfg1f.inv.{int(s)}", (F_, 4, h, w)) for s in oddim.ddim_timesteps(S)}
+    d = lambda v: v.to(DEV)
+    try:
+        img, _ = sampler.sample(S=S, batch_size=F_, shape=[4, h, w], conditioning=d(c), target_conditioning=d(tc),
+                                inverse_results_dir={k: d(v) for k, v in inv.items()}, verbose=False,
+                                unconditional_guidance_scale=3.0, unconditional_conditioning=d(uc), eta=0.0,
+                                x_T=d(x_T), flow=[], test_model_kwargs={"inpaint_image": d(inp), "inpaint_mask": d(mask)},
+                                log_every_t=1000)
+    finally:
+        sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
+    names = ounet.attn1_names(spec)
+    nthr = torch.get_num_threads()
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))   # the GPU box's share is 16 cores of a 256-thread host
+    t0 = time.time()
+    try:
+        with torch.no_grad():
+            ref, _ = oddim.sample(lambda x, t, cc, reg: ounet.unet_forward(sd, spec, x, t, cc, reg), names, S, x_T, c, uc, tc, inv,
+                                  inp, mask, scale=3.0, eta=0.0, flow=[])
+    finally:
+        torch.set_num_threads(nthr)
+    err = rel_l2(img.cpu(), ref)
+    print(f"config 1 on the 859.5M UNet, 20 DDIM steps: rel-L2 {err:.3e}  (oracle {time.time() - t0:.0f} s)")
+    assert torch.isfinite(img).all() and err < SMALL_BOUND
+
+
+@pytest.mark.parametrize("mode", ["off", "in_replace", "in_fft", "in_flow_fix", "in_fft_vfixed"])
+def test_decomposed_attn1_equals_one_call_form_bit_for_bit(small, mode):
+    """bench.py's instrumented pass issues the launches of ``vface_attn1_forward`` call by call (UNetEngine._attn1_decomposed)
+    to time the projections and the attention kernel separately: same kernels, same parameters, same order -> same bits."""
+    ldm, sampler, _ = small
+    F_, h, w = 2, 32, 32
+    x = synth.synth_normal("small.x", (6, 9, h, w)).to(DEV)
+    ctx = synth.synth_normal("small.ctx", (6, 1, 768)).to(DEV)
+    t = torch.full((6,), 481, dtype=torch.long, device=DEV)
+    flow = [synth.synth_flow(F_ - 1, h, w)[i][None] for i in range(F_ - 1)]
+    _register(sampler, mode, flow)
+    eng = ldm.unet.engine
+    try:
+        eng.decompose_attn1 = False
+        a = ldm.apply_model(x, t, ctx).clone()
+        eng.decompose_attn1 = True
+        b = ldm.apply_model(x, t, ctx).clone()
+    finally:
+        eng.decompose_attn1 = False
+    assert torch.equal(a, b), (a - b).abs().max().item()

@@ -35,10 +35,18 @@ def test_vae_vs_reference_golden(tag, res, nb):
     e1, e2 = rel_l2(z_mode, g[f"{tag}.z_mode"]), rel_l2(z_samp, g[f"{tag}.z_sample"])
     dec = m.decode(g[f"{tag}.z_sample"].to(DEV) / 0.18215).cpu()
     e3 = rel_l2(dec, g[f"{tag}.dec"])
-    print(f"VAE {tag}: z_mode {e1:.2e}  z_sample {e2:.2e}  decode {e3:.2e}")
-    # whole-network fp16 figures (30+ rounded layers each way), same scale as the whole-UNet ones; per-kernel parity
-    # is asserted at 1e-3 in test_kernels_gpu.py and below
-    assert e1 < 2e-3 and e2 < 2e-3 and e3 < 3e-3
+    # whole-network fp16 figures (30+ rounded layers each way), same scale as the whole-UNet ones; per-kernel parity is
+    # asserted at 1e-3 in test_kernels_gpu.py and below.  The bound is the reference's OWN fp16 behaviour on the same inputs
+    # (tests/golden/vae_lowp.npz, made by make_golden.py::gen_vae from the reference under torch.autocast(fp16)): this build
+    # must be at least as close to the reference's fp32 output as the reference's shipped arithmetic is (+10 %: the one
+    # case where the two coincide, the 32-channel z_sample at 8e-4).
+    lp = load_golden("vae_lowp")
+    ea = [rel_l2(lp[f"{tag}.{k}_autocast_f16"], g[f"{tag}.{k}"]) for k in ("z_mode", "z_sample", "dec")]
+    ew = [rel_l2(lp[f"{tag}.{k}_w16"], g[f"{tag}.{k}"]) for k in ("z_mode", "z_sample", "dec")]
+    print(f"VAE {tag}: z_mode {e1:.2e}  z_sample {e2:.2e}  decode {e3:.2e}   (reference under fp16 autocast: "
+          f"{ea[0]:.2e} {ea[1]:.2e} {ea[2]:.2e}; reference with fp16-rounded weights only: {ew[0]:.2e} {ew[1]:.2e} {ew[2]:.2e})")
+    for e, a in zip((e1, e2, e3), ea):
+        assert e < 1.1 * a, (e, a)
 
 
 def test_vae_bf16_measured():

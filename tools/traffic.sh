@@ -23,6 +23,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     res[c] = {k: (len(v), sum(v)) for k, v in agg.items()}
 summary = {}
 for k in sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"])):
+    if k == "other":
+        continue
     nf, f = res["FETCH_SIZE"].get(k, (0, 0.0)); nw, w = res["WRITE_SIZE"].get(k, (0, 0.0))
     n = max(nf, nw)
     summary[k] = {"launches": n, "fetch_kb_raw_per_launch": f / max(nf, 1), "write_kb_per_launch": w / max(nw, 1),
@@ -36,7 +38,10 @@ tot3 = sum(v["launches"] for v in p3)
 if tot3:
     summary["_conv_patch3"] = {"launches": tot3, "hbm_bytes_per_launch": sum(v["hbm_bytes_per_launch"] * v["launches"] for v in p3) / tot3,
                                "note": "conv_patch_kernel<.., 3, 3, ..> launches of every residual form, without the 8x8 form (the dominant kernel bench.py prices)"}
+sys.path.insert(0, R)
+from vface_amd.utils.buildinfo import source_sha16
+summary["_build"] = {"source_sha16": source_sha16(), "note": "sha256[:16] of vface_amd/csrc/{*.hip,*.hpp,*.cpp,Makefile}: bench.py quotes these figures only on the same sources"}
 json.dump(summary, open(out, "w"), indent=1)
 for k, v in summary.items():
-    print(k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in v.items()})
+    print(k, {a: (round(b, 1) if isinstance(b, float) else b) for a, b in v.items()} if isinstance(v, dict) else v)
 PY

@@ -404,13 +404,8 @@ int launch(const AttnParams& p, hipStream_t stream) {
     constexpr int KROW = k_row_elems(DKP), VROW = v_pitch_bytes(DVP) / 2;
     constexpr size_t lds = (size_t)(2 * KVB * KROW + 2 * KVB * VROW) * 2;
     auto kern = attn_kernel<TT, DH, QT, G, LAZY>;
-    static bool attr_set = false;
-    if (lds > 64 * 1024 && !attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return VF_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static VfOncePerDevice attr_set;
+    if (lds > 64 * 1024 && !attr_set.set_lds(reinterpret_cast<const void*>(kern), (int)lds)) return VF_ERR_LAUNCH;
     dim3 grid(((p.n + 64 * QT - 1) / (64 * QT)) * p.heads * p.B);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;

@@ -88,15 +88,8 @@ int vface_conv_uses_patch_kernel(int H, int W, int Cin, int Cout, int window, in
     GemmParams p{};
     p.mode = 1; p.H = H; p.W = W; p.OH = H; p.OW = W; p.Cin = Cin; p.N = Cout; p.stride = stride; p.upsample = upsample ? 1 : 0;
     p.KH = p.KW = window; p.ntaps = window * window; p.pad = 1; p.pad_x = 1; p.flags = flags;
-    if (stride != 1) return 0;
-    if (flags & (GEMM_NO_PATCH | (0xF << 8))) return 0;
-    if (window == 3 && !upsample && H == 8 && W == 8 && !(flags & GEMM_NO_Q8)) {
-        p.K = p.K1 = 9 * Cin; p.rows_per_sample = 64;
-        if (vf_conv_q8_split(p)) return 2;       // the 8x8 form (needs the split-K workspace every wrapper passes)
-    }
-    const int bn = vf_conv_patch_tile(p);
-    if (!bn) return 0;
-    return (24L * (H / 16) * (W / 16) * (Cout / bn) >= 160 || (flags & GEMM_PATCH)) ? 1 : 0;
+    p.K = p.K1 = p.ntaps * Cin; p.rows_per_sample = H * W; p.M = 24 * H * W;
+    return vf_conv_kernel_choice(p, nullptr);     // the launcher's own rule (conv.hip), not a restatement of it
 }
 
 int vface_conv3x3_plus_1x1(const void* X, int64_t ldx, int nimg, int H, int W, int Cin, const void* X2, int64_t ldx2, int C2,

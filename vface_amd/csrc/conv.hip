@@ -632,12 +632,8 @@ int launch_patch(const GemmParams& p, hipStream_t stream) {
     if constexpr (KH == 3) {
         if (p.gn_ab) { kern = conv_patch_kernel<TT, NT, KH, KW, false, true>; which = 4; }       // fused GroupNorm-apply + SiLU
     }
-    static bool attr_set[5] = {false, false, false, false, false};
-    if (!attr_set[which]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return VF_ERR_LAUNCH;
-        attr_set[which] = true;
-    }
+    static VfOncePerDevice attr_set[5];
+    if (!attr_set[which].set_lds(reinterpret_cast<const void*>(kern), (int)lds)) return VF_ERR_LAUNCH;
     const int ntm = (p.M / (p.OH * p.OW)) * (p.H / TP) * (p.W / TP), ntn = p.N / BN;
     // Column-group width of the tile order.  An XCD (own L2) works through tiles_xcd = ntm * ntn / 8 consecutive tiles = a block
     // of (tiles_xcd / GN) m-tiles x GN n-tiles, and fetches that block's patches and weight panels once: bytes per XCD =
@@ -667,12 +663,8 @@ int launch_q8(const GemmParams& p, hipStream_t stream) {
     constexpr int NT = 4, BN = 128, NPIECES = 50;
     const size_t lds = 2 * (size_t)NPIECES * 1024 + 3 * (size_t)BN * 128 + 2048;
     auto kern = conv_patch_kernel<TT, NT, 3, 3, false, false, 0, true>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return VF_ERR_LAUNCH;
-        attr_set = true;
-    }
+    static VfOncePerDevice attr_set;
+    if (!attr_set.set_lds(reinterpret_cast<const void*>(kern), (int)lds)) return VF_ERR_LAUNCH;
     const int nimg = p.M / 64, ntm = (nimg + 3) / 4, ntn = p.N / BN;
     hipLaunchKernelGGL(kern, dim3(ntm * ntn * p.split_k), dim3(512), lds, stream, p);
     return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
@@ -706,6 +698,26 @@ int vf_launch_conv_q8(const GemmParams& p, int dtype, hipStream_t stream) {
 
 namespace {
 }  // namespace
+
+// THE rule for which kernel a convolution launch runs -- 0: gemm.hip's implicit GEMM, 1: the patch-staged kernel (*arg = channel-tile
+// width), 2: its 8x8 form (*arg = K split; the launcher additionally needs the caller's split-K workspace, which every wrapper
+// passes).  vf_launch_gemm dispatches on it and vface_conv_uses_patch_kernel (what bench.py prices launches by and the engine
+// decides GroupNorm fusion by) reports it: one copy, so the two cannot drift apart.  Geometry and flags only, grid depth at the
+// nominal 24-sample batch: a sample's bits never depend on which other samples share its launch.
+int vf_conv_kernel_choice(const GemmParams& p, int* arg) {
+    if (arg) *arg = 0;
+    if (p.mode != 1 || ((p.flags >> 8) & 0xF) || (p.flags & GEMM_NO_PATCH)) return 0;
+    const int bn = vf_conv_patch_tile(p);
+    if (bn) {
+        const long tiles24 = 24L * (p.H / TP) * (p.W / TP) * (p.N / bn);
+        if (tiles24 >= 160 || (p.flags & GEMM_PATCH)) { if (arg) *arg = bn; return 1; }
+    }
+    if (!(p.flags & GEMM_NO_Q8)) {
+        const int s = vf_conv_q8_split(p);
+        if (s) { if (arg) *arg = s; return 2; }
+    }
+    return 0;
+}
 
 // 0 = this launch is not a patch-kernel shape; else the channel-tile width (160 | 128) the launch would use
 int vf_conv_patch_tile(const GemmParams& p) {

@@ -886,15 +886,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmParams p) {
 
 // workgroups a persistent launch keeps resident: 2 per CU (LDS 64-74 KB and <= 256 VGPRs each)
 int persistent_grid() {
-    static int g = 0;
-    if (!g) {
+    static std::atomic<int> g{0};
+    int v = g.load(std::memory_order_relaxed);
+    if (!v) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
-        g = 2 * cus;
-        g -= g % 8;   // whole rounds of the 8 XCDs
+        v = 2 * cus;
+        v -= v % 8;   // whole rounds of the 8 XCDs
+        g.store(v, std::memory_order_relaxed);   // (every MI355X of a node has the same CU count)
     }
-    return g;
+    return v;
 }
 
 template <class TT, int MODE, int NT, bool DB>
@@ -918,13 +920,8 @@ int launch_one(const GemmParams& p, hipStream_t stream) {
         which = persist ? 2 : 0;
         kern = persist ? gemm_kernel<TT, MODE, NT, DB, DB> : gemm_kernel<TT, MODE, NT, DB, false>;
     }
-    static bool attr_set[6] = {false, false, false, false, false, false};
-    if (lds > 64 * 1024 && !attr_set[which]) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return VF_ERR_LAUNCH;
-        attr_set[which] = true;
-    }
+    static VfOncePerDevice attr_set[6];
+    if (lds > 64 * 1024 && !attr_set[which].set_lds(reinterpret_cast<const void*>(kern), (int)lds)) return VF_ERR_LAUNCH;
     dim3 grid(persist ? persistent_grid() : ntiles * p.split_k);
     GemmParams q = p;
     if (MODE == MODE_PLAIN && p.split_k == 1 && !p.tile_group) {
@@ -1081,17 +1078,13 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         if (gb >= 0xFFFFFFF0ul) return VF_ERR_SHAPE;
         p.gn_ab_bytes = (unsigned)gb;
     }
-    if (p.mode == 1 && !((p.flags >> 8) & 0xF) && !(p.flags & GEMM_NO_PATCH)) {
-        const int bn = vf_conv_patch_tile(p);
-        if (bn) {
-            const long tiles24 = 24L * (p.H / 16) * (p.W / 16) * (p.N / bn);   // (the same rule: capi.cpp vface_conv_uses_patch_kernel)
-            if (tiles24 >= 160 || (p.flags & GEMM_PATCH)) return vf_launch_conv_patch(p, dtype, stream);
-        }
-    }
-    if (p.mode == 1 && p.workspace && !(p.flags & GEMM_NO_Q8)) {
+    int karg = 0;
+    const int kchoice = vf_conv_kernel_choice(p, &karg);      // (conv.hip: the one statement of the rule)
+    if (kchoice == 1) return vf_launch_conv_patch(p, dtype, stream);
+    if (kchoice == 2 && p.workspace) {
         // the 8x8 level: four images per workgroup through the patch-staged kernel, K split over channel chunks, then the
         // ordinary split-K reduce (which runs the whole epilogue)
-        const int s = vf_conv_q8_split(p);
+        const int s = karg;
         if (s && p.workspace_bytes >= (long)s * p.M * p.N * 4 && !((uintptr_t)p.workspace & 15) && (p.M % 64) == 0 &&
             !(p.residual && (((uintptr_t)p.residual & 15) || (p.ldr & 7))) && !(p.ldc & 7) && !((uintptr_t)p.C & 15)) {
             p.split_k = s;

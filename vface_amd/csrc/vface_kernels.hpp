@@ -3,6 +3,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting of a kernel: one bit per device ordinal, set with an
+// atomic OR (two host threads launching the same kernel for the first time both set the attribute -- idempotent -- and neither
+// skips it; a process that drives a second GPU sets it there too)
+struct VfOncePerDevice {
+    std::atomic<unsigned long long> done{0};
+    bool set_lds(const void* kern, int bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (done.load(std::memory_order_acquire) & bit) return true;
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+        done.fetch_or(bit, std::memory_order_release);
+        return true;
+    }
+};
+
 enum { GEMM_GEGLU = 1, GEMM_OUT_F32 = 2, GEMM_NO_XCD_REMAP = 0x1000, GEMM_NO_SETPRIO = 0x2000, GEMM_NARROW_EPILOGUE = 0x8000, GEMM_NO_PERSIST = 0x10000, GEMM_PERSIST = 0x20000,
        GEMM_NO_PATCH = 0x80000, GEMM_PATCH = 0x100000, GEMM_GN8 = 0x8000000 /* A/B: fixed column groups of 8 n-tiles in the plain GEMM's tile order */, GEMM_NO_Q8 = 0x4000000 /* A/B: the 8x8 level stays on the im2col kernel */, GEMM_PATCH_BN160 = 0x2000000 /* A/B: the patch kernel's 160-wide tile wherever it divides N */, GEMM_F32_TRANSPOSE = 0x1000000 /* A/B: epilogue transposes in fp32 even where 16 bits would do */ };  // (0x40000 = VFACE_CONV_PAD_TRAILING)  // bits 8..11 of flags: forced schedule variant (0 = automatic)
 
@@ -59,6 +77,7 @@ bool vf_gemm_variants_built();
 int vf_launch_gemm(const GemmParams& p, int dtype, hipStream_t stream);
 // conv.hip: the patch-staged stride-1 convolution; vf_conv_patch_tile = 0 (not a patch shape) | 160 | 128
 int vf_conv_patch_tile(const GemmParams& p);
+int vf_conv_kernel_choice(const GemmParams& p, int* arg);                        // 0 im2col | 1 patch (*arg = tile width) | 2 8x8 form (*arg = K split)
 int vf_launch_conv_patch(const GemmParams& p, int dtype, hipStream_t stream);
 int vf_gemm_patch_tile(const GemmParams& p);                                   // plain GEMM through the patch kernel's 256-row tile: 0 | 160 | 128
 int vf_launch_gemm_patch(const GemmParams& p, int dtype, hipStream_t stream);

@@ -21,6 +21,8 @@ from __future__ import annotations
 import os
 
 import math
+
+import numpy as np
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence
 
@@ -260,6 +262,78 @@ def _phase_form_pays(hw_in: int, cout: int) -> bool:
     return (24 * hw_in // 128) * (cout // 128) >= 400
 
 
+class _GraphSegments:
+    """Capture of one UNet forward as a chain of hipGraphs sharing ONE memory pool, cut wherever the forward calls the
+    frame-shard exchange (``start_exchange`` / ``finish_exchange``): those two calls are host-issued RCCL operations and run
+    BETWEEN segment replays, on the same stream, in the captured order.  Installed as the engine's ``halo_exchange`` while
+    capturing.  Buffers the captured launches exchange with the host calls have fixed addresses: the slab to send is a view
+    of a pool tensor; the slab received lands in a persistent ``recv`` buffer owned by this object (the inner exchange
+    receives straight into it where it can -- RCCL p2p -- otherwise its result is copied there).
+    An unsharded forward is the degenerate case: one segment, no host call."""
+
+    def __init__(self, engine, inner):
+        self.engine, self.inner = engine, inner
+        self.stream = torch.cuda.Stream()
+        self.pool = torch.cuda.graph_pool_handle()
+        self.segments: list = []      # [(CUDAGraph, host_op | None)]
+        self.keep: list = []          # tensors the host ops refer to
+        self.cur = None
+        # what the engine reads from its exchange object
+        if inner is not None:
+            self.rank, self.world, self.first, self.count = inner.rank, inner.world, inner.first, inner.count
+
+    def begin(self):
+        self.cur = torch.cuda.CUDAGraph()
+        # (thread_local: a collective backend's watchdog thread may poll events while this thread captures)
+        self.cur.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+
+    def end(self, host_op):
+        self.cur.capture_end()
+        self.segments.append((self.cur, host_op))
+        self.cur = None
+
+    def abort(self):
+        if self.cur is not None:
+            try:
+                self.cur.capture_end()
+            except Exception:
+                pass
+            self.cur = None
+
+    # ---- the exchange interface (parallel.FrameShard), as seen by UNetEngine._attn1_sharded while capturing
+    def start_exchange(self, tail: torch.Tensor):
+        inner, state = self.inner, {}
+        recv = torch.empty_like(tail) if inner.rank > 0 else None      # (allocated in the shared pool: lives with the graphs)
+        self.keep += [tail, recv, state]
+
+        def op():
+            state["h"] = inner.start_exchange(tail, recv=recv)
+        self.end(op)
+        op()                       # the capture pass exchanges for real too (garbage slabs): the ranks' calls stay paired
+        self.begin()
+        return (state, recv)
+
+    def finish_exchange(self, handle):
+        state, recv = handle
+        inner, eng = self.inner, self.engine
+
+        def op():
+            ev = eng.exchange_events
+            if ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            halo = inner.finish_exchange(state.pop("h"))
+            if halo is not None and recv is not None and halo.data_ptr() != recv.data_ptr():
+                recv.copy_(halo)
+            if ev is not None:
+                e1.record()
+                ev.append((e0, e1))
+        self.end(op)
+        op()
+        self.begin()
+        return recv
+
+
 class UNetEngine:
     """Packed weights + kernel sequencing for one ``UNetModel``."""
 
@@ -275,6 +349,8 @@ class UNetEngine:
         self.halo_exchange = None
         self.halo_flow: Optional[torch.Tensor] = None  # flow from the previous rank's last frame into our frame 0
         self.halo_hw = None                            # (h, w) of the clip's flow fields (set with halo_exchange)
+        self.exchange_events = None                    # a list: (start, end) HIP events around every finish_exchange (bench.py)
+        self.decompose_attn1 = False                   # bench.py's instrumented pass: vface_attn1_forward's launches call by call
         # fp32 residual stream: residual sums are carried between kernels in fp32, 16-bit copies exist only
         # where a matrix-core operand needs them.  VFACE_STREAM32=0 restores the all-16-bit activations (A/B switch).
         self.stream32 = os.environ.get("VFACE_STREAM32", "1") != "0"
@@ -285,12 +361,18 @@ class UNetEngine:
         # the ~70 vector instructions per 1-KiB patch piece sit in the K-tile period's critical path -- 28.22 vs 27.49 ms per
         # DDIM step (conv 9.46 vs 7.77 ms, gn_apply 0 vs 1.0 ms), DESIGN 4 -- so it is opt-in.
         self.fuse_gn = os.environ.get("VFACE_FUSE_GN", "off")
-        # hipGraph replay of the UNet forward of a DDIM step (step_forward_nhwc): "1" = capture once per (batch, resolution,
-        # hook configuration, context) and replay; "0" (default) = launch kernel by kernel.  The C ABI is allocation-free and
-        # stream-ordered, so the captured graph is exactly the eager launch sequence.
-        self.use_graph = os.environ.get("VFACE_GRAPH", "0") == "1"
+        # hipGraph replay of the UNet forward of a DDIM step (step_forward_nhwc): capture once per (batch, resolution, hook
+        # configuration, context shape) and replay -- the default since round 3 (bit-equal to kernel-by-kernel launches, one
+        # host call per step instead of ~1200; what bench.py times); VFACE_GRAPH=0 launches kernel by kernel.  The C ABI is
+        # allocation-free and stream-ordered, so the captured graph is exactly the eager launch sequence.  Every cached graph
+        # pins a private pool with the activations of one forward (~0.45 GB per frame at 512 x 512): the cache is bounded by
+        # BYTES (VFACE_GRAPH_GB, default 64 of the 288 GB) and by count, least recently used first; a forward whose pool alone
+        # exceeds the budget is not cached and runs kernel by kernel.
+        self.use_graph = os.environ.get("VFACE_GRAPH", "1") != "0"
         self._graphs: "Dict[tuple, dict]" = {}
+        self._graph_failed: set = set()       # keys whose capture failed: they run kernel by kernel, other keys still capture
         self.graph_capacity = 4
+        self.graph_budget_bytes = int(float(os.environ.get("VFACE_GRAPH_GB", "64")) * (1 << 30))
         hip.load()
 
     # ------------------------------------------------------------------ weights
@@ -567,12 +649,56 @@ class UNetEngine:
         if hw is not None and self.halo_exchange is not None:
             # every rank of a sharded clip takes part in the boundary exchange, a one-frame shard (no local field) too
             return self._attn1_sharded(xln, res_kw, p, wlin, a2vec, N, n, heads, flow, hw, alpha, out)
+        if self.decompose_attn1:
+            self._attn1_decomposed(xln, p, wlin, a2vec, N, n, heads, chunks, fusion, v_fixed, flow if hw is not None else None,
+                                   hw, alpha, qk_map, v_map, out, res_kw)
+            return out32 if s32 else out
         hip.attn1_forward(xln, p["wqkv"], wlin, p["wo"]["w"], p["wo"]["b"], out, B=N, n=n, d=d, heads=heads,
                           chunks=chunks, fusion=fusion, ldx=xln.stride(0), ldo=d, workspace=ws,
                           rowbias=a2vec, v_fixed=v_fixed, flow=flow if hw is not None else None,
                           h=hw[0] if hw else 0, w=hw[1] if hw else 0,
                           alpha=alpha, qk_map=qk_map, v_map=v_map, **res_kw)
         return out32 if s32 else out
+
+    def _attn1_decomposed(self, xln, p, wlin, a2vec, N, n, heads, chunks, fusion, v_fixed, flow, hw, alpha, qk_map, v_map,
+                          out, res_kw):
+        """The launch sequence of ``vface_attn1_forward`` (capi.cpp) issued call by call from here -- the same kernels with the
+        same parameters in the same order, hence the same bits (tests/test_kernels_gpu.py) -- so that ``bench.py``'s
+        instrumented pass can put HIP events around the projections and the attention kernel separately."""
+        d = p["c"]
+        F_ = N // chunks
+        Fn = F_ * n
+        ldx = xln.stride(0)
+        qkv = self._new(N * n, 3 * d)
+        g = lambda a, w, o, M, Nn, K, **kw: hip.gemm(a, w, o, M=M, N=Nn, K=K, lda=ldx, ldc=o.stride(0), ldw=w.stride(0),
+                                                      split_k=False, **kw)
+        if fusion == hip.FUSION_NONE:
+            g(xln, p["wqkv"], qkv, N * n, 3 * d, d)
+        else:
+            g(xln, p["wqkv"], qkv, Fn, 3 * d, d)
+            g(xln[Fn:], p["wqkv"][2 * d:], qkv[Fn:, 2 * d:], N * n - Fn, d, d)
+            if fusion == hip.FUSION_LINEAR:
+                T = self._new(Fn, 2 * d) if flow is not None else None
+                for c in range(1, chunks):
+                    dst = T if (flow is not None and c == 1) else qkv[c * Fn:(c + 1) * Fn, :2 * d]
+                    g(xln[c * Fn:], wlin, dst, Fn, 2 * d, 2 * d, a2=xln, lda2=ldx, k1=d)
+                if flow is not None:
+                    hip.flow_warp(T, qkv[Fn:2 * Fn, :2 * d], flow, F=F_, h=hw[0], w=hw[1], C_=2 * d, ld_src=2 * d,
+                                  fs_src=n * 2 * d, ld_dst=3 * d, fs_dst=n * 3 * d, alpha=alpha)
+        att = self._new(N * n, d)
+        kw = dict(heads=heads, n=n, nk=n, dh=d // heads, ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d,
+                  bsv=n * 3 * d, ldo=d, bso=n * d,
+                  scale=float(np.float32(1.0) / np.sqrt(np.float32(d // heads))))   # fp32 arithmetic, as capi.cpp computes it
+        if fusion == hip.FUSION_REPLACE and hip.load().vface_attention_shared_scores_supported(d // heads, chunks):
+            hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=F_, v_map=v_map if v_fixed else None, v_sets=chunks,
+                          set_stride=F_, **kw)
+        else:
+            hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=N, qk_map=qk_map if fusion == hip.FUSION_REPLACE else None,
+                          v_map=v_map if v_fixed else None, **kw)
+        o = out if out is not None else res_kw["out32"]
+        hip.gemm(att, p["wo"]["w"], out, M=N * n, N=d, K=d, lda=d, ldc=out.stride(0) if out is not None else 0,
+                 bias=p["wo"]["b"], rowbias=a2vec, rows_per_sample=n, split_k=False, **res_kw)
+        return o
 
     def _attn1_sharded(self, xln, res_kw, p, wlin, a2vec, N, n, heads, flow, hw, alpha, out):
         """flow_fix with frames sharded across ranks: the same kernels as vface_attn1_forward, sequenced here
@@ -593,7 +719,14 @@ class UNetEngine:
         hip.gemm(xln, p["wqkv"], qkv, M=Fn, N=3 * d, K=d, lda=xln.stride(0), ldc=3 * d)
         hip.gemm(xln[Fn:], p["wqkv"][2 * d:], qkv[Fn:, 2 * d:], M=N * n - Fn, N=d, K=d, lda=xln.stride(0), ldc=3 * d)
         fused(2, qkv[2 * Fn:, :2 * d])
+        ev = self.exchange_events if not isinstance(self.halo_exchange, _GraphSegments) else None
+        if ev is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         halo = self.halo_exchange.finish_exchange(handle)
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1))
         dst = qkv[Fn:2 * Fn, :2 * d]
         hip.flow_warp(T, dst, flow, F=F_, h=hw[0], w=hw[1], C_=2 * d, ld_src=2 * d, fs_src=n * 2 * d,
                       ld_dst=3 * d, fs_dst=n * 3 * d, alpha=alpha, prev=halo, ld_prev=2 * d,
@@ -780,17 +913,24 @@ class UNetEngine:
         same kernels on the same buffers, one host call per step instead of ~1200 (ddim_w_inv.py:299-305 calls the UNet once
         per step with nothing but x and t changing).  What changes between steps or clips is copied into the graph's own
         input buffers: x, t every step; the context projections and the flow fields when a new clip brings new tensors.
-        The returned eps is the graph's output buffer: consume it before the next call.  Frame-sharded engines (RCCL
-        point-to-point exchange inside the forward) and any capture failure run the eager path."""
-        if not self.use_graph or self.halo_exchange is not None or x.t32 is not None:
+        The returned eps is the graph's output buffer: consume it before the next call.
+        A frame-sharded engine (``halo_exchange`` installed: RCCL point-to-point exchange inside the forward) is captured as
+        graph SEGMENTS cut at the exchange calls -- [.. fused q|k of chunk 1] send/recv [projections it overlaps] wait
+        [warp, attention, .. next hooked layer ..] -- with the two ``isend/irecv`` + ``wait`` pairs issued from the host between
+        segment replays (5 segments and 4 host calls per step instead of ~1200 launches).  Any capture failure runs the eager
+        path for that configuration."""
+        if not self.use_graph or x.t32 is not None:
             return self.forward_nhwc(x, timesteps, context)
         self._ensure_packed()
         sig, flows = self._hook_signature()
+        ex = self.halo_exchange
+        shard_sig = None if ex is None else (id(ex), ex.rank, ex.world, ex.first, ex.count, self.halo_hw,
+                                             None if self.halo_flow is None else self.halo_flow.data_ptr())
         key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, sig,
-               tuple(context.shape), torch.cuda.current_stream().cuda_stream)
+               tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)
         if g is None:
-            g = self._capture(key, x, timesteps, context, flows)
+            g = None if key in self._graph_failed else self._capture(key, x, timesteps, context, flows)
             if g is None:
                 return self.forward_nhwc(x, timesteps, context)
         else:
@@ -806,7 +946,10 @@ class UNetEngine:
                 g["flow_keep"][id(dst)] = src
         g["x"].copy_(x.t)
         g["t"].copy_(timesteps)
-        g["graph"].replay()
+        for graph, host_op in g["segments"]:
+            graph.replay()
+            if host_op is not None:
+                host_op()
         return g["eps"]
 
     def _capture(self, key, x: Act, timesteps: torch.Tensor, context: torch.Tensor, flows):
@@ -824,35 +967,61 @@ class UNetEngine:
         own_flows = [f.clone() for f in flows]
         saved_flows = [c.flow for c in cfgs]
         saved_cache = getattr(self, "_a2_cache", None)
+        real_exchange = self.halo_exchange
+        seg = None
         try:
             a2 = self.context_projections(context, x.N).clone()
             self._a2_cache = (context, context._version, self._packed, a2)
             for c in cfgs:
                 c.flow = own_flows[next(i for i, f in enumerate(flows) if f is c.flow)]
             # warm-up on a side stream (the documented capture recipe): fills the folded-weight caches, sets every kernel's
-            # shared-memory attribute, and brings the allocator to its steady state
+            # shared-memory attribute, and brings the allocator to its steady state.  (Sharded: a real forward with real
+            # exchanges -- every rank of the clip captures at the same step, so the calls pair up.)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self.forward_nhwc(Act(xs, x.N, x.H, x.W), ts, context)
             torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            # (thread_local: a collective backend's watchdog thread may poll events while this thread captures)
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            # the captured launches write to the split-K workspace / read the zero page that exist NOW: the warm-up above must
+            # have grown them to their final size (hip.py grows by REPLACING the tensor)
+            ws_before = {k: v.data_ptr() for k, v in hip._splitk_ws.items()}
+            z_before = {k: v.data_ptr() for k, v in hip._zeros.items()}
+            torch.cuda.synchronize()
+            mem0 = torch.cuda.memory_allocated(self.device)
+            seg = _GraphSegments(self, real_exchange)
+            if real_exchange is not None:
+                self.halo_exchange = seg             # start_exchange / finish_exchange cut the capture (see _GraphSegments)
+            with torch.cuda.stream(seg.stream):
+                seg.begin()
                 eps = self.forward_nhwc(Act(xs, x.N, x.H, x.W), ts, context)
+                seg.end(None)
+            torch.cuda.current_stream().wait_stream(seg.stream)
+            pool_bytes = max(0, torch.cuda.memory_allocated(self.device) - mem0)
+            if {k: v.data_ptr() for k, v in hip._splitk_ws.items()} != ws_before or \
+                    {k: v.data_ptr() for k, v in hip._zeros.items()} != z_before:
+                raise RuntimeError("the split-K workspace / zero page was re-allocated during capture (warm-up did not reach the steady state)")
         except Exception as e:  # capture is an optimisation of the same launch sequence: the eager path is the same code
             import warnings
+            if seg is not None:
+                seg.abort()
             warnings.warn(f"vface_amd: hipGraph capture of the UNet forward failed ({type(e).__name__}: {e}); "
-                          "running kernel by kernel")
-            self.use_graph = False
+                          "this configuration runs kernel by kernel")
+            self._graph_failed.add(key)
             return None
         finally:
+            self.halo_exchange = real_exchange
             for c, f in zip(cfgs, saved_flows):
                 c.flow = f
             self._a2_cache = saved_cache
-        while len(self._graphs) >= self.graph_capacity:
-            self._graphs.pop(next(iter(self._graphs)))
-        g = {"graph": graph, "x": xs, "t": ts, "eps": eps, "a2": a2, "ctx_id": (id(context), context._version),
+        if pool_bytes > self.graph_budget_bytes:      # one forward larger than the whole budget: do not pin it
+            self._graph_failed.add(key)
+            del seg, eps
+            return None
+        while self._graphs and (len(self._graphs) >= self.graph_capacity or
+                                sum(v["bytes"] for v in self._graphs.values()) + pool_bytes > self.graph_budget_bytes):
+            self._graphs.pop(next(iter(self._graphs)))      # least recently used first
+        g = {"segments": seg.segments, "keep": seg.keep, "bytes": pool_bytes, "x": xs, "t": ts, "eps": eps, "a2": a2,
+             "ctx_id": (id(context), context._version),
              "ctx_keep": context, "flows": own_flows, "flow_ids": {id(d): (id(s_), s_._version) for d, s_ in zip(own_flows, flows)},
              "flow_keep": {id(d): s_ for d, s_ in zip(own_flows, flows)}, "packed": self._packed,
              # the split-K workspace the captured launches write to (hip.py grows it by REPLACING the tensor: keep this one alive)

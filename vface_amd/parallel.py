@@ -44,8 +44,10 @@ class FrameShard:
         return global_flow[self.first - 1]
 
     # ---- the boundary exchange
-    def start_exchange(self, tail: torch.Tensor):
-        """Send this shard's last-frame slab to rank+1 and start receiving rank-1's.  Returns a handle."""
+    def start_exchange(self, tail: torch.Tensor, recv: Optional[torch.Tensor] = None):
+        """Send this shard's last-frame slab to rank+1 and start receiving rank-1's.  Returns a handle.
+        ``recv``: a persistent receive buffer shaped like ``tail`` (the hipGraph-segmented forward bakes its address into
+        the captured warp launch); default: a fresh one per call."""
         if self.world == 1:
             return None
         d = self.dist
@@ -70,7 +72,7 @@ class FrameShard:
         if self.rank + 1 < self.world:
             ops.append(d.P2POp(d.isend, tail.contiguous(), self.rank + 1))
         if self.rank > 0:
-            halo = torch.empty_like(tail)
+            halo = recv if recv is not None else torch.empty_like(tail)
             ops.append(d.P2POp(d.irecv, halo, self.rank - 1))
         works = d.batch_isend_irecv(ops) if ops else []
         return ("p2p", works, halo)
@@ -91,6 +93,10 @@ class FrameShard:
         for w in work:
             w.wait()
         return buf
+
+    def slab_bytes_per_step(self, n: int, d: int, layers: int = 2, elem: int = 2) -> int:
+        """Bytes this rank SENDS per DDIM step: one ``[n, 2d]`` slab per hooked level-0 layer (none from the last rank)."""
+        return 0 if self.rank + 1 >= self.world else layers * n * 2 * d * elem
 
     def install(self, engine, global_flow: torch.Tensor, device) -> None:
         """Hook the exchange into a ``UNetEngine`` (used by flow_fix layers only)."""
@@ -118,7 +124,7 @@ class LoopbackShard(FrameShard):
         self.store[self.rank] = []
         self._next = 0
 
-    def start_exchange(self, tail: torch.Tensor):
+    def start_exchange(self, tail: torch.Tensor, recv=None):
         if self.world == 1:
             return None
         self.store[self.rank].append(tail.detach().clone())

@@ -69,7 +69,9 @@ def build_parser() -> argparse.ArgumentParser:
                         "h*w of the flow field (needed for the module to act at e.g. 768x768)")
     p.add_argument("--compute_dtype", choices=["fp16", "bf16"], default="fp16")
     p.add_argument("--hip_graph", action="store_true",
-                   help="replay each DDIM step's UNet forward from a hipGraph (one capture per clip shape and hook plan)")
+                   help="(default since round 3; kept for older command lines) replay each DDIM step's UNet forward from a "
+                        "hipGraph: one capture per clip shape and hook plan, bit-equal to kernel-by-kernel launches")
+    p.add_argument("--no_hip_graph", action="store_true", help="launch every kernel of a step from the host (VFACE_GRAPH=0)")
     p.add_argument("--max_steps", type=int, default=None, help="stop after this many DDIM steps (smoke runs)")
     return p
 
@@ -82,6 +84,72 @@ def load_unet_config(path):
     with open(path) as f:
         cfg = yaml.safe_load(f)
     return dict(cfg["model"]["params"]["unet_config"]["params"])
+
+
+class _StubUnpickler:
+    """``pickle_module`` for ``torch.load`` of a checkpoint written by the reference's pytorch_lightning==1.4.2
+    (``REFace/environment.yml``): its ``callbacks`` / ``hyper_parameters`` entries pickle CLASS objects (the ModelCheckpoint
+    class as a dict key) and omegaconf containers, which ``weights_only=True`` rejects and which are not importable here.
+    Tensors, storages and plain containers unpickle as usual; every other global becomes an inert placeholder class -- no
+    foreign constructor or ``__setstate__`` ever runs, so this is as safe as ``weights_only`` and strictly more tolerant."""
+    import pickle as _pickle
+
+    class Unpickler(_pickle.Unpickler):
+        _stubs: dict = {}
+
+        def find_class(self, module, name):
+            root = module.split(".")[0]
+            if root in ("torch", "collections", "builtins", "numpy", "_codecs") and not (root == "builtins" and name in (
+                    "eval", "exec", "compile", "open", "__import__", "getattr", "setattr", "delattr", "input", "breakpoint")):
+                return super().find_class(module, name)
+            key = (module, name)
+            if key not in self._stubs:
+                def _new(cls, *a, **k):
+                    return object.__new__(cls)
+                self._stubs[key] = type(name, (), {"__module__": module, "__new__": _new, "__init__": lambda self, *a, **k: None,
+                                                   "__setstate__": lambda self, st: None, "__call__": lambda self, *a, **k: None,
+                                                   "append": lambda self, *a: None, "extend": lambda self, *a: None,
+                                                   "__setitem__": lambda self, *a: None})
+            return self._stubs[key]
+
+    @staticmethod
+    def load(f, **kw):
+        return _StubUnpickler.Unpickler(f, **kw).load()
+
+    @staticmethod
+    def loads(b, **kw):
+        import io
+        return _StubUnpickler.Unpickler(io.BytesIO(b), **kw).load()
+
+    __name__ = "vface_stub_pickle"
+
+
+def load_checkpoint(model, path: str, with_vae: bool = False) -> str:
+    """Load ``last.ckpt`` of the reference (``VFace_inference_batch.py:118-135``: ``torch.load`` -> ``["state_dict"]`` ->
+    ``load_state_dict(strict=False)``) into ``model``.  Only the keys of what this build runs are taken:
+    ``model.diffusion_model.*`` always, ``first_stage_model.*`` when the first stage was built (``with_vae``); the CLIP /
+    ArcFace / landmark conditioning weights of a full LDM checkpoint are outside the path and ignored.  Unlike the reference's
+    non-strict load, a checkpoint that does not cover every parameter of the path raises instead of silently running on
+    default-initialised weights."""
+    import pickle
+    try:
+        ck = torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError:
+        # Lightning checkpoints carry class-keyed callback state: retry with placeholders for every non-tensor global
+        ck = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_StubUnpickler)
+    sd = ck.get("state_dict", ck) if isinstance(ck, dict) else ck
+    prefixes = ("model.diffusion_model.",) + (("first_stage_model.",) if with_vae else ())
+    taken = {k: v for k, v in sd.items() if k.startswith(prefixes) and torch.is_tensor(v)}
+    if not taken:
+        raise RuntimeError(f"{path}: no key starts with {prefixes} -- not an LDM checkpoint of this model "
+                           f"(first keys: {list(sd)[:5]})")
+    missing, unexpected = model.load_state_dict(taken, strict=False)
+    hot = [k for k in missing if k.startswith(prefixes)]
+    if hot or unexpected:
+        raise RuntimeError(f"{path}: {len(hot)} parameter(s) of the denoising path missing (first: {hot[:5]}), "
+                           f"{len(unexpected)} unexpected key(s) (first: {list(unexpected)[:5]})")
+    return (f"loaded {path}: {len(taken)} tensors under {', '.join(prefixes)} matched every parameter of the path "
+            f"({len(sd) - len(taken)} checkpoint entries outside it ignored)")
 
 
 def run_synthetic(opt) -> dict:
@@ -99,16 +167,7 @@ def run_synthetic(opt) -> dict:
     else:
         model = LatentDiffusion(cfg)
     if opt.ckpt:
-        sd = torch.load(opt.ckpt, map_location="cpu", weights_only=True)
-        sd = sd.get("state_dict", sd)
-        missing, unexpected = model.load_state_dict(
-            {k: v for k, v in sd.items() if k.startswith(("model.diffusion_model.", "first_stage_model."))}, strict=False)
-        # a checkpoint whose prefixes do not match must not run on default-initialised weights
-        hot = [k for k in missing if k.startswith("model.diffusion_model.") or (opt.with_vae and k.startswith("first_stage_model."))]
-        if hot or unexpected:
-            raise RuntimeError(f"{opt.ckpt}: {len(hot)} parameter(s) of the denoising path missing (first: {hot[:5]}), "
-                               f"{len(unexpected)} unexpected key(s) (first: {list(unexpected)[:5]})")
-        print(f"loaded {opt.ckpt}: every model.diffusion_model.* key matched ({len(missing)} keys outside the path absent)")
+        print(load_checkpoint(model, opt.ckpt, with_vae=opt.with_vae))
     else:
         synth.fill_module_(model.unet, seed=0)
         if opt.with_vae:
@@ -119,6 +178,8 @@ def run_synthetic(opt) -> dict:
     sampler.flow_gate = opt.flow_gate
     if opt.hip_graph:
         sampler.model.model.diffusion_model.engine.use_graph = True
+    if opt.no_hip_graph:
+        sampler.model.model.diffusion_model.engine.use_graph = False
     sampler.flow_resample = "area" if opt.flow_pixels else None
     h, w = opt.H // opt.f, opt.W // opt.f
     F_ = opt.n_samples

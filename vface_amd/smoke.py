@@ -42,5 +42,5 @@ def run(verbose: bool = True) -> float:
     err = float((got - ref).norm() / ref.norm())
     if verbose:
         print(f"smoke: hooked UNet (flow_fix) on {torch.cuda.get_device_name(0)}: rel-L2 vs CPU oracle = {err:.3e}")
-    assert err < 2e-3, err
+    assert err < 1.5e-3, err   # measured 1.27e-3 (the reference's own fp16 autocast: 2.06e-3 on this size, tests/golden/lowp.npz)
     return err
