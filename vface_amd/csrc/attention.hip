@@ -266,23 +266,33 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             if (tail) {
+                // (the key index goes through an opaque register INSIDE the branch: hipcc otherwise hoists the 16 index
+                //  computations and 16 compares of the mask above the branch, into every block of the loop -- 32 vector
+                //  instructions per block of a VALU-bound kernel for a branch only the last block can take)
+                int kbase = kb * KVB + fg * 4;
+                asm volatile("" : "+v"(kbase));
 #pragma unroll
                 for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (kb * KVB + tl * 16 + fg * 4 + r >= nk) s[tl][qt][r] = -1e30f;
+                        if (kbase + tl * 16 + r >= nk) s[tl][qt][r] = -1e30f;
             }
             float mx = -1e30f;
 #pragma unroll
             for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[tl][qt][r]);
-            mx = quad_row_max(mx);
+            if constexpr (!LAZY) mx = quad_row_max(mx);
             float ls = 0.f;
             if constexpr (LAZY) {
-                // scores are relative to m_ref already.  Raise m_ref (first block: set it) only where needed.
-                const bool shift = (kb == 0) || (mx > 8.0f);
-                if (__any(shift)) {
+                // scores are relative to m_ref already.  Raise m_ref (first block: set it) only where needed.  The decision
+                // "does any query of this wave exceed its reference by more than 8" needs only the LANE-local maxima (a
+                // query's four lane groups hold 16 of its 64 keys each: the query's max exceeds 8 iff one of theirs does), so
+                // the cross-lane reduction (two lane swaps + the canonicalising maxima hipcc wraps around them: 10 vector
+                // instructions per query tile) runs only inside the rare branch -- the kernel is VALU-issue-bound.
+                if (__any((kb == 0) || (mx > 8.0f))) {
+                    mx = quad_row_max(mx);
+                    const bool shift = (kb == 0) || (mx > 8.0f);
                     const float delta = shift ? mx : 0.f;
                     const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll

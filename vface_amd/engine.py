@@ -925,7 +925,7 @@ class UNetEngine:
         sig, flows = self._hook_signature()
         ex = self.halo_exchange
         shard_sig = None if ex is None else (id(ex), ex.rank, ex.world, ex.first, ex.count, self.halo_hw,
-                                             None if self.halo_flow is None else self.halo_flow.data_ptr())
+                                             None if self.halo_flow is None else tuple(self.halo_flow.shape))
         key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)
@@ -944,6 +944,9 @@ class UNetEngine:
                 dst.copy_(src)
                 g["flow_ids"][id(dst)] = (id(src), src._version)
                 g["flow_keep"][id(dst)] = src
+        if g["halo_flow"] is not None and (id(self.halo_flow), self.halo_flow._version) != g["halo_flow_id"]:
+            g["halo_flow"].copy_(self.halo_flow)      # (the graph reads its own copy: FrameShard.install may hand a new tensor)
+            g["halo_flow_id"], g["halo_flow_keep"] = (id(self.halo_flow), self.halo_flow._version), self.halo_flow
         g["x"].copy_(x.t)
         g["t"].copy_(timesteps)
         for graph, host_op in g["segments"]:
@@ -967,9 +970,12 @@ class UNetEngine:
         own_flows = [f.clone() for f in flows]
         saved_flows = [c.flow for c in cfgs]
         saved_cache = getattr(self, "_a2_cache", None)
-        real_exchange = self.halo_exchange
+        real_exchange, real_halo_flow = self.halo_exchange, self.halo_flow
+        own_halo_flow = real_halo_flow.clone() if (real_exchange is not None and real_halo_flow is not None) else None
         seg = None
         try:
+            if own_halo_flow is not None:
+                self.halo_flow = own_halo_flow
             a2 = self.context_projections(context, x.N).clone()
             self._a2_cache = (context, context._version, self._packed, a2)
             for c in cfgs:
@@ -1009,7 +1015,7 @@ class UNetEngine:
             self._graph_failed.add(key)
             return None
         finally:
-            self.halo_exchange = real_exchange
+            self.halo_exchange, self.halo_flow = real_exchange, real_halo_flow
             for c, f in zip(cfgs, saved_flows):
                 c.flow = f
             self._a2_cache = saved_cache
@@ -1022,6 +1028,8 @@ class UNetEngine:
             self._graphs.pop(next(iter(self._graphs)))      # least recently used first
         g = {"segments": seg.segments, "keep": seg.keep, "bytes": pool_bytes, "x": xs, "t": ts, "eps": eps, "a2": a2,
              "ctx_id": (id(context), context._version),
+             "halo_flow": own_halo_flow, "halo_flow_keep": real_halo_flow,
+             "halo_flow_id": None if own_halo_flow is None else (id(real_halo_flow), real_halo_flow._version),
              "ctx_keep": context, "flows": own_flows, "flow_ids": {id(d): (id(s_), s_._version) for d, s_ in zip(own_flows, flows)},
              "flow_keep": {id(d): s_ for d, s_ in zip(own_flows, flows)}, "packed": self._packed,
              # the split-K workspace the captured launches write to (hip.py grows it by REPLACING the tensor: keep this one alive)
