@@ -232,6 +232,21 @@ int vface_attn1_forward(const void* x, int64_t ldx, const void* Wqkv, const void
                         const int32_t* qk_map, const int32_t* v_map, void* workspace, size_t workspace_bytes,
                         const void* zeros, int dtype, void* stream, const vface_stream32* s32);
 
+/* The FeedForward third of BasicTransformerBlock._forward in ONE launch (REFace/ldm/modules/attention.py:243 `x = ff(norm3(x)) + x`,
+ * FeedForward / GEGLU :37-64, LayerNorm :233):  out = W2 (a * gelu(g)) + b2 + x,  [a ; g] = W1 LN(x) + b1.
+ * x32: the block's running sum, fp32 [M][ldx] (LayerNorm input and residual).  W1: ff.net[0].proj.weight [8C][C] 16-bit with rows
+ * interleaved in 16-row value / gate blocks (the vface_gemm GEGLU packing), b1 in the same order; W2p: ff.net[2].weight [C][4C] with
+ * the columns of every aligned 32-block stored in the order 8g + j <- 16 (j >> 2) + 4g + (j & 3) (the k order in which two 16 x 16
+ * accumulator tiles of the hidden activations form one k32 MFMA operand: vface_amd/packing.py::pack_ffn_w2).  out16 (16-bit) and /
+ * or out32 (fp32) receive the result.  The [M x 4C] hidden matrix never exists; LayerNorm statistics and the GEGLU are fp32, the
+ * normalised activations and the hidden activations are rounded to 16 bits once, as in the three-kernel path.
+ * Supported: C in {64, 128, 320} (one wave keeps C / 16 x 2 output tiles in registers), M % 128 == 0: vface_ffn_fused_supported();
+ * other shapes: VFACE_ERR_SHAPE (the caller runs vface_layernorm + vface_gemm(GEGLU) + vface_gemm). */
+int vface_ffn_fused_supported(int64_t M, int C);
+int vface_ffn_fused(const float* x32, int64_t ldx, const float* gamma, const float* beta, float eps, const void* W1, const float* b1,
+                    const void* W2p, const float* b2, void* out16, int64_t ldo, float* out32, int64_t ldo32, int M, int C,
+                    int dtype, void* stream);
+
 /* fusion="temporal" (pnp_utils.py:59-90,145-154): 5-tap Gaussian (sigma 1, renormalised at the clip ends) over the
  * FRAME axis of src [F][n][C] (chunk 0's q|k), written to dst1 and dst2 (chunk 1 and chunk 2). */
 int vface_temporal_gauss(const void* src, int64_t ld_src, int64_t fs_src, void* dst1, void* dst2, int64_t ld_dst,

@@ -926,3 +926,56 @@ def test_conv_8x8_four_images_per_workgroup_form(dt, cin, cout, nimg, c2):
     # a sample's bits do not depend on which other samples share its launch (here: 3 images alone, a ragged tile)
     p16, p32, pcs = run(0, n=3)
     assert torch.equal(p16, o16[:3 * 64]) and torch.equal(p32, o32[:3 * 64]) and torch.equal(pcs, cs[:3])
+
+
+def _ffn_reference(x, gamma, beta, w1, b1, w2, b2):
+    """attention.py:243 `ff(norm3(x)) + x` with FeedForward = Linear(GEGLU) -> Linear (:37-64), in fp64 on the given weights."""
+    x = x.double()
+    ln = F.layer_norm(x, (x.shape[1],), gamma.double(), beta.double(), 1e-5)
+    y = ln @ w1.double().t() + b1.double()
+    a, g = y.chunk(2, dim=-1)
+    h = a * F.gelu(g)
+    return h @ w2.double().t() + b2.double() + x
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,C", [(128, 64), (384, 128), (256, 320), (4096, 320)])
+def test_ffn_fused_vs_reference_and_vs_three_kernel_path(dt, M, C):
+    """csrc/ffn.hip: LayerNorm -> ff.net[0] (GEGLU) -> ff.net[2] -> + x in one launch, the normalised activations held in
+    registers as MFMA operands and the hidden activations going from accumulators to operands without leaving the registers,
+    against (a) an fp64 evaluation of the reference's formula on the same 16-bit weights and (b) the three-kernel path
+    (vface_layernorm + vface_gemm(GEGLU) + vface_gemm + residual) it replaces."""
+    h = hip()
+    from vface_amd import packing
+    assert h.ffn_fused_supported(M, C) and not h.ffn_fused_supported(M + 64, C) and not h.ffn_fused_supported(M, 640)
+    x = rnd((M, C), 31, torch.float32, 1.5) + rnd((M, 1), 32, torch.float32, 0.7)     # rows with a non-zero mean
+    gamma, beta = 1.0 + rnd((C,), 33, torch.float32, 0.2), rnd((C,), 34, torch.float32, 0.2)
+    w1, b1 = rnd((8 * C, C), 35, dt, C ** -0.5), rnd((8 * C,), 36, torch.float32, 0.3)
+    w2, b2 = rnd((C, 4 * C), 37, dt, (4 * C) ** -0.5), rnd((C,), 38, torch.float32, 0.3)
+    ref = _ffn_reference(x, gamma, beta, w1.float(), b1, w2.float(), b2).float()
+    w1p, b1p = packing.pack_geglu(w1, b1)
+    w2p = packing.pack_ffn_w2(w2)
+    d = lambda v: v.to(DEV).contiguous()
+    xd, out16, out32 = d(x), torch.zeros(M, C, dtype=dt, device=DEV), torch.zeros(M, C, dtype=torch.float32, device=DEV)
+    h.ffn_fused(xd, d(gamma), d(beta), d(w1p), d(b1p), d(w2p), d(b2), out16, M=M, C_=C, out32=out32)
+    e32, e16 = rel_l2(out32.cpu(), ref), rel_l2(out16.cpu().float(), ref)
+    # the three-kernel path on the same operands
+    ln = torch.empty(M, C, dtype=dt, device=DEV)
+    h.layernorm(xd, d(gamma), d(beta), ln, M=M, C_=C, ldx=C, ldy=C)
+    ff = torch.empty(M, 4 * C, dtype=dt, device=DEV)
+    h.gemm(ln, d(w1p), ff, M=M, N=8 * C, K=C, lda=C, ldc=4 * C, bias=d(b1p), flags=h.EPI_GEGLU)
+    o3 = torch.empty(M, C, dtype=torch.float32, device=DEV)
+    h.gemm(ff, d(w2), None, M=M, N=C, K=4 * C, lda=4 * C, ldc=0, bias=d(b2), residual32=xd, out32=o3)
+    e3 = rel_l2(o3.cpu(), ref)
+    e_vs3 = rel_l2(out32.cpu(), o3.cpu())
+    print(f"ffn fused M={M} C={C} {dt}: fp32 out {e32:.2e}, 16-bit out {e16:.2e}; three-kernel path {e3:.2e}; fused vs three-kernel {e_vs3:.2e}")
+    assert torch.equal(out16, out32.to(dt)), "the 16-bit output is the single rounding of the fp32 sum"
+    assert e32 < TOL[dt] and e32 < 1.5 * e3 + 1e-5 and e_vs3 < TOL[dt]
+
+
+def test_ffn_fused_rejects_what_it_cannot_run():
+    h = hip()
+    x = torch.zeros(128, 640, device=DEV)
+    w = torch.zeros(8, 8, dtype=torch.float16, device=DEV)
+    with pytest.raises(h.VFaceHipError):
+        h.ffn_fused(x, x, x, w, x, w, x, torch.zeros(128, 640, dtype=torch.float16, device=DEV), M=128, C_=640)

@@ -54,18 +54,18 @@ def ab(label, fn, rounds=7, flops=None):
           f"   {names[1]}/{names[0]} = {med[names[1]] / med[names[0]]:.3f}" + extra, flush=True)
 
 
-def attn_case(dh, n, N, sets=1):
+def attn_case(dh, n, N, sets=1, variant=0):
     d = 8 * dh
     g = torch.Generator(device=DEV).manual_seed(0)
     qkv = torch.randn(N * sets, n, 3 * d, device=DEV, generator=g).half()
     out = torch.empty(N * sets, n, d, dtype=torch.float16, device=DEV)
     kw = dict(heads=8, n=n, nk=n, dh=dh, ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d, ldo=d,
-              bso=n * d, scale=dh ** -0.5)
+              bso=n * d, scale=dh ** -0.5, variant=variant)
     if sets > 1:
         run = lambda: hip.attention(qkv, qkv[:, :, d:], qkv[:, :, 2 * d:], out, B=N, v_sets=sets, set_stride=N, **kw)
     else:
         run = lambda: hip.attention(qkv, qkv[:, :, d:], qkv[:, :, 2 * d:], out, B=N, **kw)
-    ab(f"attention dh={dh} n={n} B={N} sets={sets}", run, flops=4.0 * n * n * dh * 8 * N * sets)
+    ab(f"attention dh={dh} n={n} B={N} sets={sets} variant={variant}", run, flops=4.0 * n * n * dh * 8 * N * sets)
     sp = lambda t: t.reshape(2, n, 8, dh).permute(0, 2, 1, 3).double()
     r = torch.softmax(sp(qkv[:2, :, :d]) @ sp(qkv[:2, :, d:2 * d]).transpose(-1, -2) * dh ** -0.5, -1) @ sp(qkv[:2, :, 2 * d:])
     r = r.permute(0, 2, 1, 3).reshape(2, n, d)
@@ -102,8 +102,10 @@ def gemm_case(spec):
 if __name__ == "__main__":
     LIBS["base"], LIBS["new"] = bind(sys.argv[1]), bind(sys.argv[2])
     for what in sys.argv[3:] or ["attn40", "attn40s3", "attn80", "attn160"]:
-        if what == "attn40": attn_case(40, 4096, 24)
-        elif what == "attn40s3": attn_case(40, 4096, 8, sets=3)
+        var = int(what.split(":v")[1]) if ":v" in what else 0
+        what = what.split(":v")[0]
+        if what == "attn40": attn_case(40, 4096, 24, variant=var)
+        elif what == "attn40s3": attn_case(40, 4096, 8, sets=3, variant=var)
         elif what == "attn80": attn_case(80, 1024, 24)
         elif what == "attn160": attn_case(160, 256, 24)
         elif what.startswith("gemm:"): gemm_case(what[5:])

@@ -287,6 +287,17 @@ int vface_attn1_forward(const void* x, int64_t ldx, const void* Wqkv, const void
     return vf_launch_gemm(po, dtype, st);
 }
 
+int vface_ffn_fused_supported(int64_t M, int C) { return vf_ffn_fused_supported((long)M, C) ? 1 : 0; }
+
+int vface_ffn_fused(const float* x32, int64_t ldx, const float* gamma, const float* beta, float eps, const void* W1, const float* b1,
+                    const void* W2p, const float* b2, void* out16, int64_t ldo, float* out32, int64_t ldo32, int M, int C,
+                    int dtype, void* stream) {
+    FfnParams p{};
+    p.x32 = x32; p.ldx = ldx; p.gamma = gamma; p.beta = beta; p.eps = eps; p.W1 = W1; p.b1 = b1; p.W2p = W2p; p.b2 = b2;
+    p.out16 = out16; p.ldo = ldo; p.out32 = out32; p.ldo32 = ldo32; p.M = M; p.C = C;
+    return vf_launch_ffn_fused(p, dtype, S(stream));
+}
+
 int vface_temporal_gauss(const void* src, int64_t ld_src, int64_t fs_src, void* dst1, void* dst2, int64_t ld_dst,
                          int64_t fs_dst, int F, int n, int C, int dtype, void* stream) {
     return vf_launch_temporal_gauss(src, ld_src, fs_src, dst1, dst2, ld_dst, fs_dst, F, n, C, dtype, S(stream));

@@ -8,6 +8,7 @@ typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 b8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 b4_t __attribute__((ext_vector_type(4)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef float f16_t __attribute__((ext_vector_type(16)));
 typedef short s4_t __attribute__((ext_vector_type(4)));
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -25,6 +26,26 @@ struct F16 {
     static __device__ __forceinline__ f4_t mfma16(v4 a, v4 b, f4_t c) {  // 16x16x16: lane holds k = 4*(lane>>4) + j
         return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
     }
+    // 32x32x16: lane l holds A[row l & 31][k = 8 (l >> 5) + j], B[k = 8 (l >> 5) + j][col l & 31]; C/D: col = l & 31,
+    // row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)
+    static __device__ __forceinline__ f16_t mfma32x32(v8 a, v8 b, f16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    // in-place accumulation pinned to ONE accumulator-register tuple (the register allocator otherwise renames loop-carried
+    // 16-register accumulators and pays for it in v_accvgpr copies every iteration).  Operands must not have been written by
+    // a vector instruction in the two preceding issue slots (callers: fragments come from LDS reads, B operands are old)
+    static __device__ __forceinline__ void mfma32x32_acc(f16_t& c, v8 a, v8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
+    // the same pinned to VECTOR registers (an accumulator that vector instructions read afterwards: no v_accvgpr_read per value),
+    // and its first step with C = 0.  NOTE for callers: no wait states are inserted around inline asm -- a vector instruction
+    // that reads the result needs >= 18 idle issue slots after the last MFMA that wrote it (raw_mfma_to_valu_gap()).
+    static __device__ __forceinline__ void mfma32x32_vacc(f16_t& c, v8 a, v8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void mfma32x32_vzero(f16_t& c, v8 a, v8 b) {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+    }
     static __device__ __forceinline__ v4 tr_read(const elem* lds) {
         return __builtin_bit_cast(v4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                                           (__attribute__((address_space(3))) s4_t*)(lds)));
@@ -39,6 +60,21 @@ struct BF16 {
     }
     static __device__ __forceinline__ f4_t mfma16(v4 a, v4 b, f4_t c) {
         return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s4_t, a), __builtin_bit_cast(s4_t, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f16_t mfma32x32(v8 a, v8 b, f16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mfma32x32_acc(f16_t& c, v8 a, v8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    }
+    // the same pinned to VECTOR registers (an accumulator that vector instructions read afterwards: no v_accvgpr_read per value),
+    // and its first step with C = 0.  NOTE for callers: no wait states are inserted around inline asm -- a vector instruction
+    // that reads the result needs >= 18 idle issue slots after the last MFMA that wrote it (raw_mfma_to_valu_gap()).
+    static __device__ __forceinline__ void mfma32x32_vacc(f16_t& c, v8 a, v8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    }
+    static __device__ __forceinline__ void mfma32x32_vzero(f16_t& c, v8 a, v8 b) {
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
     }
     static __device__ __forceinline__ v4 tr_read(const elem* lds) {
         return __builtin_bit_cast(v4, __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -84,6 +120,16 @@ __device__ __forceinline__ float quad_row_sum(float v) {
     auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
 }
+
+// raw workgroup barrier (no fence, no vmcnt drain: LDS-DMA stays in flight across it; callers place their own counted waits).
+// Behind a __device__ function: called straight from a __global__ template, the builtin makes hipcc's HOST pass drop the
+// kernel's stub without a diagnostic (undefined kernel symbol at dlopen).
+__device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
+
+// wait states hipcc would insert between an MFMA and a vector instruction reading its result (or between a vector write and an
+// MFMA reading it as an operand) when the MFMA is inline asm and therefore invisible to its hazard recogniser
+__device__ __forceinline__ void raw_mfma_to_valu_gap() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
+__device__ __forceinline__ void raw_valu_to_mfma_gap() { asm volatile("s_nop 1" ::: "memory"); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -87,6 +87,21 @@ bool vf_attention_shared_scores_supported(int dh, int v_sets);
 int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream);
 int vf_launch_gemm_pp(const GemmParams& p, int dtype, int variant, hipStream_t stream);
 
+// ffn.hip: fused LayerNorm -> ff.net[0] (GEGLU) -> ff.net[2] -> + x over token matrices with C in {64, 128, 320}, M % 128 == 0
+struct FfnParams {
+    const float* x32; long ldx;      // [M][C] fp32: the block's running sum (LayerNorm input AND residual)
+    const float* gamma; const float* beta; float eps;
+    const void* W1;                  // [8C][C] 16-bit, GEGLU rows interleaved in 16-row value / gate blocks (packing.pack_geglu)
+    const float* b1;                 // [8C] in the same row order
+    const void* W2p;                 // [C][4C] 16-bit, columns permuted per 32 (packing.pack_ffn_w2)
+    const float* b2;                 // [C]
+    void* out16; long ldo;           // [M][C] 16-bit result (or null)
+    float* out32; long ldo32;        // optional fp32 result
+    int M, C;
+};
+bool vf_ffn_fused_supported(long M, int C);
+int vf_launch_ffn_fused(const FfnParams& p, int dtype, hipStream_t stream);
+
 struct AttnParams {
     const void* Q; const void* K; const void* V;  // [B][n][ld*], head h at column h*dh
     long ldq, ldk, ldv;           // row (token) strides in elements

@@ -350,6 +350,9 @@ class UNetEngine:
         self.halo_flow: Optional[torch.Tensor] = None  # flow from the previous rank's last frame into our frame 0
         self.halo_hw = None                            # (h, w) of the clip's flow fields (set with halo_exchange)
         self.exchange_events = None                    # a list: (start, end) HIP events around every finish_exchange (bench.py)
+        # norm3 + FeedForward of the level-0 transformer blocks (C = 320; also the 64- / 128-channel test models) as one
+        # activation-stationary kernel (csrc/ffn.hip).  VFACE_FUSE_FFN=0: the three-kernel path (A/B switch).
+        self.fuse_ffn = os.environ.get("VFACE_FUSE_FFN", "1") != "0"
         self.decompose_attn1 = False                   # bench.py's instrumented pass: vface_attn1_forward's launches call by call
         # fp32 residual stream: residual sums are carried between kernels in fp32, 16-bit copies exist only
         # where a matrix-core operand needs them.  VFACE_STREAM32=0 restores the all-16-bit activations (A/B switch).
@@ -473,6 +476,7 @@ class UNetEngine:
                                                   sd[t + ".attn1.to_v.weight"])),
                 "wo": self.pack_lin(sd, t + ".attn1.to_out.0"),
                 "ff1": {"w": self._w16(ffw), "b": self._f32(ffb)}, "ff2": self.pack_lin(sd, t + ".ff.net.2"),
+                "ff2p": self._w16(packing.pack_ffn_w2(cpu(t + ".ff.net.2.weight"))),   # fused FeedForward (csrc/ffn.hip)
                 "a2_out": self.pack_lin(sd, t + ".attn2.to_out.0"), "c": sd[t + ".norm1.weight"].shape[0],
                 "wlin": {}, "attn1_name": t + ".attn1",
                 "qk_src": (sd[t + ".attn1.to_q.weight"], sd[t + ".attn1.to_k.weight"])}
@@ -752,11 +756,16 @@ class UNetEngine:
             raise hip.VFaceHipError("attn1.forward was replaced by a closure this engine does not know; use "
                                     "vface_amd.ldm.models.pnp_utils.register_spa_attn_injection")
         t1 = self._attn1(ln, t0, p, cfg, a2vec, N, n, attn1.heads, hw)
+        t2 = self._new(M, c)
+        t2_32 = self._new(M, c, torch.float32) if want32 else None
+        if self.fuse_ffn and t1.dtype == torch.float32 and hip.ffn_fused_supported(M, c):
+            # norm3 -> ff.net[0] (GEGLU) -> ff.net[2] -> + x in ONE launch (csrc/ffn.hip): the [M, 4c] hidden matrix never exists
+            hip.ffn_fused(t1, p["ln3"][0], p["ln3"][1], p["ff1"]["w"], p["ff1"]["b"], p["ff2p"], p["ff2"]["b"], t2, M=M, C_=c,
+                          out32=t2_32)
+            return (t2, t2_32) if want32 else t2
         hip.layernorm(t1, p["ln3"][0], p["ln3"][1], ln, M=M, C_=c, ldx=c, ldy=c)
         ff = self._new(M, 4 * c)
         hip.gemm(ln, p["ff1"]["w"], ff, M=M, N=8 * c, K=c, lda=c, ldc=4 * c, bias=p["ff1"]["b"], flags=hip.EPI_GEGLU)
-        t2 = self._new(M, c)
-        t2_32 = self._new(M, c, torch.float32) if want32 else None
         self._gemm(ff, p["ff2"], t2, hw=n, out32=t2_32, **self._resid(t1))
         return (t2, t2_32) if want32 else t2
 

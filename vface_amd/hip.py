@@ -70,6 +70,8 @@ SIGNATURES = {
     "vface_attn1_forward": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32,
                                       _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp,
                                       _vp, _vp, _sz, _vp, _i32, _vp, _s32p]),
+    "vface_ffn_fused_supported": (C.c_int, [_i64, _i32]),
+    "vface_ffn_fused": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "vface_temporal_gauss": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "vface_adain_workspace_bytes": (_sz, [_i64, _i32]),
     "vface_adain_fusion": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _sz, _i32, _vp]),
@@ -317,6 +319,23 @@ def attn1_forward(x, wqkv, wlin, wo, bo, out, *, B, n, d, heads, chunks, fusion,
                                     _p(qk_map), _p(v_map), _p(workspace), workspace.numel() * workspace.element_size(),
                                     _p(zeros_page(x.device)), dtype_code(x.dtype), _stream(), _s32(residual32, out32))
     _check(rc, "vface_attn1_forward")
+
+
+def ffn_fused_supported(M: int, C_: int) -> bool:
+    return bool(load().vface_ffn_fused_supported(M, C_))
+
+
+def ffn_fused(x32: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor,
+              b2: torch.Tensor, out16: Optional[torch.Tensor], *, M: int, C_: int, out32: Optional[torch.Tensor] = None,
+              eps: float = 1e-5):
+    """``out = ff.net[2](GEGLU(ff.net[0](LayerNorm(x32)))) + x32`` in one launch (``vface_ffn_fused``); ``w1`` / ``b1`` in the GEGLU
+    packing of ``packing.pack_geglu``, ``w2p`` from ``packing.pack_ffn_w2``."""
+    if x32.dtype != torch.float32 or x32.dim() != 2 or x32.stride(1) != 1:
+        raise VFaceHipError("ffn_fused: x32 must be a 2-D fp32 view with unit column stride")
+    rc = load().vface_ffn_fused(_p(x32), x32.stride(0), _p(gamma), _p(beta), eps, _p(w1), _p(b1), _p(w2p), _p(b2), _p(out16),
+                                out16.stride(0) if out16 is not None else 0, _p(out32),
+                                out32.stride(0) if out32 is not None else 0, M, C_, dtype_code(w1.dtype), _stream())
+    _check(rc, "vface_ffn_fused")
 
 
 def timestep_embedding(t: torch.Tensor, out: torch.Tensor, dim: int):

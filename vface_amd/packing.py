@@ -75,6 +75,23 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor):
     return wp, bp
 
 
+def ffn_w2_perm(inner: int) -> torch.Tensor:
+    """Column order of ``ff.net[2].weight`` for the fused FeedForward kernel (csrc/ffn.hip): inside every aligned block of 16
+    hidden units, position ``8 h + j`` holds original unit ``8 (j >> 2) + 4 h + (j & 3)`` -- the k order in which the 16-bit
+    roundings of a 32 x 32 fp32 accumulator tile's registers 0..7 (rows ``(reg & 3) + 8 (reg >> 2) + 4 h`` of lane half h) form
+    ONE k16 MFMA B operand without any lane movement (guide 3, "an accumulator tile as the next MFMA's operand")."""
+    assert inner % 16 == 0
+    j = torch.arange(8)
+    h = torch.arange(2)
+    within = (8 * (j[None, :] >> 2) + 4 * h[:, None] + (j[None, :] & 3)).reshape(16)       # [8 h + j]
+    return (torch.arange(0, inner, 16)[:, None] + within[None, :]).reshape(inner)
+
+
+def pack_ffn_w2(w2: torch.Tensor) -> torch.Tensor:
+    """``ff.net[2].weight`` [C, 4C] with its columns in ``ffn_w2_perm`` order."""
+    return w2[:, ffn_w2_perm(w2.shape[1])].contiguous()
+
+
 def pack_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor) -> torch.Tensor:
     return torch.cat([wq, wk, wv], 0).contiguous()
 
