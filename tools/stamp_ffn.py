@@ -25,5 +25,5 @@ for _ in range(30):
 torch.cuda.synchronize()
 d = buf[M * C:].view(nw, 8).cpu()
 med = d.median(0).values
-print(f"cycles per wave (median over {nw} waves): prologue {med[0]:.0f} | main loop {med[1]:.0f} (of which GEGLU {med[3]:.0f}) | epilogue {med[2]:.0f} | total {med[5]:.0f}")
-print(f"in-kernel clock: {(d[:, 5] / d[:, 4]).median().item() * 100:.0f} MHz;  per hidden chunk: {med[1] / 20:.0f} cycles for 120 MFMAs (3840 matrix cycles)")
+print(f"cycles per wave (median over {nw} waves): prologue {med[0]:.0f} | main loop {med[1]:.0f} (of which: vmcnt waits {med[3]:.0f}, barrier waits {med[6]:.0f}) | epilogue {med[2]:.0f} | total {med[5]:.0f}")
+print(f"in-kernel clock: {(d[:, 5] / d[:, 4]).median().item() * 100:.0f} MHz;  per 64 hidden units: {med[1] / 20:.0f} cycles for 120 MFMAs (3840 matrix cycles)")

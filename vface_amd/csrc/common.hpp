@@ -39,7 +39,7 @@ struct F16 {
     }
     // the same pinned to VECTOR registers (an accumulator that vector instructions read afterwards: no v_accvgpr_read per value),
     // and its first step with C = 0.  NOTE for callers: no wait states are inserted around inline asm -- a vector instruction
-    // that reads the result needs >= 18 idle issue slots after the last MFMA that wrote it (raw_mfma_to_valu_gap()).
+    // that reads the result needs >= 18 idle issue slots after the last MFMA that wrote it (gap_mfma_result_to_valu()).
     static __device__ __forceinline__ void mfma32x32_vacc(f16_t& c, v8 a, v8 b) {
         asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     }
@@ -69,7 +69,7 @@ struct BF16 {
     }
     // the same pinned to VECTOR registers (an accumulator that vector instructions read afterwards: no v_accvgpr_read per value),
     // and its first step with C = 0.  NOTE for callers: no wait states are inserted around inline asm -- a vector instruction
-    // that reads the result needs >= 18 idle issue slots after the last MFMA that wrote it (raw_mfma_to_valu_gap()).
+    // that reads the result needs >= 18 idle issue slots after the last MFMA that wrote it (gap_mfma_result_to_valu()).
     static __device__ __forceinline__ void mfma32x32_vacc(f16_t& c, v8 a, v8 b) {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     }
@@ -126,10 +126,29 @@ __device__ __forceinline__ float quad_row_sum(float v) {
 // kernel's stub without a diagnostic (undefined kernel symbol at dlopen).
 __device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
 
-// wait states hipcc would insert between an MFMA and a vector instruction reading its result (or between a vector write and an
-// MFMA reading it as an operand) when the MFMA is inline asm and therefore invisible to its hazard recogniser
-__device__ __forceinline__ void raw_mfma_to_valu_gap() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
-__device__ __forceinline__ void raw_valu_to_mfma_gap() { asm volatile("s_nop 1" ::: "memory"); }
+// Wait states hipcc would insert itself if the MFMAs around them were not inline asm (invisible to its hazard recogniser).  Each
+// takes the value it protects as a "+v" operand: a plain asm nop orders nothing -- hipcc moves register-only instructions across
+// it (guide 5.7 item 3) -- whereas this pins every producer of `x` above the nop and every consumer below it.
+template <class T> __device__ __forceinline__ void gap_mfma_result_to_valu(T& x) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x)); }
+template <class T> __device__ __forceinline__ void gap_valu_result_to_mfma(T& x) { asm volatile("s_nop 3" : "+v"(x)); }
+template <class T> __device__ __forceinline__ void gap_acc_result_to_valu(T& x) { asm volatile("s_nop 15\n\ts_nop 3" : "+a"(x)); }
+
+// One LDS-DMA instruction (16 bytes per lane, lane-linear LDS destination) as inline asm: through the builtin, hipcc treats the
+// LDS write as a store it must order against every later LDS read it cannot disambiguate and drains the whole DMA queue
+// (`s_waitcnt vmcnt(0)`) before the first ds_read after an issue -- which serialises a multi-stage ring.  Here the caller
+// owns the counting (`s_waitcnt vmcnt(N)`) and the visibility (barrier).  m0 = LDS byte address of lane 0's slot.
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4_t raw_buffer_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    return i32x4_t{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void raw_lds_dma16(i32x4_t rsrc, unsigned lds_addr, int voffset, int soffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_addr), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory", "m0");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)p;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -5,66 +5,77 @@
 //
 // ONE launch instead of LayerNorm + GEMM(GEGLU) + GEMM(+residual), and the [M x 4C] hidden matrix (252 MB per level-0 block at
 // F = 8) never exists: a workgroup keeps its 128 tokens' normalised activations IN REGISTERS as MFMA B operands for the whole
-// kernel (activation-stationary) and streams the two weight matrices through LDS once, hidden chunk by hidden chunk:
+// kernel (activation-stationary) and streams the two weight matrices through LDS once.
 //
 //   * 256 threads = 4 waves, ONE wave per SIMD with the whole 512-register file (`__launch_bounds__(256, 1)`); a wave owns 32
-//     tokens = one column tile of `mfma_f32_32x32x16`.  With one wave per SIMD the kernel is bound by INSTRUCTION ISSUE, not by
-//     the matrix pipe (a first version on 16x16x32 tiles issued 1 400 instructions per hidden chunk for 240 MFMAs and ran at
-//     their issue time): the 32 x 32 shape does the same work in half the MFMA instructions and leaves 32-cycle gaps for the
-//     LDS reads and the GEGLU's vector work.
+//     tokens = one column tile of `mfma_f32_32x32x16`.  With one wave per SIMD nothing hides a wave's own stalls, and the
+//     kernel is bound by INSTRUCTION ISSUE and by what is NOT overlapped (stamps of the earlier chunk-at-a-time versions: 9 100
+//     cycles per 64 hidden units for 3 840 cycles of MFMA, 2 900 of them the GEGLU standing alone between the two GEMMs).
+//     Hence the 32 x 32 shape (half the MFMA instructions, 32-cycle gaps for other work) and the software pipeline below.
 //   * Prologue: the wave reads its tokens' fp32 rows in the B-operand lane layout (lane = token l & 31, half h = l >> 5 holds
 //     channels 16 s + 8 h .. + 7 of every k16 step s), does the two-pass LayerNorm across its two lane halves, and keeps
 //     fp16(LN(x)) as C / 16 fragments (80 registers).
-//   * Hidden chunk = 64 hidden units = 128 rows of the GEGLU-interleaved ff.net[0] weight (16 value rows, 16 gate rows, ...) =
-//     four 32-row A tiles, each holding 16 hidden units' value AND gate rows: in the 32 x 32 accumulator layout
-//     (row = (reg & 3) + 8 (reg >> 2) + 4 h) register q < 8 is a value row and register q + 8 ITS gate row, in the same lane.
-//     GEMM 1: acc1[4 tiles] over K = C in 64-deep stages (16 KB, LDS-DMA, ring of four, landed ONE interval ahead so the first
-//     fragments of a stage are read before its interval starts); GEGLU in registers (value * gelu(gate), erf form); the eight
-//     results of a tile, rounded to 16 bits, ARE the B operand of one k16 step of GEMM 2 (guide 3, "an accumulator tile as
-//     the next MFMA's operand": element j of lane half h is hidden unit 8 (j >> 2) + 4 h + (j & 3) of the tile), so
-//     ff.net[2]'s weight columns are stored in THAT order (packing.pack_ffn_w2) and no lane ever moves.  GEMM 2:
-//     out[C / 32 tiles] += W2[:, chunk] h over the chunk's four k16 steps (the whole [C x 64] slice is one 40 KB stage,
-//     double-buffered, fetched a chunk ahead in pieces beside GEMM 1's stages).
-//   * Epilogue: (out + b2) + x in fp32, transposed through LDS (the ring is free by then) to whole 32-byte row chunks.
+//   * Unit of work = one hidden TILE: 16 hidden units = 32 rows of the GEGLU-interleaved ff.net[0] weight (16 value rows, then
+//     their 16 gate rows): in the 32 x 32 accumulator layout (row = (reg & 3) + 8 (reg >> 2) + 4 h) register q < 8 is a value row
+//     and register q + 8 ITS gate row, in the same lane.  Interval t of the pipeline issues, interleaved in one stream:
+//        GEMM 1 of tile t      acc1[t & 1] = W1[tile t] LN(x)        C / 16 MFMAs, one accumulation chain, A fragments from LDS
+//        GEGLU of tile t - 1   hb = value * gelu(gate) (erf form)    8 values per lane, cut into 24 pieces, one per MFMA gap
+//        GEMM 2 of tile t - 2  out[C / 32 tiles] += W2[:, tile] hb   C / 32 MFMAs: the eight GEGLU results of a lane, rounded to
+//                              16 bits, ARE the B operand of a k16 step (guide 3, "an accumulator tile as the next MFMA's
+//                              operand": element j of lane half h is hidden unit 8 (j >> 2) + 4 h + (j & 3) of the tile), so
+//                              ff.net[2]'s weight columns are stored in THAT order (packing.pack_ffn_w2) and no lane ever moves.
+//     Both accumulator sets are pinned by inline-asm MFMAs (acc1 in vector registers -- the GEGLU reads it --, out in
+//     accumulator registers): left to hipcc, loop-carried 16-register tiles were renamed at ~190 v_accvgpr copies per 64 hidden.
+//   * Weights: W1 tile stages [32 rows x C] (20 KB), LDS-DMA, ring of four, landed ONE interval ahead so a rolling window of A
+//     fragments runs across interval boundaries; W2 stages [C rows x 32 hidden] (20 KB, two tiles), ring of three, issued every
+//     other interval, the DMA instructions spread one at a time over the interval's k loop.  Static schedule, counted
+//     `s_waitcnt vmcnt(N)` + raw `s_barrier` once per interval; the issue continues past the end (wrapping to stages nobody
+//     reads) so the count never changes.  No ordinary global load lives inside the loop (hipcc would drain the DMA queue for
+//     it): ff.net[0]'s bias and LayerNorm's gamma / beta are staged in LDS.
+//   * Measured: 328-336 us at M = 98 304, C = 320 against ~450 us for the three launches it replaces; the loop
+//     runs at ~2 300 cycles per interval for 960 cycles of MFMA -- ablations remove the GEGLU, the fragment reads and GEMM 2's
+//     MFMAs at ~15 / 6 / 13 % each, ADDITIVELY, in every arrangement of the stream tried (chunked, pipelined, piecewise).
+//   * Epilogue: (out + b2) + x in fp32, transposed through LDS (the rings are free by then) to whole 32-byte row chunks; the
+//     residual rows of a half are requested together.
 //
 // L2 -> LDS bytes per FLOP are half those of the 128 x 160 tile GEMM (the activations are never re-staged): 7.6 B / kFLOP.
-// Static DMA schedule (counted `s_waitcnt vmcnt`, raw `s_barrier`): every GEMM-1 interval issues 4 + 2 LDS-DMA instructions per
-// wave (next-but-two W1 stage, a fifth of the next chunk's W2 slice) -- also past the end, wrapping to stages nobody reads, so
-// the counts never change -- and waits `vmcnt(8)` = "the stage after the current one has landed".  No ordinary global load
-// lives inside the loop (hipcc would drain the DMA queue for it): ff.net[0]'s bias and LayerNorm's gamma / beta are staged in LDS.
+#include <type_traits>
+
 #include "common.hpp"
 #include "vface_kernels.hpp"
 
 namespace {
 
+constexpr int ffn_ring(int n, int want) { for (int r = want; r > 1; --r) if (n % r == 0) return r; return 1; }
+
 template <class TT, int C>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
-    constexpr int KS = C / 16;          // k16 steps of GEMM 1
-    constexpr int KT = C / 64;          // 64-deep W1 stages per hidden chunk (4 k16 steps each)
-    constexpr int NOT = C / 32;         // output row tiles of GEMM 2
-    constexpr int NCH = 4 * C / 64;     // hidden chunks
-    constexpr int NW1 = 4;              // W1 stage ring
-    constexpr int W1E = 128 * 64;       // elements per W1 stage
-    constexpr int W2E = C * 64;         // elements per W2 stage (one chunk's [C x 64] slice)
-    constexpr int W2OPS = C / 32;       // LDS-DMA instructions per wave per W2 stage: 2 per GEMM-1 interval
-    constexpr int TOT = NCH * KT;       // W1 stages in all
-    static_assert(C % 64 == 0 && W2OPS == 2 * KT, "C must be a multiple of 64");
+    constexpr int KS = C / 16;          // k16 steps of GEMM 1 = MFMAs per tile
+    constexpr int NOT = C / 32;         // output row tiles of GEMM 2 = its MFMAs per tile
+    constexpr int NT = 4 * C / 16;      // hidden tiles
+    constexpr int NW1 = 4, NW2 = 3;     // stage rings
+    constexpr int W1E = 32 * C;         // elements per W1 stage: [32 rows][C]
+    constexpr int W2E = C * 32;         // elements per W2 stage: [C rows][32 hidden]
+    constexpr int OPS = C / 64;         // LDS-DMA instructions per wave per stage (either kind): 1 KB each
+    constexpr int RA = ffn_ring(KS, 5); // A-fragment window of GEMM 1 (reads run RA steps ahead, across interval boundaries)
+    constexpr int RB = ffn_ring(NOT, 5);// the same for GEMM 2
+    static_assert(C % 64 == 0 && C <= 320, "C: a multiple of 64, at most 320 (accumulators of C / 32 output tiles per wave)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     E* sW1 = reinterpret_cast<E*>(smem_raw);
     E* sW2 = sW1 + NW1 * W1E;
-    float* sB1 = reinterpret_cast<float*>(sW2 + 2 * W2E);   // ff.net[0] bias, [8 C] fp32 in packed row order
-    float* sGB = sB1 + 8 * C;                               // gamma [C], beta [C]
+    float* sB1 = reinterpret_cast<float*>(sW2 + NW2 * W2E);   // ff.net[0] bias, [8 C] fp32 in packed row order
+    float* sGB = sB1 + 8 * C;                                 // gamma [C], beta [C]
 
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int t_ = threadIdx.x, lane = t_ & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
     const int fr = lane & 31, fh = lane >> 5;
     const long tok0 = (long)blockIdx.x * 128 + wave * 32;
 
     // ---- bias of GEMM 1, gamma, beta into LDS (ordinary loads: before any LDS-DMA is in flight)
-    for (int i = t; i < 8 * C / 4; i += 256) reinterpret_cast<float4*>(sB1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
-    for (int i = t; i < C / 4; i += 256) {
+    for (int i = t_; i < 8 * C / 4; i += 256) reinterpret_cast<float4*>(sB1)[i] = reinterpret_cast<const float4*>(p.b1)[i];
+    for (int i = t_; i < C / 4; i += 256) {
         reinterpret_cast<float4*>(sGB)[i] = reinterpret_cast<const float4*>(p.gamma)[i];
         reinterpret_cast<float4*>(sGB + C)[i] = reinterpret_cast<const float4*>(p.beta)[i];
     }
@@ -111,54 +122,52 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
         }
     }
 
-    // ---- weight streams: buffer descriptors, per-lane source offsets (the LDS image of one DMA instruction is lane-linear:
-    // 8 rows x 8 sixteen-byte slots; the rows' XOR swizzle is applied on the SOURCE chunk, as in gemm.hip); the stage's base goes
-    // in the instruction's scalar offset
-    const __amdgpu_buffer_rsrc_t rW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W1), 0, (int)(8u * C * C * 2u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W2p), 0, (int)(4u * C * C * 2u), 0x00020000);
-    int w1_off[4];          // (row * C + 8 * chunk) * 2 for this lane's slot of the wave's i-th instruction of a W1 stage
+    // ---- weight streams.  The LDS image of one DMA instruction is lane-linear (64 sixteen-byte slots); a stage is written in
+    // its reading order and the XOR swizzles that make the fragment reads conflict-free are applied on the SOURCE chunk.
+    //   W1 stage = [32 rows][C / 8 slots]: slot of k chunk c of row r = (c & ~7) | ((c & 7) ^ ((r >> 1) & 7))
+    //   W2 stage = [C rows][4 slots]:      slot of chunk c of row r   = c ^ ((r >> 2) & 3)
+    const i32x4_t rW1 = raw_buffer_rsrc(p.W1, 8u * C * C * 2u), rW2 = raw_buffer_rsrc(p.W2p, 4u * C * C * 2u);
+    const unsigned ldsW1 = lds_addr_of(sW1), ldsW2 = lds_addr_of(sW2);
+    constexpr int SPR = C / 8;          // 16-byte slots per W1 row
+    int w1_off[OPS], w2_off[OPS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = wave * 32 + i * 8 + (lane >> 3);
-        const int ch = (lane & 7) ^ ((row >> 1) & 7);
-        w1_off[i] = (row * C + ch * 8) * 2;
+    for (int i = 0; i < OPS; ++i) {
+        const int id = (wave * OPS + i) * 64 + lane;          // slot index inside the stage
+        const int r1 = id / SPR, s1 = id - r1 * SPR;
+        const int c1 = (s1 & ~7) | ((s1 & 7) ^ ((r1 >> 1) & 7));
+        w1_off[i] = (r1 * C + c1 * 8) * 2;
+        const int r2 = id >> 2, s2 = id & 3;
+        const int c2 = s2 ^ ((r2 >> 2) & 3);
+        w2_off[i] = (r2 * 4 * C + c2 * 8) * 2;
     }
-    int w2_off[W2OPS];      // (row * 4C + 8 * chunk) * 2
+    auto issue_w1_op = [&](int tile, int i) {     // piece i of the W1 stage of hidden tile `tile` (wrapped) -> ring slot tile % NW1
+        const int base = ((tile % NT) * 32 * C) * 2;
+        const unsigned dst = ldsW1 + (unsigned)(((tile % NW1) * W1E + wave * OPS * 512) * 2);
+        raw_lds_dma16(rW1, dst + i * 1024, w1_off[i], base);
+    };
+    auto issue_w2_op = [&](int st, int i) {       // piece i of W2 stage st = hidden tiles 2 st, 2 st + 1 (wrapped) -> slot st % NW2
+        const int base = ((st % (NT / 2)) * 32) * 2;
+        const unsigned dst = ldsW2 + (unsigned)(((st % NW2) * W2E + wave * OPS * 512) * 2);
+        raw_lds_dma16(rW2, dst + i * 1024, w2_off[i], base);
+    };
+    auto issue_w1 = [&](int tile) {
 #pragma unroll
-    for (int i = 0; i < W2OPS; ++i) {
-        const int row = wave * (C / 4) + i * 8 + (lane >> 3);
-        const int ch = (lane & 7) ^ ((row >> 1) & 7);
-        w2_off[i] = (row * 4 * C + ch * 8) * 2;
-    }
-    auto issue_w1 = [&](int g) {        // stage g (wrapped): chunk g / KT rows, k tile g % KT -> ring slot g % NW1
-        const int gw = g % TOT;
-        const int c = gw / KT, kt = gw - c * KT;
-        const int base = (c * 128 * C + kt * 64) * 2;
-        E* dst = sW1 + (g % NW1) * W1E + (wave * 32) * 64;
+        for (int i = 0; i < OPS; ++i) issue_w1_op(tile, i);
+    };
+    auto issue_w2 = [&](int st) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = w1_off[i];
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW1, LDS_PTR(dst + i * 8 * 64), 16, off, base, 0, 0);
-        }
+        for (int i = 0; i < OPS; ++i) issue_w2_op(st, i);
     };
-    auto issue_w2 = [&](int c, int i) { // the wave's i-th instruction of chunk c's (wrapped) [C x 64] slice -> buffer c & 1
-        const int base = ((c % NCH) * 64) * 2;
-        E* dst = sW2 + (c & 1) * W2E + (wave * (C / 4) + i * 8) * 64;
-        const int off = w2_off[i];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW2, LDS_PTR(dst), 16, off, base, 0, 0);
+    // fragment reads (A operands of the 32x32x16 MFMA): 32 rows x one 16-byte chunk per lane half
+    auto w1_frag = [&](int tile, int ks) -> V8 {
+        const int c = 2 * ks + fh;
+        const int slot = (c & ~7) | ((c & 7) ^ ((fr >> 1) & 7));
+        return *reinterpret_cast<const V8*>(sW1 + (tile % NW1) * W1E + fr * C + slot * 8);
     };
-
-    // fragment reads (A operands of the 32x32x16 MFMA): 32 rows x one 16-byte k chunk; rows 2i and 2i + 1 share a slot of the
-    // (row >> 1) & 7 swizzle but sit in different halves of the 64-bank row: conflict-free
-    auto w1_frag = [&](int buf, int ks, int rt) -> V8 {       // ks: k16 step inside the stage (0..3)
-        const int row = rt * 32 + fr;
-        const int slot = (ks * 2 + fh) ^ ((row >> 1) & 7);
-        return *reinterpret_cast<const V8*>(sW1 + buf * W1E + row * 64 + slot * 8);
-    };
-    auto w2_frag = [&](int buf, int ks, int ot) -> V8 {       // ks: k16 step inside the chunk (0..3) = hidden tile
+    auto w2_frag = [&](int tile, int ot) -> V8 {
         const int row = ot * 32 + fr;
-        const int slot = (ks * 2 + fh) ^ ((row >> 1) & 7);
-        return *reinterpret_cast<const V8*>(sW2 + buf * W2E + row * 64 + slot * 8);
+        const int slot = (2 * (tile & 1) + fh) ^ ((row >> 2) & 3);
+        return *reinterpret_cast<const V8*>(sW2 + ((tile >> 1) % NW2) * W2E + row * 32 + slot * 8);
     };
 
     f16_t out[NOT];
@@ -167,117 +176,148 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[ot][r] = 0.f;
 
-    // ---- prime the pipeline: W1 stages 0..2, all of chunk 0's W2 slice
+    // ---- prime the pipeline: W1 stages 0..2, W2 stage 0
     __syncthreads();                     // nothing else touches LDS before the DMA lands
 #pragma unroll
     for (int g = 0; g < 3; ++g) issue_w1(g);
-#pragma unroll
-    for (int i = 0; i < W2OPS; ++i) issue_w2(0, i);
+    issue_w2(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     raw_barrier();
 
-    V8 af[2][4];                         // W1 fragments of two consecutive k16 steps
+    V8 af[RA], wf[RB], hbE, hbO;         // hbE / hbO: GEGLU results (GEMM 2 B operands) of even / odd tiles
+    f16_t accA, accB;                    // GEMM 1 accumulators of even / odd tiles
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) af[0][rt] = w1_frag(0, 0, rt);
+    for (int i = 0; i < RA; ++i) af[i] = w1_frag(0, i);
 
-    for (int c = 0; c < NCH; ++c) {
-        f16_t acc1[4];                   // in VECTOR registers (the GEGLU reads them), `out` in accumulator registers: both pinned
-                                         // through inline-asm MFMAs -- left to hipcc, loop-carried tiles were renamed across the
-                                         // chunk loop at ~190 v_accvgpr copies per chunk of a kernel that is bound by issue slots
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            const int g = c * KT + kt;
-            // top of the interval: this wave's share of stage g + 1 has landed (everything but its 8 youngest DMA instructions);
-            // behind the barrier every wave's has, and every wave is done with stage g - 1, whose ring slot stage g + 3 takes
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            raw_barrier();
-            issue_w1(g + 3);
-            issue_w2(c + 1, 2 * kt);
-            issue_w2(c + 1, 2 * kt + 1);
-            const int buf = g % NW1, nbuf = (g + 1) % NW1;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                // fragments of the NEXT k16 step go out before this step's MFMAs (the first step of the next stage too: it has
-                // landed, see the wait above; after the chunk's last stage they are read behind GEMM 2 instead)
-                if (ks < 3) {
-#pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) af[(ks + 1) & 1][rt] = w1_frag(buf, ks + 1, rt);
-                } else if (kt + 1 < KT) {
-#pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) af[0][rt] = w1_frag(nbuf, 0, rt);
-                }
-#pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
-                    if (kt == 0 && ks == 0) TT::mfma32x32_vzero(acc1[rt], af[ks & 1][rt], xf[4 * kt + ks]);
-                    else TT::mfma32x32_vacc(acc1[rt], af[ks & 1][rt], xf[4 * kt + ks]);
-                }
-            }
-        }
-        // ---- GEMM 2's first weight fragments go out before the GEGLU: their LDS latency runs under its vector work
-        // (this chunk's slice landed and became visible at the barrier of interval (c, 2) at the latest; KT < 3: see below)
-        constexpr int G2 = 5 <= NOT ? (NOT % 5 == 0 ? 5 : 2) : NOT;      // fragments per read group
-        constexpr int NG2 = 4 * NOT / G2;
-        static_assert((4 * NOT) % G2 == 0);
-        const int b2 = c & 1;
-        V8 wfr[2][G2];
-        auto rd2 = [&](int grp, int slot) {
-#pragma unroll
-            for (int u = 0; u < G2; ++u) {
-                const int idx = grp * G2 + u;
-                wfr[slot][u] = w2_frag(b2, idx / NOT, idx % NOT);
-            }
-        };
-        if constexpr (KT < 3) {
-            // short K: the last pieces of this chunk's W2 slice may still be among the 8 youngest DMA instructions
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            raw_barrier();
-        }
-        rd2(0, 0);
-        raw_mfma_to_valu_gap();          // acc1's last MFMA -> the vector reads below
-        // ---- GEGLU (attention.py:37-45: x, gate = proj(x).chunk(2); x * gelu(gate)) on the accumulators; bias from LDS.
-        // Tile rt = packed rows 32 rt .. : hidden units 16 rt .. 16 rt + 15 of the chunk, value rows first, then their gates.
-        // Register q < 8 of a lane is value row (q & 3) + 8 (q >> 2) + 4 h, register q + 8 the same unit's gate.
-        V8 hb[4];                        // B operand of GEMM 2's k16 step rt
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            const float* bp = sB1 + c * 128 + rt * 32 + fh * 4;
+    // One interval of the three-deep pipeline: GEMM 1 of tile t (H1) || GEGLU of tile t - 1 (HG) || GEMM 2 of tile t - 2 (H2),
+    // one instruction stream: per k16 step one MFMA of GEMM 1, every other step one of GEMM 2, every other step one GEGLU value.
+    // `cur` receives tile t's sums, `prev` holds tile t - 1's; `hw` receives tile t - 1's GEGLU, `hr` holds tile t - 2's.
+    auto interval = [&](int t, f16_t& cur, f16_t& prev, V8& hw, V8& hr, auto h1_tag, auto hg_tag, auto h2_tag, auto even_tag) {
+        constexpr bool H1 = decltype(h1_tag)::value, HG = decltype(hg_tag)::value, H2 = decltype(h2_tag)::value;
+        constexpr bool EVEN = decltype(even_tag)::value;
+        // top of the interval: this wave's share of W1 stage t + 1 has landed (everything but its 2 OPS (= 10) youngest DMA
+        // instructions: intervals t - 1 and t - 2 issued that many after it); behind the barrier every wave's has, every wave is
+        // done with W1 stage t - 1 (ring slot of stage t + 3) and, in even intervals, with the W2 stage of tiles t - 4, t - 3
+        // (issue order inside an even interval is W1 piece, W2 piece, W1 piece, ...: behind the last W1 piece of stage t + 1 come
+        // one W2 piece and interval t - 1's OPS pieces when t is even, interval t - 1's 2 OPS pieces when t is odd)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EVEN ? OPS + 1 : 2 * OPS) : "memory");
+        raw_barrier();
+        // (the stages of this interval -- W1 stage t + 3, in even intervals W2 stage t / 2 + 1 -- are issued one DMA instruction
+        // at a time inside the k loop below: a burst of them at the top cost each wave the whole CU's address-unit time)
+        float ba[8], bg[8], hv[8];
+        if constexpr (HG) {
+            gap_mfma_result_to_valu(prev);     // tile t - 1's last MFMA -> the vector reads below
+            const float* bp = sB1 + (t - 1) * 32 + fh * 4;
             const float4 v0 = *reinterpret_cast<const float4*>(bp), v1 = *reinterpret_cast<const float4*>(bp + 8);
             const float4 g0 = *reinterpret_cast<const float4*>(bp + 16), g1 = *reinterpret_cast<const float4*>(bp + 24);
-            const float ba[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            const float bg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-            for (int qi = 0; qi < 8; ++qi) {
-                const float a = acc1[rt][qi] + ba[qi], gt = acc1[rt][qi + 8] + bg[qi];
-                hb[rt][qi] = from_f32<E>(a * gelu_erf_f(gt));
+            ba[0] = v0.x; ba[1] = v0.y; ba[2] = v0.z; ba[3] = v0.w; ba[4] = v1.x; ba[5] = v1.y; ba[6] = v1.z; ba[7] = v1.w;
+            bg[0] = g0.x; bg[1] = g0.y; bg[2] = g0.z; bg[3] = g0.w; bg[4] = g1.x; bg[5] = g1.y; bg[6] = g1.z; bg[7] = g1.w;
+        }
+        // GEGLU (attention.py:37-45: x, gate = proj(x).chunk(2); x * gelu(gate), erf form) of tile t - 1's eight hidden units per
+        // lane, cut into 24 pieces of 5-7 vector instructions -- piece (value q, stage s) goes into the gap behind the (3 q + s)-th
+        // MFMA of the interval.  A wave issues in order: an MFMA behind an MFMA waits for the matrix pipe (32 cycles), and only the
+        // instructions BETWEEN two MFMAs run beside the first; the earlier layout (two MFMAs, then a whole value's 22 dependent
+        // vector instructions) measured as the plain SUM of matrix and vector time.  The arithmetic and its order are those of
+        // gelu_erf_f (common.hpp): the result is bit-identical to the three-kernel path's epilogue.  Empty asm statements pin each
+        // piece in its gap (volatile asm keeps its order; hipcc otherwise packs pieces pairwise into v_pk_*_f32 and hoists them).
+        float gG[8], gA[8], gX[8], gT[8], gE[8], gP[8];
+        auto gelu_piece = [&](int idx) {
+            if (idx >= 24) return;
+            const int q = idx / 3, st = idx % 3;
+            if (st == 0) {
+                float a = prev[q], gt = prev[q + 8];
+                asm volatile("" : "+v"(a), "+v"(gt));
+                a += ba[q];
+                gt += bg[q];
+                const float xs = gt * 0.70710678118654752440f;
+                const float z = fabsf(xs);
+                float tt = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+                float ee = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+                asm volatile("" : "+v"(tt), "+v"(ee));
+                gG[q] = gt; gA[q] = a; gX[q] = xs; gT[q] = tt; gE[q] = ee;
+            } else if (st == 1) {
+                float tt = gT[q];
+                asm volatile("" : "+v"(tt));
+                float poly = fmaf(1.061405429f, tt, -1.453152027f);
+                poly = fmaf(poly, tt, 1.421413741f);
+                poly = fmaf(poly, tt, -0.284496736f);
+                poly = fmaf(poly, tt, 0.254829592f);
+                poly *= tt;
+                asm volatile("" : "+v"(poly));
+                gP[q] = poly;
+            } else {
+                float poly = gP[q];
+                asm volatile("" : "+v"(poly));
+                const float r = 1.0f - poly * gE[q];
+                const float erf_ = copysignf(r, gX[q]);
+                float hq = gA[q] * (0.5f * gG[q] * (1.0f + erf_));
+                asm volatile("" : "+v"(hq));
+                hv[q] = hq;
             }
-        }
-        raw_valu_to_mfma_gap();          // hb's last conversion -> the MFMAs below
-        // ---- GEMM 2: out[C x 32 tokens] += W2[:, chunk] h.  Fragment reads run one group ahead, pinned: hipcc otherwise reads
-        // each fragment right before its MFMA and waits for it there (one exposed LDS round trip per MFMA).
+        };
+        int gap = 0;                                 // (compile-time after unrolling)
 #pragma unroll
-        for (int grp = 0; grp < NG2; ++grp) {
-            if (grp + 1 < NG2) rd2(grp + 1, (grp + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < G2; ++u) {
-                const int idx = grp * G2 + u;
-                const int ks = idx / NOT, ot = idx % NOT;
-                TT::mfma32x32_acc(out[ot], wfr[grp & 1][u], hb[ks]);
+        for (int ks = 0; ks < KS; ++ks) {
+            if constexpr (H1) {
+                if (ks == 0) TT::mfma32x32_vzero(cur, af[ks % RA], xf[ks]);
+                else TT::mfma32x32_vacc(cur, af[ks % RA], xf[ks]);
+                // refill the window slot of the PREVIOUS MFMA (a load into the registers the MFMA just issued is still reading
+                // waits for it, and everything behind the load with it: measured as matrix + vector time in series): step
+                // ks - 1 + RA of this tile, or of the next (its stage has landed)
+                af[(ks + RA - 1) % RA] = (ks - 1 + RA < KS) ? w1_frag(t, ks - 1 + RA) : w1_frag(t + 1, ks - 1 + RA - KS);
+            }
+            if (ks % 4 == 1) issue_w1_op(t + 3, ks / 4);                    // (KS = 4 OPS)
+            if constexpr (EVEN) { if (ks % 4 == 3) issue_w2_op(t / 2 + 1, ks / 4); }
+            if constexpr (HG) {
+                if constexpr (KS >= 16) { gelu_piece(gap); ++gap; }
+                else { for (int u = 0; u < (24 + KS + KS / 2 - 1) / (KS + KS / 2); ++u) { gelu_piece(gap); ++gap; } }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (H2) {
+                if (ks % 2 == 0) {
+                    const int ot = ks / 2;           // (KS = 2 NOT)
+                    TT::mfma32x32_acc(out[ot], wf[ot % RB], hr);
+                    // refill the previous MFMA's slot: tile t - 2's fragment ot - 1 + RB, or the next tile's (tile t - 1: its W2
+                    // stage landed intervals ago)
+                    wf[(ot + RB - 1) % RB] = (ot - 1 + RB < NOT) ? w2_frag(t - 2, ot - 1 + RB) : w2_frag(t - 1, ot - 1 + RB - NOT);
+                }
+            } else if (ks >= KS - RB && t == 1) {
+                wf[ks - (KS - RB)] = w2_frag(0, ks - (KS - RB));      // interval 1: GEMM 2's window for tile 0
+            }
+            if constexpr (HG) {
+                if (ks % 2 == 0) {
+                    if constexpr (KS >= 16) { gelu_piece(gap); ++gap; }
+                    else { for (int u = 0; u < (24 + KS + KS / 2 - 1) / (KS + KS / 2); ++u) { gelu_piece(gap); ++gap; } }
+                }
+            }
+            // pin the gap (hipcc otherwise regroups the interleave, which is the point of the pipeline)
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (c + 1 < NCH) {               // first fragments of the next chunk's first stage (landed since interval (c, KT - 1))
-            const int nb = ((c + 1) * KT) % NW1;
+        if constexpr (HG) {
 #pragma unroll
-            for (int rt = 0; rt < 4; ++rt) af[0][rt] = w1_frag(nb, 0, rt);
+            for (int qi = 0; qi < 8; ++qi) hw[qi] = from_f32<E>(hv[qi]);
+            gap_valu_result_to_mfma(hw);
         }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    static_assert(KS == 2 * NOT && NT % 2 == 0 && NT >= 4);
+    //        t      cur   prev  hw   hr    H1   HG   H2   EVEN     (tile t -> accA / hbE when t is even)
+    interval(0,      accA, accB, hbO, hbE,  T_{}, F_{}, F_{}, T_{});
+    interval(1,      accB, accA, hbE, hbO,  T_{}, T_{}, F_{}, F_{});
+    for (int t = 2; t < NT; t += 2) {
+        interval(t,     accA, accB, hbO, hbE, T_{}, T_{}, T_{}, T_{});
+        interval(t + 1, accB, accA, hbE, hbO, T_{}, T_{}, T_{}, F_{});
     }
+    interval(NT,     accA, accB, hbO, hbE,  F_{}, T_{}, T_{}, T_{});
+    interval(NT + 1, accB, accA, hbE, hbO,  F_{}, F_{}, T_{}, F_{});
 
     // ---- epilogue: (out + b2) + x, half the channels of a wave's 32 tokens at a time through LDS (row pitch C / 2 + 4 floats:
     // consecutive tokens one 16-byte slot apart), read back as whole 32-byte row chunks
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    raw_barrier();                       // every wave is done with the weight ring: it becomes scratch
-    raw_mfma_to_valu_gap();              // out's last MFMA -> the accumulator reads below
+    raw_barrier();                       // every wave is done with the weight rings: they become scratch
+#pragma unroll
+    for (int ot = 0; ot < NOT; ++ot) gap_acc_result_to_valu(out[ot]);     // out's last MFMA -> the accumulator reads below
     constexpr int NH = (NOT + 1) / 2;    // output tiles per half
     constexpr int SP = NH * 32 + 4;
     float* scr = reinterpret_cast<float*>(smem_raw) + wave * (32 * SP);
@@ -286,6 +326,20 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     for (int hf = 0; hf < 2; ++hf) {
         const int ot0 = hf * NH, nt = (hf == 0) ? NH : NOT - NH;      // tiles [ot0, ot0 + nt)
         if (nt <= 0) continue;
+        constexpr int ITM = (32 * NH * 4 + 63) / 64;                  // items (token, 8-channel chunk) per lane, upper bound
+        const int CH = nt * 4;           // 8-channel chunks per row of this half
+        // the residual rows of the half are requested before the transposes: one HBM latency per half, not one per item
+        float4 r0[ITM], r1[ITM];
+#pragma unroll
+        for (int k = 0; k < ITM; ++k) {
+            const int it = lane + 64 * k;
+            if (it < 32 * CH) {
+                const int tok = it / CH, ch = it - tok * CH;
+                const float* xr = p.x32 + (tok0 + tok) * p.ldx + ot0 * 32 + ch * 8;
+                r0[k] = *reinterpret_cast<const float4*>(xr);
+                r1[k] = *reinterpret_cast<const float4*>(xr + 4);
+            }
+        }
 #pragma unroll
         for (int o = 0; o < NH; ++o) {
             if (o >= nt) continue;
@@ -295,28 +349,29 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
                     make_float4(out[ot0 + o][4 * q4], out[ot0 + o][4 * q4 + 1], out[ot0 + o][4 * q4 + 2], out[ot0 + o][4 * q4 + 3]);
         }
         // (LDS operations of one wave execute in order: the reads below see the writes above)
-        const int CH = nt * 4;           // 8-channel chunks per row of this half
-        for (int it = lane; it < 32 * CH; it += 64) {
-            const int tok = it / CH, ch = it - tok * CH;
-            const float* sp = scr + tok * SP + ch * 8;
-            const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
-            const int col = ot0 * 32 + ch * 8;
-            const float4 c0 = *reinterpret_cast<const float4*>(p.b2 + col), c1 = *reinterpret_cast<const float4*>(p.b2 + col + 4);
-            const long row = tok0 + tok;
-            const float* xr = p.x32 + row * p.ldx + col;
-            const float4 r0 = *reinterpret_cast<const float4*>(xr), r1 = *reinterpret_cast<const float4*>(xr + 4);
-            const float v[8] = {(a0.x + c0.x) + r0.x, (a0.y + c0.y) + r0.y, (a0.z + c0.z) + r0.z, (a0.w + c0.w) + r0.w,
-                                (a1.x + c1.x) + r1.x, (a1.y + c1.y) + r1.y, (a1.z + c1.z) + r1.z, (a1.w + c1.w) + r1.w};
-            if (out16) {
-                V8 o;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
-                *reinterpret_cast<V8*>(out16 + row * p.ldo + col) = o;
-            }
-            if (p.out32) {
-                float* d = p.out32 + row * p.ldo32 + col;
-                *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        for (int k = 0; k < ITM; ++k) {
+            const int it = lane + 64 * k;
+            if (it < 32 * CH) {
+                const int tok = it / CH, ch = it - tok * CH;
+                const float* sp = scr + tok * SP + ch * 8;
+                const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
+                const int col = ot0 * 32 + ch * 8;
+                const float4 c0 = *reinterpret_cast<const float4*>(p.b2 + col), c1 = *reinterpret_cast<const float4*>(p.b2 + col + 4);
+                const long row = tok0 + tok;
+                const float v[8] = {(a0.x + c0.x) + r0[k].x, (a0.y + c0.y) + r0[k].y, (a0.z + c0.z) + r0[k].z, (a0.w + c0.w) + r0[k].w,
+                                    (a1.x + c1.x) + r1[k].x, (a1.y + c1.y) + r1[k].y, (a1.z + c1.z) + r1[k].z, (a1.w + c1.w) + r1[k].w};
+                if (out16) {
+                    V8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
+                    *reinterpret_cast<V8*>(out16 + row * p.ldo + col) = o;
+                }
+                if (p.out32) {
+                    float* d = p.out32 + row * p.ldo32 + col;
+                    *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                }
             }
         }
     }
@@ -324,8 +379,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
 
 template <class TT, int C>
 int launch_c(const FfnParams& p, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(4 * 128 * 64 + 2 * C * 64) * 2 + (size_t)10 * C * 4;
-    static_assert((size_t)4 * 32 * (((C / 32 + 1) / 2) * 32 + 4) * 4 <= (size_t)(4 * 128 * 64 + 2 * C * 64) * 2, "epilogue scratch fits the weight ring");
+    constexpr size_t lds = (size_t)(4 * 32 * C + 3 * C * 32) * 2 + (size_t)10 * C * 4;
+    static_assert((size_t)4 * 32 * (((C / 32 + 1) / 2) * 32 + 4) * 4 <= (size_t)(4 * 32 * C + 3 * C * 32) * 2, "epilogue scratch fits the weight rings");
     auto kern = ffn_fused_kernel<TT, C>;
     static VfOncePerDevice attr_set;
     if (lds > 64 * 1024 && !attr_set.set_lds(reinterpret_cast<const void*>(kern), (int)lds)) return VF_ERR_LAUNCH;
