@@ -108,6 +108,7 @@ class FamilyTimer:
                  `im2col` = gemm.hip's implicit GEMM (stride 2, the 9->320 and 320->4 convolutions);
       gemm       gemm_kernel<T, MODE_PLAIN, ..>: every Linear / 1x1 conv (sub-classes: `ff1` = the GEGLU projection, `n320` = the
                  level-0 projections with N = 320, `other`); FLOPs = 2 M N K as executed (incl. the folded FSAI K = 2d);
+                 `ffn_fused` = ffn_fused_kernel (ffn.hip): LayerNorm + both FeedForward GEMMs + residual of a level-0 block;
       attention  attn_kernel<T, DH, ..> by head dim; FLOPs = the ALGORITHMIC 4 n nk dh per (output sample, head) --
                  the shared-score form executes fewer;
       norm       layernorm / groupnorm apply+finalize: HBM-bound, reported in GB/s of algorithmic bytes."""
@@ -169,6 +170,15 @@ class FamilyTimer:
             key = "ff1" if (kw.get("flags", 0) & hip.EPI_GEGLU) else ("n320" if (N == 320 and M >= 4096) else "other")
             timer._timed("gemm", key, 2.0 * M * N * K, 1, call)
         hip.gemm = gemm
+        orig_ffn = hip.ffn_fused
+
+        def ffn_fused(x32, gamma, beta, w1, b1, w2p, b2, out16, *, M, C_, **kw):
+            # LayerNorm + ff.net[0] (GEGLU, N = 8 C) + ff.net[2] (K = 4 C) + residual in one launch: 2 M (8 C C + 4 C C) FLOPs
+            call = lambda: orig_ffn(x32, gamma, beta, w1, b1, w2p, b2, out16, M=M, C_=C_, **kw)
+            if not timer.on:
+                return call()
+            timer._timed("gemm", "ffn_fused", 24.0 * M * C_ * C_, 1, call)
+        hip.ffn_fused = ffn_fused
         orig_attn = hip.attention
 
         def attention(q, k, v, out, *, B, heads, n, nk, dh, v_sets=1, **kw):
@@ -519,7 +529,7 @@ def main():
             return o
 
         by_family = {k: fam_total(k) for k in ("gemm", "conv", "attention", "norm")}
-        by_family["gemm"]["kernel"] = "gemm_kernel<T, MODE_PLAIN, NT, DB, PERSIST, RM> (gemm.hip): every Linear / 1x1 conv; FLOPs as executed (2 M N K)"
+        by_family["gemm"]["kernel"] = "gemm_kernel<T, MODE_PLAIN, NT, DB, PERSIST, RM> (gemm.hip): every Linear / 1x1 conv, + ffn_fused_kernel<T, C> (ffn.hip): the level-0 FeedForward in one launch; FLOPs as executed (2 M N K)"
         by_family["conv"]["kernel"] = "conv_patch_kernel<T, NT, KH, KW, ..> (conv.hip) + gemm_kernel<T, MODE_CONV_*> (im2col); FLOPs as executed"
         by_family["attention"]["kernel"] = "attn_kernel<T, DH, QT, G, LAZY> (attention.hip); algorithmic FLOPs 4 n nk dh per (output sample, head)"
         by_family["norm"]["kernel"] = "layernorm_kernel, gn_apply_kernel, gn_finalize_cols, flow_warp_kernel (pointwise.hip): HBM-bound, algorithmic bytes"
@@ -527,7 +537,7 @@ def main():
         mfma_fams = ("gemm", "conv", "attention")
         dom = max(mfma_fams, key=lambda k: by_family[k]["ms"])
         d = by_family[dom]
-        prefixes = {"gemm": ("gemm_kernel<F16, 0,", "gemm_kernel<BF16, 0,"), "conv": ("conv_patch_kernel", "gemm_kernel<F16, 1,", "gemm_kernel<F16, 2,"),
+        prefixes = {"gemm": ("gemm_kernel<F16, 0,", "gemm_kernel<BF16, 0,", "ffn_fused_kernel"), "conv": ("conv_patch_kernel", "gemm_kernel<F16, 1,", "gemm_kernel<F16, 2,"),
                     "attention": ("attn_kernel",)}[dom]
         traffic, traffic_src = traffic_from_profiles(prefixes, F_ == 8 and h == 64 and a.fusion == "replace" and a.dtype == "fp16" and world == 1)
         out = {
