@@ -213,6 +213,37 @@ int vface_flow_warp(const void* src, int64_t ld_src, int64_t fs_src, const void*
  * H, W multiples of `factor`).  RAFT's own weights are third-party: the flow VALUES are outside this library. */
 int vface_flow_to_latent(const float* flow_px, float* out, int pairs, int H, int W, int factor, void* stream);
 
+/* ---- paste-back of a swapped crop into its original frame (VFace_inference_batch.py:597-636) ----------------
+ * The reference runs these steps per frame on the host with numpy, Pillow and torchvision; each entry point replaces one of
+ * them on device buffers, with Pillow's 8-bit arithmetic restated exactly (oracle/paste.py is pinned against Pillow itself).
+ *
+ * vface_frame_to_u8: `torch.clamp((x + 1) / 2, 0, 1)` (:597), `255. * x` and `.astype(np.uint8)` (:606-608).
+ *   x planar [frames][3][H][W] in [-1, 1], in_kind 0 fp16 | 1 bf16 | 2 fp32; out interleaved [frames][H][W][3]. */
+int vface_frame_to_u8(const void* x, uint8_t* out, int frames, int H, int W, int in_kind, void* stream);
+
+/* One pass of `Image.resize(size, Image.BILINEAR)` on 8-bit RGB (:608, :623; Pillow Resample.c).  axis 0 resamples along x:
+ * src [frames][lines][in_n][3] -> dst [frames][lines][out_n][3]; axis 1 along y: src [frames][in_n][lines][3] -> dst
+ * [frames][out_n][lines][3] (lines = the row length).  bounds [out_n][2] = (first input sample, taps), kk [out_n][ksize] =
+ * the 22-bit fixed-point taps of Pillow's precompute_coeffs + normalize_coeffs_8bpc -- host work, built once per size pair by
+ * vface_amd/scripts/paste_back.py `resample_coeffs` and uploaded.  A resize is the x pass then the y pass. */
+int vface_resample_u8(const uint8_t* src, uint8_t* dst, int frames, int in_n, int out_n, int lines, int axis, const int32_t* bounds,
+                      const int32_t* kk, int ksize, void* stream);
+
+/* `crop.convert('RGBA') + putalpha(255)`, `.transform(frame.size, Image.PERSPECTIVE, coeffs, Image.BILINEAR)` and
+ * `frame.alpha_composite(projected)` (:627-633; Pillow Geometry.c / AlphaComposite.c) in one launch, IN PLACE on `frame`
+ * [frames][H][W][3] (the background on entry, the pasted frame on return); crop [frames][crop_h][crop_w][3].
+ * The eight coefficients (output pixel centre -> crop coordinates, the rows of `inv_transforms_all`, :625) come either from
+ * device memory (coeffs_dev [frames][8] doubles) or, for frames == 1, from the host (coeffs_host[8], passed by value);
+ * exactly one of the two must be non-NULL. */
+int vface_perspective_paste(const uint8_t* crop, int crop_w, int crop_h, uint8_t* frame, int W, int H, int frames,
+                            const double* coeffs_dev, const double* coeffs_host, void* stream);
+
+/* `get_tensor()(orig_image)` (ToTensor + Normalize(0.5, 0.5), :48-56, :611) and `transforms.Resize([H, W])` on the tensor
+ * (:612 = bilinear, align_corners false, no antialias): frame [frames][H][W][3] uint8 -> out planar [frames][3][OH][OW] fp32
+ * in [-1, 1], the VAE encoder's input for the background round trip (:615-618).  fp32 arithmetic in ATen's order; ATen's CPU
+ * kernel differs from it by <= 2 ulp (tests bound it at 2e-6). */
+int vface_frame_normalise_resize(const uint8_t* frame, int W, int H, float* out, int OW, int OH, int frames, void* stream);
+
 /* The hooked self-attention as one call (pnp_utils.py:94-287, the closure installed on attn1):
  *   x [B][n][d] (already LayerNorm'd), B = chunks * F laid out [uncond ; cond ; recon]
  *   Wqkv [3d][d]  = rows of to_q | to_k | to_v

@@ -39,15 +39,16 @@ def need_variant(h, variant):
         pytest.skip("experimental GEMM schedule: not in the product build (make VARIANTS=1)")
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
-@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (200, 72, 136), (1000, 320, 320), (24, 1280, 320), (4096, 960, 320),
-                                   (700, 160, 1096)])
+GEMM_SHAPES = [(256, 128, 64), (200, 72, 136), (1000, 320, 320), (24, 1280, 320), (4096, 960, 320), (700, 160, 1096)]
+# every shape x dtype on the automatic schedule; forced schedules: fp16 on every shape, bf16 on one
+GEMM_CASES = [(dt, *s, v) for v in VARIANTS for dt in (torch.float16, torch.bfloat16) for s in GEMM_SHAPES
+              if not (v and dt == torch.bfloat16 and s != (1000, 320, 320))]
+
+
+@pytest.mark.parametrize("dt,M,N,K,variant", GEMM_CASES)
 def test_gemm_plain_bias_residual(dt, M, N, K, variant):
     h = hip()
     need_variant(h, variant)
-    if variant and dt == torch.bfloat16 and (M, N, K) != (1000, 320, 320):
-        pytest.skip("forced variants: bf16 checked on one shape")
     a, w = rnd((M, K), 1, dt), rnd((N, K), 2, dt, 1 / math.sqrt(K))
     bias = rnd((N,), 3, torch.float32)
     res = rnd((M, N), 4, dt)
@@ -99,16 +100,16 @@ def test_gemm_geglu(variant):
     assert rel_l2(out.cpu().float(), val * F.gelu(gate)) < 1e-3
 
 
-@pytest.mark.parametrize("variant", VARIANTS)
-@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("cin,cout,H,W,stride,up", [(16, 64, 12, 10, 1, False), (64, 72, 16, 16, 2, False),
-                                                    (64, 64, 8, 8, 1, True), (320, 320, 16, 16, 1, False),
-                                                    (128, 160, 20, 12, 1, False)])
+CONV_SHAPES = [(16, 64, 12, 10, 1, False), (64, 72, 16, 16, 2, False), (64, 64, 8, 8, 1, True), (320, 320, 16, 16, 1, False),
+               (128, 160, 20, 12, 1, False)]
+CONV_CASES = [(dt, *s, v) for v in VARIANTS for dt in (torch.float16, torch.bfloat16) for s in CONV_SHAPES
+              if not (v and dt == torch.bfloat16)]          # forced schedules: fp16 only
+
+
+@pytest.mark.parametrize("dt,cin,cout,H,W,stride,up,variant", CONV_CASES)
 def test_conv3x3(dt, cin, cout, H, W, stride, up, variant):
     h = hip()
     need_variant(h, variant)
-    if variant and dt == torch.bfloat16:
-        pytest.skip("forced variants: fp16 only")
     from vface_amd.packing import pack_conv3x3
     nimg = 3
     x = rnd((nimg, cin, H, W), 1, dt)

@@ -270,3 +270,66 @@ def test_lowp_fixture_is_the_references_own_error_floor():
     for mode, key in (("plain", "plain"), ("flow_fix", "in_flow_fix"), ("replace", "in_replace")):
         e_auto, e_w = rel_l2(lp[f"tiny.{mode}_autocast_f16"], ti[key]), rel_l2(lp[f"tiny.{mode}_w16"], ti[key])
         assert 1.8e-3 < e_auto < 2.3e-3 and 1.0e-3 < e_w < 1.2e-3, (mode, e_auto, e_w)
+
+
+# ---- paste-back: the oracle's restatement of Pillow's 8-bit arithmetic is pinned against Pillow itself, on the
+# reference's own call sequence (VFace_inference_batch.py:597-636) ----------------------------------------------------------
+from oracle import paste as opaste  # noqa: E402
+
+
+def _perspective_coeffs(src_quad, dst_quad):
+    """Eight PIL coefficients mapping output (dst) pixel centres to source coordinates, from four corner pairs."""
+    A, B = [], []
+    for (x, y), (u, v) in zip(dst_quad, src_quad):
+        A += [[x, y, 1, 0, 0, 0, -u * x, -u * y], [0, 0, 0, x, y, 1, -v * x, -v * y]]
+        B += [u, v]
+    return np.linalg.solve(np.array(A, float), np.array(B, float))
+
+
+@pytest.mark.parametrize("h,w,ow,oh", [(64, 64, 128, 128), (50, 70, 33, 91), (37, 41, 100, 17), (128, 96, 96, 128), (17, 17, 17, 40),
+                                       (90, 120, 512, 512)])
+def test_paste_resize_matches_pillow(h, w, ow, oh):
+    from PIL import Image
+    img = np.random.default_rng(h * 1000 + w).integers(0, 256, (h, w, 3), dtype=np.uint8)
+    ref = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+    assert np.array_equal(opaste.resize_bilinear_u8(img, ow, oh), ref)
+    # the host-side tap tables of the product (vface_amd/scripts/paste_back.py) are the oracle's, element for element
+    from vface_amd.scripts.paste_back import resample_coeffs
+    for a, b in ((w, ow), (h, oh)):
+        pb, pk = resample_coeffs(a, b)
+        ob, ok_ = opaste.resample_coeffs(a, b)
+        assert np.array_equal(pb, ob) and np.array_equal(pk, ok_)
+
+
+@pytest.mark.parametrize("quad", [[(30.3, 20.1), (110.7, 25.2), (115.1, 100.9), (25.5, 95.5)],      # inside the frame
+                                  [(-20, -10), (100, 5), (90, 140), (10, 90)],                       # crossing its border
+                                  [(0, 0), (160, 0), (160, 120), (0, 120)]])                         # covering it
+def test_paste_perspective_composite_matches_pillow(quad):
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    sw = sh = 96
+    swapped = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+    bg = rng.integers(0, 256, (120, 160, 3), dtype=np.uint8)
+    co = _perspective_coeffs([(0, 0), (sw, 0), (sw, sh), (0, sh)], quad)
+    s = Image.fromarray(swapped).convert("RGBA")          # :629-633, statement for statement
+    pasted = Image.fromarray(bg).convert("RGBA")
+    s.putalpha(255)
+    projected = s.transform((160, 120), Image.PERSPECTIVE, co, Image.BILINEAR)
+    pasted.alpha_composite(projected)
+    ref = np.asarray(pasted)
+    assert (ref[..., 3] == 255).all()
+    assert np.array_equal(opaste.perspective_paste(swapped, bg, co), ref[..., :3])
+
+
+def test_paste_float_steps_match_numpy_and_torch():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((3, 40, 30)).astype(np.float32) * 1.2
+    ref = torch.clamp((torch.from_numpy(x) + 1.0) / 2.0, min=0.0, max=1.0).numpy()
+    assert np.array_equal(opaste.clamp01(x), ref)
+    assert np.array_equal(opaste.to_u8(ref), (255. * ref).astype(np.uint8))
+    fr = rng.integers(0, 256, (40, 30, 3), dtype=np.uint8)
+    t = (torch.from_numpy(fr).permute(2, 0, 1).float().div(255) - 0.5) / 0.5         # ToTensor + Normalize(0.5, 0.5)
+    assert np.array_equal(opaste.normalise_frame(fr), t.numpy())
+    for oh, ow in ((64, 64), (80, 60), (20, 100)):
+        ref = torch.nn.functional.interpolate(t[None], size=(oh, ow), mode="bilinear", align_corners=False)[0].numpy()
+        assert np.abs(opaste.resize_bilinear_f32(t.numpy(), oh, ow) - ref).max() <= 2e-6     # ATen's vectorised CPU kernel: <= 2 ulp

@@ -199,6 +199,24 @@ int vface_flow_to_latent(const float* flow_px, float* out, int pairs, int H, int
     return vf_launch_flow_to_latent(flow_px, out, pairs, H, W, factor, S(stream));
 }
 
+int vface_frame_to_u8(const void* x, uint8_t* out, int frames, int H, int W, int in_kind, void* stream) {
+    return vf_launch_frame_to_u8(x, out, frames, H, W, in_kind, S(stream));
+}
+
+int vface_resample_u8(const uint8_t* src, uint8_t* dst, int frames, int in_n, int out_n, int lines, int axis, const int32_t* bounds,
+                      const int32_t* kk, int ksize, void* stream) {
+    return vf_launch_resample_u8(src, dst, frames, in_n, out_n, lines, axis, bounds, kk, ksize, S(stream));
+}
+
+int vface_perspective_paste(const uint8_t* crop, int crop_w, int crop_h, uint8_t* frame, int W, int H, int frames,
+                            const double* coeffs_dev, const double* coeffs_host, void* stream) {
+    return vf_launch_perspective_paste(crop, crop_w, crop_h, frame, W, H, frames, coeffs_dev, coeffs_host, S(stream));
+}
+
+int vface_frame_normalise_resize(const uint8_t* frame, int W, int H, float* out, int OW, int OH, int frames, void* stream) {
+    return vf_launch_frame_normalise_resize(frame, W, H, out, OW, OH, frames, S(stream));
+}
+
 size_t vface_attn1_workspace_bytes(int B, int n, int d, int chunks) {
     if (B <= 0 || n <= 0 || d <= 0 || chunks <= 0) return 0;
     const size_t F = (size_t)B / chunks;

@@ -134,6 +134,14 @@ int vf_launch_flow_warp(const void* src, long ld_src, long fs_src, const void* p
                         int w, int C, float alpha, float one_minus_alpha, int flags, int* dbg_x0, int* dbg_y0, int dtype,
                         hipStream_t stream);
 int vf_launch_flow_to_latent(const float* flow_px, float* out, int pairs, int H, int W, int factor, hipStream_t stream);
+// paste.hip: per-frame paste-back (VFace_inference_batch.py:597-636); in_kind 0 fp16 | 1 bf16 | 2 fp32
+int vf_launch_frame_to_u8(const void* x, unsigned char* out, int frames, int H, int W, int in_kind, hipStream_t stream);
+int vf_launch_resample_u8(const unsigned char* src, unsigned char* dst, int frames, int in_n, int out_n, int lines, int axis,
+                          const int* bounds, const int* kk, int ksize, hipStream_t stream);
+int vf_launch_perspective_paste(const unsigned char* crop, int sw, int sh, unsigned char* frame, int W, int H, int frames,
+                                const double* coeffs_dev, const double* coeffs_host, hipStream_t stream);
+int vf_launch_frame_normalise_resize(const unsigned char* frame, int W, int H, float* out, int OW, int OH, int frames,
+                                     hipStream_t stream);
 int vf_launch_timestep_embedding(const long long* t, void* out, int N, int dim, int dtype, hipStream_t stream);
 int vf_launch_silu(const void* x, void* y, long count, int in_f32, int dtype, hipStream_t stream);
 int vf_launch_softmax_rows(const float* S, long lds_, void* P, long ldp, int M, int N, float scale, int dtype, hipStream_t stream);

@@ -66,6 +66,10 @@ SIGNATURES = {
     "vface_flow_warp": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                                   _f32, _i32, _vp, _vp, _i32, _vp]),
     "vface_flow_to_latent": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vface_frame_to_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vface_resample_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "vface_perspective_paste": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "vface_frame_normalise_resize": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     "vface_attn1_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "vface_attn1_forward": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _i32, _i32,
                                       _i32, _i32, _i32, _i32, _vp, _i32, _i32, _f32, _f32, _i32, _vp, _vp, _vp, _vp,
@@ -302,6 +306,71 @@ def flow_to_latent(flow_px: torch.Tensor, factor: int = 8) -> torch.Tensor:
     out = torch.empty(P, 2, H // factor, W // factor, dtype=torch.float32, device=f.device)
     rc = load().vface_flow_to_latent(_p(f), _p(out), P, H, W, factor, _stream())
     _check(rc, "vface_flow_to_latent")
+    return out
+
+
+def frame_to_u8(x: torch.Tensor) -> torch.Tensor:
+    """Decoded frames [F, 3, H, W] in [-1, 1] (fp16 / bf16 / fp32) -> uint8 [F, H, W, 3]: clamp((x + 1) / 2, 0, 1) * 255, truncated."""
+    if x.dim() != 4 or x.shape[1] != 3:
+        raise VFaceHipError(f"frame_to_u8: frames must be [F, 3, H, W]; got {tuple(x.shape)}")
+    x = x.contiguous()
+    kind = 2 if x.dtype == torch.float32 else dtype_code(x.dtype)
+    F_, _, H, W = x.shape
+    out = torch.empty(F_, H, W, 3, dtype=torch.uint8, device=x.device)
+    _check(load().vface_frame_to_u8(_p(x), _p(out), F_, H, W, kind, _stream()), "vface_frame_to_u8")
+    return out
+
+
+def resample_u8(src: torch.Tensor, out_n: int, axis: int, bounds: torch.Tensor, kk: torch.Tensor) -> torch.Tensor:
+    """One pass of Pillow's 8-bit bilinear resampling over uint8 [F, H, W, 3] frames: axis 0 along x (W -> out_n), axis 1 along y."""
+    if src.dtype != torch.uint8 or src.dim() != 4 or src.shape[3] != 3 or not src.is_contiguous():
+        raise VFaceHipError("resample_u8: frames must be contiguous uint8 [F, H, W, 3]")
+    if bounds.dtype != torch.int32 or kk.dtype != torch.int32 or tuple(bounds.shape) != (out_n, 2) or kk.shape[0] != out_n:
+        raise VFaceHipError("resample_u8: bounds [out_n, 2] / kk [out_n, ksize] must be int32 tables for this output size")
+    F_, H, W, _ = src.shape
+    if axis == 0:
+        dst = torch.empty(F_, H, out_n, 3, dtype=torch.uint8, device=src.device)
+        in_n, lines = W, H
+    else:
+        dst = torch.empty(F_, out_n, W, 3, dtype=torch.uint8, device=src.device)
+        in_n, lines = H, W
+    rc = load().vface_resample_u8(_p(src), _p(dst), F_, in_n, out_n, lines, axis, _p(bounds), _p(kk), kk.shape[1], _stream())
+    _check(rc, "vface_resample_u8")
+    return dst
+
+
+def perspective_paste(crop: torch.Tensor, frame: torch.Tensor, coeffs) -> torch.Tensor:
+    """Paste uint8 crops [F, h, w, 3] into uint8 frames [F, H, W, 3] IN PLACE through the eight PIL perspective coefficients per
+    frame (``coeffs``: a float64 device tensor [F, 8], or eight host floats when F == 1)."""
+    for t in (crop, frame):
+        if t.dtype != torch.uint8 or t.dim() != 4 or t.shape[3] != 3 or not t.is_contiguous():
+            raise VFaceHipError("perspective_paste: crops and frames must be contiguous uint8 [F, H, W, 3]")
+    F_, sh, sw, _ = crop.shape
+    if frame.shape[0] != F_:
+        raise VFaceHipError("perspective_paste: one crop per frame")
+    dev_c, host_c = None, None
+    if isinstance(coeffs, torch.Tensor) and coeffs.is_cuda:
+        if coeffs.dtype != torch.float64 or tuple(coeffs.shape) != (F_, 8) or not coeffs.is_contiguous():
+            raise VFaceHipError("perspective_paste: device coefficients must be contiguous float64 [F, 8]")
+        dev_c = coeffs
+    else:
+        vals = [float(v) for v in (coeffs.reshape(-1).tolist() if hasattr(coeffs, "reshape") else coeffs)]
+        if len(vals) != 8 or F_ != 1:
+            raise VFaceHipError("perspective_paste: host coefficients are eight numbers for a single frame")
+        host_c = (C.c_double * 8)(*vals)
+    rc = load().vface_perspective_paste(_p(crop), sw, sh, _p(frame), frame.shape[2], frame.shape[1], F_, _p(dev_c),
+                                        C.cast(host_c, C.c_void_p) if host_c is not None else None, _stream())
+    _check(rc, "vface_perspective_paste")
+    return frame
+
+
+def frame_normalise_resize(frame: torch.Tensor, OH: int, OW: int) -> torch.Tensor:
+    """uint8 frames [F, H, W, 3] -> fp32 [F, 3, OH, OW] in [-1, 1]: ToTensor + Normalize(0.5, 0.5) + bilinear Resize (no antialias)."""
+    if frame.dtype != torch.uint8 or frame.dim() != 4 or frame.shape[3] != 3 or not frame.is_contiguous():
+        raise VFaceHipError("frame_normalise_resize: frames must be contiguous uint8 [F, H, W, 3]")
+    F_, H, W, _ = frame.shape
+    out = torch.empty(F_, 3, OH, OW, dtype=torch.float32, device=frame.device)
+    _check(load().vface_frame_normalise_resize(_p(frame), W, H, _p(out), OW, OH, F_, _stream()), "vface_frame_normalise_resize")
     return out
 
 
