@@ -155,6 +155,15 @@ def test_cli_synthetic_smoke(tmp_path):
     assert res["batches"][0]["finite"] and res["batches"][0]["pixels"] == [2, 3, 256, 256]
     px = torch.load(tmp_path / "out_vae" / "pixels_batch0.pt")
     assert px.min() >= 0 and px.max() <= 1
+    # ... and the paste-back of the decoded crops into (synthetic) 320 x 320 original frames (:603-636), on the GPU
+    res = cli.main(["--synthetic", "--with_vae", "--paste_back", "--frame_size", "320", "--config", str(ypath), "--n_frames", "2",
+                    "--n_samples", "2", "--H", "256", "--W", "256", "--max_steps", "2", "--Base_dir", str(tmp_path / "out_paste"),
+                    "--ddim_steps", "50"])
+    assert res["batches"][0]["pasted"] == [2, 320, 320, 3]
+    from PIL import Image
+    import numpy as np
+    im = np.asarray(Image.open(tmp_path / "out_paste" / "pasted_b0_f1.png"))
+    assert im.shape == (320, 320, 3) and im.dtype == np.uint8
 
 
 @pytest.mark.parametrize("mode", ["in_flow_fix"])

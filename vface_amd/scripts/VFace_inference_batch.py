@@ -54,6 +54,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--precision", type=str, choices=["full", "autocast"], default="autocast")
     # additions of this build
     p.add_argument("--synthetic", action="store_true", help="synthetic latents/conditioning/flow instead of video I/O")
+    p.add_argument("--paste_back", action="store_true",
+                   help="with --with_vae: paste the decoded crops into (synthetic) original frames on the GPU, the block of "
+                        "VFace_inference_batch.py:603-636 (scripts/paste_back.py); --only_target_crop is implied")
+    p.add_argument("--frame_size", type=int, default=1024, help="side of the synthetic original frames of --paste_back")
     p.add_argument("--with_vae", action="store_true",
                    help="synthetic run through the first-stage KL-VAE too: the inpaint latents come from encode_first_stage of "
                         "synthetic images (:456-457) and the samples are decoded to pixels (:596-600)")
@@ -152,6 +156,18 @@ def load_checkpoint(model, path: str, with_vae: bool = False) -> str:
             f"({len(sd) - len(taken)} checkpoint entries outside it ignored)")
 
 
+def _quad_coeffs(size, quad):
+    """Eight PIL perspective coefficients (output pixel -> crop coordinates) that land the ``size`` x ``size`` crop on ``quad``
+    (four frame-space corners, clockwise from top-left) -- what ``crop_and_align_face`` (:58-73) stores per frame."""
+    import numpy as np
+    src = [(0, 0), (size, 0), (size, size), (0, size)]
+    A, B = [], []
+    for (x, y), (u, v) in zip(quad, src):
+        A += [[x, y, 1, 0, 0, 0, -u * x, -u * y], [0, 0, 0, x, y, 1, -v * x, -v * y]]
+        B += [u, v]
+    return np.linalg.solve(np.array(A, float), np.array(B, float))
+
+
 def run_synthetic(opt) -> dict:
     from ..ldm.models.diffusion.ddim_w_inv import DDIMSampler, HookPlan
     from ..ldm.models.diffusion.ddpm import LatentDiffusion
@@ -185,6 +201,7 @@ def run_synthetic(opt) -> dict:
     F_ = opt.n_samples
     os.makedirs(opt.Base_dir, exist_ok=True)
     results, t_all = [], time.time()
+    paster = None
     for batch_id in range(opt.n_frames // F_):  # DataLoader(batch_size=n_samples, drop_last=True) (:376-382)
         tag = lambda s: f"cli.{s}.{batch_id}"
         d = lambda t: t.to(dev)
@@ -232,13 +249,36 @@ def run_synthetic(opt) -> dict:
         if opt.with_vae:
             x_samples = model.decode_first_stage(samples)                                          # :596
             pixels = torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0)                       # :597
+        pasted, paste_s = None, None
+        if opt.paste_back:
+            if not opt.with_vae:
+                raise SystemExit("--paste_back pastes decoded pixels: it needs --with_vae")
+            from .paste_back import PasteBack
+            if paster is None:
+                paster = PasteBack(H=opt.H, W=opt.W, device=dev, encode_decode=PasteBack.vae_round_trip(model))
+            S_ = opt.frame_size
+            gen = torch.Generator().manual_seed(opt.seed + 1000 + batch_id)
+            frames = torch.randint(0, 256, (F_, S_, S_, 3), dtype=torch.uint8, generator=gen).to(dev)
+            # inv_transforms_all rows (:625): here the 1024 canvas lands on the central half of the frame, slightly sheared
+            q = S_ / 4.0
+            co = [_quad_coeffs(paster.canvas, [(q + 3 * f, q), (3 * q, q + f), (3 * q - f, 3 * q), (q, 3 * q - 2 * f)]) for f in range(F_)]
+            torch.cuda.synchronize()
+            t1 = time.time()
+            pasted = paster.paste(x_samples, frames, co)                                           # :603-633
+            torch.cuda.synchronize()
+            paste_s = time.time() - t1
         if not opt.skip_save:
+            if pasted is not None:
+                from PIL import Image
+                for f in range(F_):                                                                # :636
+                    Image.fromarray(pasted[f].cpu().numpy()).save(os.path.join(opt.Base_dir, f"pasted_b{batch_id}_f{f}.png"))
             torch.save(samples.cpu(), os.path.join(opt.Base_dir, f"samples_batch{batch_id}.pt"))
             if pixels is not None:
                 torch.save(pixels.cpu(), os.path.join(opt.Base_dir, f"pixels_batch{batch_id}.pt"))
         results.append({"batch": batch_id, "frames": F_, "sample_seconds": dt_s,
                         "finite": bool(torch.isfinite(samples).all()) and (pixels is None or bool(torch.isfinite(pixels).all())),
-                        "pixels": None if pixels is None else list(pixels.shape)})
+                        "pixels": None if pixels is None else list(pixels.shape),
+                        "pasted": None if pasted is None else list(pasted.shape), "paste_seconds": paste_s})
         print(f"batch {batch_id}: {F_} frames sampled in {dt_s:.2f} s")
     return {"batches": results, "total_seconds": time.time() - t_all}
 
