@@ -213,6 +213,52 @@ int vface_flow_warp(const void* src, int64_t ld_src, int64_t fs_src, const void*
  * H, W multiples of `factor`).  RAFT's own weights are third-party: the flow VALUES are outside this library. */
 int vface_flow_to_latent(const float* flow_px, float* out, int pairs, int H, int W, int factor, void* stream);
 
+/* ---- optical-flow producer (temporal_flow.py:27-38, 163-188: torchvision raft_large, 20 updates) -----------------
+ * The convolutions and the all-pairs correlation of the RAFT-shaped network run through vface_gemm / vface_conv3x3; these are
+ * the HBM-bound steps between them, all on token-major [M = nimg*H*W][ld] buffers of the 16-bit compute type.
+ * PARITY UNPINNED: torchvision (pinned 0.14.1 by the reference's environment) is third-party, not under the reference tree and
+ * not installed; the network is restated from the published architecture in oracle/raft.py and tested against that.
+ *
+ * vface_im2col: the KH x KW window (7x7, 1x5, 5x1: more than the implicit GEMM's 9 taps, or a non-square shape) as an explicit
+ *   matrix out[m][tap*C + c], zero outside the image; C % 8 == 0, ldo >= KH*KW*C.  OH = (H + 2 pad_y - KH) / stride + 1. */
+int vface_im2col(const void* X, int64_t ldx, int nimg, int H, int W, int C, int KH, int KW, int stride, int pad_y, int pad_x, void* out,
+                 int64_t ldo, int dtype, void* stream);
+
+/* nn.InstanceNorm2d statistics (per image and channel over hw pixels, biased variance): stats [nimg][C][2] = (mean, rstd);
+ * `partial` = vface_channel_stats_partial_floats(nimg, hw, C) floats of scratch (fixed summation order: reproducible). */
+int64_t vface_channel_stats_partial_floats(int nimg, int hw, int C);
+int vface_channel_stats(const void* x, int64_t ldx, int nimg, int hw, int C, float eps, float* partial, float* stats, int dtype,
+                        void* stream);
+
+/* y = act((x - mean) * rstd + residual): stats NULL = no normalisation (the BatchNorm of the context encoder is folded into its
+ * convolutions on the host), residual NULL = none; act 0 none | 1 ReLU | 2 tanh | 3 sigmoid; y (16-bit) and / or y32 (fp32). */
+int vface_channel_norm_act(const void* x, int64_t ldx, const float* stats, const void* residual, int64_t ldr, void* y, int64_t ldy,
+                           float* y32, int64_t ldy32, int64_t M, int hw, int C, int act, int dtype, void* stream);
+
+/* ConvGRU gates: zr [M][2 hidden] = pre-activations of convz | convr; z = sigmoid -> z [M][ldz]; sigmoid(r) * h32 -> rh. */
+int vface_gru_gate(const void* zr, int64_t ldzr, const float* h32, void* z, int64_t ldz, void* rh, int64_t ldrh, int64_t M, int hidden,
+                   int dtype, void* stream);
+/* h32 = (1 - z) h32 + z tanh(q) in place (fp32 master state), 16-bit copies into h16a / h16b (each may be NULL). */
+int vface_gru_update(const void* q, int64_t ldq, const void* z, int64_t ldz, float* h32, void* h16a, int64_t lda, void* h16b, int64_t ldb,
+                     int64_t M, int hidden, int dtype, void* stream);
+
+/* F.avg_pool2d(x, 2, 2) over the last two dims of fp32 [R][h][w] (the correlation pyramid). */
+int vface_avgpool2_f32(const float* x, float* y, int64_t R, int h, int w, void* stream);
+
+/* CorrBlock.index_pyramid: out[m][l*81 + i*9 + j] = scale * bilinear(vols[l][m], (x + flow.x) / 2^l + i - 4, (y + flow.y) / 2^l + j - 4),
+ * zero outside (grid_sample, align_corners = True); vols / hs / ws are HOST arrays of `levels` (<= 4) device pointers and sizes,
+ * vols[l] = fp32 [M][hs[l]][ws[l]]; flow32 [M][2]; m = (pair*h + y)*w + x. */
+int vface_corr_lookup(const float* const* vols, const int* hs, const int* ws, int levels, const float* flow32, int h, int w, float scale,
+                      void* out, int64_t ldo, int64_t M, int dtype, void* stream);
+
+/* flow32 [M][2] += delta32[m][0..1] (delta32 NULL: no change); 16-bit copies of the new flow into columns 0..1 of a / b / c. */
+int vface_flow_update(float* flow32, const float* delta32, int64_t ldd, void* a, int64_t lda, void* b, int64_t ldb, void* c, int64_t ldc,
+                      int64_t M, int dtype, void* stream);
+
+/* upsample_flow: out [B][2][8h][8w] = sum_k softmax_k(mult * mask32[m][k*64 + fy*8 + fx]) * 8 * flow(neighbour k), zero padded. */
+int vface_convex_upsample(const float* mask32, int64_t ldm, const float* flow32, float* out, int B, int h, int w, float mult,
+                          void* stream);
+
 /* ---- paste-back of a swapped crop into its original frame (VFace_inference_batch.py:597-636) ----------------
  * The reference runs these steps per frame on the host with numpy, Pillow and torchvision; each entry point replaces one of
  * them on device buffers, with Pillow's 8-bit arithmetic restated exactly (oracle/paste.py is pinned against Pillow itself).

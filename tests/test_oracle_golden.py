@@ -333,3 +333,34 @@ def test_paste_float_steps_match_numpy_and_torch():
     for oh, ow in ((64, 64), (80, 60), (20, 100)):
         ref = torch.nn.functional.interpolate(t[None], size=(oh, ow), mode="bilinear", align_corners=False)[0].numpy()
         assert np.abs(opaste.resize_bilinear_f32(t.numpy(), oh, ow) - ref).max() <= 2e-6     # ATen's vectorised CPU kernel: <= 2 ulp
+
+
+# ---- flow producer: parity UNPINNED (torchvision absent); what CAN be checked without it --------------------
+def test_raft_restatement_has_the_published_parameter_count_and_layout():
+    """raft_large has 5 257 536 parameters (torchvision's documented `num_params` for Raft_Large_Weights); the oracle's shape table
+    and the product's parameter container (vface_amd/raft.py) must both add up to it and agree key by key."""
+    from oracle import raft as oraft
+    from vface_amd.raft import RAFT
+    shapes = oraft.param_shapes()
+    assert sum(int(np.prod(s)) for k, s in shapes.items() if "running_" not in k) == 5_257_536
+    sd = RAFT().state_dict()
+    assert set(sd) == set(shapes) and all(tuple(sd[k].shape) == tuple(shapes[k]) for k in shapes)
+
+
+def test_raft_oracle_lookup_and_upsample_conventions():
+    """Two conventions the restatement has to get right: the correlation window adds meshgrid(d, d, 'ij') to (x, y) -- entry (i, j)
+    samples at (x + d_i, y + d_j) -- and the convex upsampling of a constant flow with any mask is 8 x that constant away from
+    the border."""
+    from oracle import raft as oraft
+    B, h, w = 1, 16, 16
+    fm1 = torch.zeros(B, 256, h, w)
+    fm2 = torch.zeros(B, 256, h, w)
+    fm1[0, 0, 3, 3] = 16.0                       # pixel (x=3, y=3) of image 1 correlates only with ...
+    fm2[0, 0, 5, 4] = 1.0                        # ... pixel (x=4, y=5) of image 2, value 16 / sqrt(256) = 1
+    feat = oraft.corr_lookup(oraft.corr_pyramid(fm1, fm2), oraft.coords_grid(B, h, w))
+    win = feat[0, :81, 3, 3].reshape(9, 9)
+    assert win[4 + 1, 4 + 2] == 1.0 and win.sum() == 1.0      # dx = +1 is the FIRST index, dy = +2 the second
+    sd = synth.synth_state_dict(oraft.param_shapes(), seed=0)
+    hidden = synth.synth_normal("raft.up.h", (1, 128, h, w))
+    up = oraft.upsample_flow(sd, hidden, torch.full((1, 2, h, w), 1.5))
+    assert torch.allclose(up[:, :, 8:-8, 8:-8], torch.full((1, 2, 112, 112), 12.0), atol=1e-5)

@@ -199,6 +199,55 @@ int vface_flow_to_latent(const float* flow_px, float* out, int pairs, int H, int
     return vf_launch_flow_to_latent(flow_px, out, pairs, H, W, factor, S(stream));
 }
 
+int vface_im2col(const void* X, int64_t ldx, int nimg, int H, int W, int C, int KH, int KW, int stride, int pad_y, int pad_x, void* out,
+                 int64_t ldo, int dtype, void* stream) {
+    return vf_launch_im2col(X, ldx, nimg, H, W, C, KH, KW, stride, pad_y, pad_x, out, ldo, dtype, S(stream));
+}
+
+int64_t vface_channel_stats_partial_floats(int nimg, int hw, int C) {
+    if (nimg <= 0 || hw <= 0 || C <= 0) return 0;
+    return (int64_t)nimg * vf_chan_stats_slices(hw) * C * 2;
+}
+
+int vface_channel_stats(const void* x, int64_t ldx, int nimg, int hw, int C, float eps, float* partial, float* stats, int dtype,
+                        void* stream) {
+    return vf_launch_chan_stats(x, ldx, nimg, hw, C, eps, partial, stats, dtype, S(stream));
+}
+
+int vface_channel_norm_act(const void* x, int64_t ldx, const float* stats, const void* residual, int64_t ldr, void* y, int64_t ldy,
+                           float* y32, int64_t ldy32, int64_t M, int hw, int C, int act, int dtype, void* stream) {
+    return vf_launch_chan_norm_act(x, ldx, stats, residual, ldr, y, ldy, y32, ldy32, M, hw, C, act, dtype, S(stream));
+}
+
+int vface_gru_gate(const void* zr, int64_t ldzr, const float* h32, void* z, int64_t ldz, void* rh, int64_t ldrh, int64_t M, int hidden,
+                   int dtype, void* stream) {
+    return vf_launch_gru_gate(zr, ldzr, h32, z, ldz, rh, ldrh, M, hidden, dtype, S(stream));
+}
+
+int vface_gru_update(const void* q, int64_t ldq, const void* z, int64_t ldz, float* h32, void* h16a, int64_t lda, void* h16b, int64_t ldb,
+                     int64_t M, int hidden, int dtype, void* stream) {
+    return vf_launch_gru_update(q, ldq, z, ldz, h32, h16a, lda, h16b, ldb, M, hidden, dtype, S(stream));
+}
+
+int vface_avgpool2_f32(const float* x, float* y, int64_t R, int h, int w, void* stream) {
+    return vf_launch_avgpool2_f32(x, y, R, h, w, S(stream));
+}
+
+int vface_corr_lookup(const float* const* vols, const int* hs, const int* ws, int levels, const float* flow32, int h, int w, float scale,
+                      void* out, int64_t ldo, int64_t M, int dtype, void* stream) {
+    return vf_launch_corr_lookup(vols, hs, ws, levels, flow32, h, w, scale, out, ldo, M, dtype, S(stream));
+}
+
+int vface_flow_update(float* flow32, const float* delta32, int64_t ldd, void* a, int64_t lda, void* b, int64_t ldb, void* c, int64_t ldc,
+                      int64_t M, int dtype, void* stream) {
+    return vf_launch_flow_update(flow32, delta32, ldd, a, lda, b, ldb, c, ldc, M, dtype, S(stream));
+}
+
+int vface_convex_upsample(const float* mask32, int64_t ldm, const float* flow32, float* out, int B, int h, int w, float mult,
+                          void* stream) {
+    return vf_launch_convex_upsample(mask32, ldm, flow32, out, B, h, w, mult, S(stream));
+}
+
 int vface_frame_to_u8(const void* x, uint8_t* out, int frames, int H, int W, int in_kind, void* stream) {
     return vf_launch_frame_to_u8(x, out, frames, H, W, in_kind, S(stream));
 }

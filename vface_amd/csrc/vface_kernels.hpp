@@ -134,6 +134,25 @@ int vf_launch_flow_warp(const void* src, long ld_src, long fs_src, const void* p
                         int w, int C, float alpha, float one_minus_alpha, int flags, int* dbg_x0, int* dbg_y0, int dtype,
                         hipStream_t stream);
 int vf_launch_flow_to_latent(const float* flow_px, float* out, int pairs, int H, int W, int factor, hipStream_t stream);
+// raft.hip: glue kernels of the RAFT-shaped flow producer (temporal_flow.py:27-38, 163-188)
+int vf_launch_im2col(const void* x, long ldx, int nimg, int H, int W, int C, int KH, int KW, int stride, int pad_y, int pad_x, void* out,
+                     long ldo, int dtype, hipStream_t stream);
+int vf_chan_stats_slices(int hw);
+int vf_launch_chan_stats(const void* x, long ldx, int nimg, int hw, int C, float eps, float* partial, float* stats, int dtype,
+                         hipStream_t stream);
+int vf_launch_chan_norm_act(const void* x, long ldx, const float* stats, const void* res, long ldr, void* y, long ldy, float* y32,
+                            long ldy32, long M, int hw, int C, int act, int dtype, hipStream_t stream);
+int vf_launch_gru_gate(const void* zr, long ldzr, const float* h32, void* z, long ldz, void* rh, long ldrh, long M, int Hd, int dtype,
+                       hipStream_t stream);
+int vf_launch_gru_update(const void* q, long ldq, const void* z, long ldz, float* h32, void* h16a, long lda, void* h16b, long ldb, long M,
+                         int Hd, int dtype, hipStream_t stream);
+int vf_launch_avgpool2_f32(const float* x, float* y, long R, int h, int w, hipStream_t stream);
+int vf_launch_corr_lookup(const float* const* vols, const int* hs, const int* ws, int levels, const float* flow32, int h, int w, float scale,
+                          void* out, long ldo, long M, int dtype, hipStream_t stream);
+int vf_launch_flow_update(float* flow32, const float* delta32, long ldd, void* a, long lda, void* b, long ldb, void* c, long ldc, long M,
+                          int dtype, hipStream_t stream);
+int vf_launch_convex_upsample(const float* mask32, long ldm, const float* flow32, float* out, int B, int h, int w, float mult,
+                              hipStream_t stream);
 // paste.hip: per-frame paste-back (VFace_inference_batch.py:597-636); in_kind 0 fp16 | 1 bf16 | 2 fp32
 int vf_launch_frame_to_u8(const void* x, unsigned char* out, int frames, int H, int W, int in_kind, hipStream_t stream);
 int vf_launch_resample_u8(const unsigned char* src, unsigned char* dst, int frames, int in_n, int out_n, int lines, int axis,

@@ -66,6 +66,16 @@ SIGNATURES = {
     "vface_flow_warp": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                                   _f32, _i32, _vp, _vp, _i32, _vp]),
     "vface_flow_to_latent": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "vface_im2col": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "vface_channel_stats_partial_floats": (_i64, [_i32, _i32, _i32]),
+    "vface_channel_stats": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _vp]),
+    "vface_channel_norm_act": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "vface_gru_gate": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "vface_gru_update": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "vface_avgpool2_f32": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "vface_corr_lookup": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _i32, _i32, _f32, _vp, _i64, _i64, _i32, _vp]),
+    "vface_flow_update": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "vface_convex_upsample": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
     "vface_frame_to_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "vface_resample_u8": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "vface_perspective_paste": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
@@ -306,6 +316,76 @@ def flow_to_latent(flow_px: torch.Tensor, factor: int = 8) -> torch.Tensor:
     out = torch.empty(P, 2, H // factor, W // factor, dtype=torch.float32, device=f.device)
     rc = load().vface_flow_to_latent(_p(f), _p(out), P, H, W, factor, _stream())
     _check(rc, "vface_flow_to_latent")
+    return out
+
+
+# ---- glue of the RAFT-shaped flow producer (csrc/raft.hip; include/vface_hip.h "optical-flow producer") ----
+ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
+
+
+def im2col(x: torch.Tensor, out: torch.Tensor, *, nimg: int, H: int, W: int, C_: int, kh: int, kw: int, stride: int = 1,
+           pad_y: int = 0, pad_x: int = 0, ldx: Optional[int] = None):
+    rc = load().vface_im2col(_p(x), ldx if ldx is not None else x.stride(0), nimg, H, W, C_, kh, kw, stride, pad_y, pad_x, _p(out),
+                             out.stride(0), dtype_code(x.dtype), _stream())
+    _check(rc, "vface_im2col")
+
+
+def channel_stats(x: torch.Tensor, *, nimg: int, hw: int, C_: int, ldx: Optional[int] = None, eps: float = 1e-5) -> torch.Tensor:
+    lib = load()
+    partial = torch.empty(int(lib.vface_channel_stats_partial_floats(nimg, hw, C_)), dtype=torch.float32, device=x.device)
+    stats = torch.empty(nimg, C_, 2, dtype=torch.float32, device=x.device)
+    rc = lib.vface_channel_stats(_p(x), ldx if ldx is not None else x.stride(0), nimg, hw, C_, eps, _p(partial), _p(stats),
+                                 dtype_code(x.dtype), _stream())
+    _check(rc, "vface_channel_stats")
+    return stats
+
+
+def channel_norm_act(x: torch.Tensor, y: Optional[torch.Tensor], *, M: int, hw: int, C_: int, act: int, stats=None, residual=None,
+                     y32=None, ldx: Optional[int] = None, ldy: Optional[int] = None, ldr: Optional[int] = None):
+    rc = load().vface_channel_norm_act(_p(x), ldx if ldx is not None else x.stride(0), _p(stats), _p(residual),
+                                       (ldr if ldr is not None else residual.stride(0)) if residual is not None else 0, _p(y),
+                                       (ldy if ldy is not None else y.stride(0)) if y is not None else 0, _p(y32),
+                                       y32.stride(0) if y32 is not None else 0, M, hw, C_, act, dtype_code(x.dtype), _stream())
+    _check(rc, "vface_channel_norm_act")
+
+
+def gru_gate(zr: torch.Tensor, h32: torch.Tensor, z: torch.Tensor, rh: torch.Tensor, *, M: int, hidden: int, ldrh: int):
+    rc = load().vface_gru_gate(_p(zr), zr.stride(0), _p(h32), _p(z), z.stride(0), _p(rh), ldrh, M, hidden, dtype_code(zr.dtype), _stream())
+    _check(rc, "vface_gru_gate")
+
+
+def gru_update(q: torch.Tensor, z: torch.Tensor, h32: torch.Tensor, h16a, lda: int, h16b, ldb: int, *, M: int, hidden: int):
+    rc = load().vface_gru_update(_p(q), q.stride(0), _p(z), z.stride(0), _p(h32), _p(h16a), lda, _p(h16b), ldb, M, hidden,
+                                 dtype_code(q.dtype), _stream())
+    _check(rc, "vface_gru_update")
+
+
+def avgpool2_f32(x: torch.Tensor, y: torch.Tensor, *, R: int, h: int, w: int):
+    _check(load().vface_avgpool2_f32(_p(x), _p(y), R, h, w, _stream()), "vface_avgpool2_f32")
+
+
+def corr_lookup(vols, flow32: torch.Tensor, out: torch.Tensor, *, h: int, w: int, scale: float):
+    n = len(vols)
+    ptrs = (C.c_void_p * n)(*[_p(v) for v in vols])
+    hs = (C.c_int * n)(*[int(v.shape[-2]) for v in vols])
+    ws = (C.c_int * n)(*[int(v.shape[-1]) for v in vols])
+    rc = load().vface_corr_lookup(C.cast(ptrs, C.c_void_p), C.cast(hs, C.c_void_p), C.cast(ws, C.c_void_p), n, _p(flow32), h, w,
+                                  scale, _p(out), out.stride(0), flow32.shape[0], dtype_code(out.dtype), _stream())
+    _check(rc, "vface_corr_lookup")
+
+
+def flow_update(flow32: torch.Tensor, delta32, copies, *, dtype: torch.dtype):
+    """``copies``: up to three (tensor view whose first two columns receive the 16-bit flow, row stride) pairs."""
+    c = list(copies) + [(None, 0)] * (3 - len(copies))
+    rc = load().vface_flow_update(_p(flow32), _p(delta32), delta32.stride(0) if delta32 is not None else 0, _p(c[0][0]), c[0][1],
+                                  _p(c[1][0]), c[1][1], _p(c[2][0]), c[2][1], flow32.shape[0], dtype_code(dtype), _stream())
+    _check(rc, "vface_flow_update")
+
+
+def convex_upsample(mask32: torch.Tensor, flow32: torch.Tensor, *, B: int, h: int, w: int, mult: float = 0.25) -> torch.Tensor:
+    out = torch.empty(B, 2, 8 * h, 8 * w, dtype=torch.float32, device=mask32.device)
+    rc = load().vface_convex_upsample(_p(mask32), mask32.stride(0), _p(flow32), _p(out), B, h, w, mult, _stream())
+    _check(rc, "vface_convex_upsample")
     return out
 
 
