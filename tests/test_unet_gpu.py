@@ -155,6 +155,12 @@ def test_cli_synthetic_smoke(tmp_path):
     assert res["batches"][0]["finite"] and res["batches"][0]["pixels"] == [2, 3, 256, 256]
     px = torch.load(tmp_path / "out_vae" / "pixels_batch0.pt")
     assert px.min() >= 0 and px.max() <= 1
+    # ... with the flow computed from the target frames by the RAFT-shaped producer (:550-553 `return_flow`), pixel resolution,
+    # resampled to the latent map and used by the flow_fix hooks
+    res = cli.main(["--synthetic", "--raft_flow", "--fusion", "flow_fix", "--flow_gate", "flow_hw", "--config", str(ypath), "--n_frames", "2",
+                    "--n_samples", "2", "--H", "256", "--W", "256", "--max_steps", "2", "--Base_dir", str(tmp_path / "out_raft"),
+                    "--ddim_steps", "50"])
+    assert res["batches"][0]["finite"]
     # ... and the paste-back of the decoded crops into (synthetic) 320 x 320 original frames (:603-636), on the GPU
     res = cli.main(["--synthetic", "--with_vae", "--paste_back", "--frame_size", "320", "--config", str(ypath), "--n_frames", "2",
                     "--n_samples", "2", "--H", "256", "--W", "256", "--max_steps", "2", "--Base_dir", str(tmp_path / "out_paste"),

@@ -54,6 +54,11 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--precision", type=str, choices=["full", "autocast"], default="autocast")
     # additions of this build
     p.add_argument("--synthetic", action="store_true", help="synthetic latents/conditioning/flow instead of video I/O")
+    p.add_argument("--raft_flow", action="store_true",
+                   help="compute the optical flow from the (synthetic) target frames with the RAFT-shaped producer "
+                        "(temporal_flow.return_flow, VFace_inference_batch.py:550-553) instead of a synthetic field; implies "
+                        "--flow_pixels.  --raft_ckpt: a raft_large state dict (torchvision layout); default synthetic weights")
+    p.add_argument("--raft_ckpt", type=str, default=None)
     p.add_argument("--paste_back", action="store_true",
                    help="with --with_vae: paste the decoded crops into (synthetic) original frames on the GPU, the block of "
                         "VFace_inference_batch.py:603-636 (scripts/paste_back.py); --only_target_crop is implied")
@@ -201,7 +206,7 @@ def run_synthetic(opt) -> dict:
     F_ = opt.n_samples
     os.makedirs(opt.Base_dir, exist_ok=True)
     results, t_all = [], time.time()
-    paster = None
+    paster, raft = None, None
     for batch_id in range(opt.n_frames // F_):  # DataLoader(batch_size=n_samples, drop_last=True) (:376-382)
         tag = lambda s: f"cli.{s}.{batch_id}"
         d = lambda t: t.to(dev)
@@ -212,7 +217,21 @@ def run_synthetic(opt) -> dict:
         else:
             z_inp = d(synth.synth_normal(tag("inp"), (F_, opt.C, h, w)) * 0.18215)
         mask = d(synth.synth_mask(F_, h, w))
-        if opt.flow_pixels:   # a pixel-resolution field whose latent resample is a +-2-cell motion
+        if opt.raft_flow:     # :550-553 flow = return_flow(target frames), pixel resolution
+            from . import temporal_flow as tflow
+            if raft is None:
+                from ..raft import RAFT
+                raft = RAFT(compute_dtype=dt)
+                if opt.raft_ckpt:
+                    raft.load_state_dict(torch.load(opt.raft_ckpt, map_location="cpu", weights_only=True))
+                else:
+                    synth.fill_module_(raft, seed=0, prefix="raft.")
+                raft = raft.to(dev).eval()
+            video = img if opt.with_vae else d(torch.stack([synth.synth_normal(tag(f"img{f}"), (3, opt.H, opt.W)).clamp(-1, 1)
+                                                            for f in range(F_)]))
+            flow = tflow.return_flow(video, raft)
+            sampler.flow_resample = "area"
+        elif opt.flow_pixels:   # a pixel-resolution field whose latent resample is a +-2-cell motion
             flow = [f[None] * opt.f for f in synth.synth_flow(F_ - 1, opt.H, opt.W, seed=opt.seed + batch_id)]
         else:
             flow = [f[None] for f in synth.synth_flow(F_ - 1, h, w, seed=opt.seed + batch_id)]
