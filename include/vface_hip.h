@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VFACE_ABI_VERSION 3
+#define VFACE_ABI_VERSION 4   /* 4: + vface_ffn_fused, the flow-producer glue (vface_im2col .. vface_convex_upsample), the paste-back entry points; nothing of 3 changed */
 
 #define VFACE_OK 0
 #define VFACE_ERR_ARG (-1)

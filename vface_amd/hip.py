@@ -123,7 +123,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.vface_abi_version() != 3:
+    if lib.vface_abi_version() != 4:
         raise VFaceHipError("libvface_hip.so ABI version mismatch")
     _lib = lib
     return lib
