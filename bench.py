@@ -506,6 +506,27 @@ def main():
             log(f"  {e['ms_step']:.2f} ms/step = {extras[-1]['frames_per_s']:.2f} frames/s "
                 f"({extras[-1]['unet_algorithmic_tflops']:.0f} TFLOP/s algorithmic)")
     eng.use_graph, eng._graphs = False, {}     # (frees the captured graphs' activation pools)
+    # the widened pipeline end to end, outside the metric: VAE encode -> RAFT-shaped flow -> 50-step DDIM inversion
+    # -> 50-step sampling with the shipped flow_fix schedule -> VAE decode -> paste-back, through the CLI's own code path
+    e2e = None
+    if world == 1 and not a.no_extras and a.res == 512 and a.dtype == "fp16":
+        try:
+            from vface_amd.scripts import VFace_inference_batch as cli
+            log("extra: end-to-end pipeline (encode, flow, inversion, sampling, decode, paste-back), 2 x 8 frames ...")
+            opt = cli.build_parser().parse_args(["--synthetic", "--with_vae", "--raft_flow", "--paste_back", "--skip_save", "--n_frames", "16",
+                                                 "--n_samples", "8", "--fusion", "flow_fix", "--ddim_steps", str(a.ddim_steps),
+                                                 "--Base_dir", "/tmp/vface_bench_e2e"])
+            res_ = cli.run_synthetic(opt)
+            st = res_["batches"][-1]["stage_seconds"]        # the second batch: graphs captured, caches warm
+            tot = sum(st.values())
+            e2e = {"workload": "8 frames 512x512 -> 1024x1024 pasted frames: VAE encode, flow (7 pairs, 20 updates), 50-step inversion (2F "
+                               "samples), 50-step sampling (flow_fix), VAE decode, paste-back incl. the background's VAE round trip; "
+                               "synthetic weights and frames; conditioning encoders, face alignment and video I/O are not part of it",
+                   "stage_seconds": st, "seconds_per_8_frames": tot, "frames_per_s": 8.0 / tot}
+            log(f"  {tot:.2f} s per 8 frames = {8.0 / tot:.2f} frames/s end to end: " + ", ".join(f"{k} {v * 1e3:.0f} ms" for k, v in st.items()))
+        except Exception as ex:       # an extra never costs the metric line
+            e2e = {"error": f"{type(ex).__name__}: {ex}"}
+            log(f"  end-to-end extra failed: {e2e['error']}")
     if rank == 0:
         step_ms_i = el * 1e3                     # the instrumented pass, all K steps
         unet_tflops = 3 * F_ * unet_gflop * 1e9 / (ms_step * 1e-3) / 1e12 if unet_gflop else None
@@ -564,6 +585,7 @@ def main():
                         "sampling only, as BASELINE's metric",
                 "frames_per_s_sampling_plus_inversion": (F_ * world) / (a.ddim_steps * (ms_step + inv_ms) / 1e3)},
             "extra": extras,
+            "end_to_end": e2e,
             "instrumented_pass": {"launch": "kernel by kernel, HIP events around every GEMM / convolution / attention / norm launch (what `roofline` "
                                             "is computed from; vface_attn1_forward's launches issued call by call, bit-identical)",
                                   "ms_per_step": ri["ms_step"], "host_enqueue_ms_per_step": ri["enqueue_ms"], "steps": a.steps, "warmup": a.warmup,

@@ -455,6 +455,39 @@ def gen_vae():
     save("vae_lowp", **lowp)
 
 
+def gen_paste():
+    """Paste-back (VFace_inference_batch.py:597-636): what PILLOW (the reference's own dependency, 12.2.0 in this image) returns
+    for that block's calls on seeded inputs -- `Image.resize(.., BILINEAR)` up / down / one axis, and `putalpha(255)` +
+    `transform(size, PERSPECTIVE, coeffs, BILINEAR)` + `alpha_composite` for three quads (inside, crossing the border, covering)."""
+    import PIL
+    from PIL import Image
+    out = {"pillow_version": np.array(PIL.__version__)}
+    rng = np.random.default_rng(20260401)
+    for i, (h, w, ow, oh) in enumerate([(32, 32, 64, 64), (50, 70, 33, 91), (37, 41, 100, 17), (64, 48, 48, 64), (96, 96, 192, 192)]):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        out[f"resize{i}.in"] = img
+        out[f"resize{i}.size"] = np.array([ow, oh])
+        out[f"resize{i}.out"] = np.asarray(Image.fromarray(img).resize((ow, oh), Image.BILINEAR))
+    sw = sh = 64
+    crop = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+    bg = rng.integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    out["persp.crop"], out["persp.bg"] = crop, bg
+    quads = [[(20.3, 15.1), (80.7, 18.2), (85.1, 70.9), (18.5, 66.5)], [(-15, -8), (75, 4), (70, 105), (8, 68)], [(0, 0), (120, 0), (120, 90), (0, 90)]]
+    for i, quad in enumerate(quads):
+        A, B = [], []
+        for (x, y), (u, v) in zip(quad, [(0, 0), (sw, 0), (sw, sh), (0, sh)]):
+            A += [[x, y, 1, 0, 0, 0, -u * x, -u * y], [0, 0, 0, x, y, 1, -v * x, -v * y]]
+            B += [u, v]
+        co = np.linalg.solve(np.array(A, float), np.array(B, float))
+        s = Image.fromarray(crop).convert("RGBA")
+        pasted = Image.fromarray(bg).convert("RGBA")
+        s.putalpha(255)
+        pasted.alpha_composite(s.transform((120, 90), Image.PERSPECTIVE, co, Image.BILINEAR))
+        out[f"persp{i}.coeffs"] = co
+        out[f"persp{i}.out"] = np.asarray(pasted)
+    save("paste", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also the 860 M-parameter UNet fixture")
@@ -464,7 +497,7 @@ if __name__ == "__main__":
     import builtins
     _print = builtins.print
     gens = {"fsai": gen_fsai, "warp": gen_warp, "warp_cuda": gen_warp_cuda_form, "attn": gen_attn_module, "tiny": gen_tiny_unet, "ddim": gen_ddim,
-            "vae": gen_vae}
+            "vae": gen_vae, "paste": gen_paste}
     gens["lowp"] = lambda: gen_lowp(a.full)
     if a.full:
         gens["full"] = gen_full_unet

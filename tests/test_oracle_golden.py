@@ -1,5 +1,6 @@
 """Pin the CPU oracle against golden vectors produced by the reference itself (tests/golden/make_golden.py).
 CPU only (`-m "not gpu"`)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -364,3 +365,15 @@ def test_raft_oracle_lookup_and_upsample_conventions():
     hidden = synth.synth_normal("raft.up.h", (1, 128, h, w))
     up = oraft.upsample_flow(sd, hidden, torch.full((1, 2, h, w), 1.5))
     assert torch.allclose(up[:, :, 8:-8, 8:-8], torch.full((1, 2, 112, 112), 12.0), atol=1e-5)
+
+
+def test_paste_oracle_matches_the_committed_pillow_fixture():
+    """tests/golden/paste.npz (make_golden.py::gen_paste: Pillow's own outputs, committed) -- the same pin as the live comparisons
+    above, for a box whose Pillow differs or is missing."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "paste.npz"), allow_pickle=False)
+    for i in range(5):
+        ow, oh = (int(v) for v in z[f"resize{i}.size"])
+        assert np.array_equal(opaste.resize_bilinear_u8(z[f"resize{i}.in"], ow, oh), z[f"resize{i}.out"])
+    for i in range(3):
+        got = opaste.perspective_paste(z["persp.crop"], z["persp.bg"], z[f"persp{i}.coeffs"])
+        assert np.array_equal(got, z[f"persp{i}.out"][..., :3]) and (z[f"persp{i}.out"][..., 3] == 255).all()

@@ -138,3 +138,20 @@ def test_paste_back_refuses_host_tensors_and_non_square_frames():
         pb.paste(dec, torch.zeros(1, 80, 80, 3, dtype=torch.uint8, device=DEV), np.zeros(8))
     with pytest.raises(ValueError, match="images do not match"):       # :621 swaps width and height (see PasteBack.background)
         pb.paste(dec.to(DEV), torch.zeros(1, 80, 100, 3, dtype=torch.uint8, device=DEV), np.array([1, 0, 0, 0, 1, 0, 0, 0.0]))
+
+
+def test_kernels_match_the_committed_pillow_fixture():
+    """The HIP kernels against tests/golden/paste.npz (Pillow's outputs, committed): resize and perspective paste, bit for bit."""
+    import os
+    from vface_amd import hip
+    from vface_amd.scripts.paste_back import PasteBack
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "paste.npz"), allow_pickle=False)
+    pb = PasteBack(device=DEV)
+    for i in range(5):
+        ow, oh = (int(v) for v in z[f"resize{i}.size"])
+        got = pb.resize_u8(torch.from_numpy(z[f"resize{i}.in"])[None].to(DEV), ow, oh)[0].cpu().numpy()
+        assert np.array_equal(got, z[f"resize{i}.out"])
+    for i in range(3):
+        frame = torch.from_numpy(z["persp.bg"])[None].contiguous().to(DEV)
+        hip.perspective_paste(torch.from_numpy(z["persp.crop"])[None].contiguous().to(DEV), frame, z[f"persp{i}.coeffs"])
+        assert np.array_equal(frame[0].cpu().numpy(), z[f"persp{i}.out"][..., :3])

@@ -210,10 +210,18 @@ def run_synthetic(opt) -> dict:
     for batch_id in range(opt.n_frames // F_):  # DataLoader(batch_size=n_samples, drop_last=True) (:376-382)
         tag = lambda s: f"cli.{s}.{batch_id}"
         d = lambda t: t.to(dev)
+        stages = {}
+
+        def stage(name, t_start):      # wall seconds of a pipeline stage, GPU drained on both sides
+            torch.cuda.synchronize()
+            stages[name] = stages.get(name, 0.0) + time.time() - t_start
+            return time.time()
         c, uc, tc = (d(synth.synth_normal(tag(k), (F_, 1, 768))) for k in ("c", "uc", "tc"))
         if opt.with_vae:
             img = d(torch.stack([synth.synth_normal(tag(f"img{f}"), (3, opt.H, opt.W)).clamp(-1, 1) for f in range(F_)]))
+            ts_ = stage("_", time.time())
             z_inp = model.get_first_stage_encoding(model.encode_first_stage(img)).detach()       # :456-457
+            stage("vae_encode", ts_)
         else:
             z_inp = d(synth.synth_normal(tag("inp"), (F_, opt.C, h, w)) * 0.18215)
         mask = d(synth.synth_mask(F_, h, w))
@@ -229,7 +237,9 @@ def run_synthetic(opt) -> dict:
                 raft = raft.to(dev).eval()
             video = img if opt.with_vae else d(torch.stack([synth.synth_normal(tag(f"img{f}"), (3, opt.H, opt.W)).clamp(-1, 1)
                                                             for f in range(F_)]))
+            ts_ = stage("_", time.time())
             flow = tflow.return_flow(video, raft)
+            stage("flow", ts_)
             sampler.flow_resample = "area"
         elif opt.flow_pixels:   # a pixel-resolution field whose latent resample is a +-2-cell motion
             flow = [f[None] * opt.f for f in synth.synth_flow(F_ - 1, opt.H, opt.W, seed=opt.seed + batch_id)]
@@ -245,9 +255,11 @@ def run_synthetic(opt) -> dict:
             # :531-540: invert [target ; source] (2F), hooks off; the target half is cached per timestep
             z2 = d(synth.synth_normal(tag("z2"), (2 * F_, opt.C, h, w)))
             kw2 = {"inpaint_image": torch.cat([z_inp, z_inp]), "inpaint_mask": torch.cat([mask, mask])}
+            ts_ = stage("_", time.time())
             sampler.ddim_invert(x=z2, cond=torch.cat([tc, c]), S=opt.ddim_steps, shape=[opt.C, h, w], eta=opt.ddim_eta,
                                 unconditional_guidance_scale=opt.scale, unconditional_conditioning=None,
                                 inverse_dir=inv_store, batch_size=F_, test_model_kwargs=kw2, max_steps=opt.max_steps)
+            stage("inversion", ts_)
         # :541 start code = the cached latent of the second-highest timestep ("ddim_latents_961.pt" at 50 steps)
         sampler.make_schedule(opt.ddim_steps, ddim_eta=opt.ddim_eta, verbose=False)
         ts = [int(s) for s in sampler.ddim_timesteps]
@@ -264,10 +276,13 @@ def run_synthetic(opt) -> dict:
                                     test_model_kwargs=kw, max_steps=opt.max_steps)
         torch.cuda.synchronize()
         dt_s = time.time() - t0
+        stages["sampling"] = dt_s
         pixels = None
         if opt.with_vae:
+            ts_ = time.time()
             x_samples = model.decode_first_stage(samples)                                          # :596
             pixels = torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0)                       # :597
+            stage("vae_decode", ts_)
         pasted, paste_s = None, None
         if opt.paste_back:
             if not opt.with_vae:
@@ -286,6 +301,7 @@ def run_synthetic(opt) -> dict:
             pasted = paster.paste(x_samples, frames, co)                                           # :603-633
             torch.cuda.synchronize()
             paste_s = time.time() - t1
+            stages["paste_back"] = paste_s
         if not opt.skip_save:
             if pasted is not None:
                 from PIL import Image
@@ -297,7 +313,8 @@ def run_synthetic(opt) -> dict:
         results.append({"batch": batch_id, "frames": F_, "sample_seconds": dt_s,
                         "finite": bool(torch.isfinite(samples).all()) and (pixels is None or bool(torch.isfinite(pixels).all())),
                         "pixels": None if pixels is None else list(pixels.shape),
-                        "pasted": None if pasted is None else list(pasted.shape), "paste_seconds": paste_s})
+                        "pasted": None if pasted is None else list(pasted.shape), "paste_seconds": paste_s,
+                        "stage_seconds": {k: v for k, v in stages.items() if k != "_"}})
         print(f"batch {batch_id}: {F_} frames sampled in {dt_s:.2f} s")
     return {"batches": results, "total_seconds": time.time() - t_all}
 
