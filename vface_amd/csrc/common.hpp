@@ -86,22 +86,27 @@ template <class E> __device__ __forceinline__ float to_f32(E x) { return (float)
 template <class E> __device__ __forceinline__ E from_f32(float x) { return (E)x; }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute): 1 - (a1 t + ... + a5 t^5) exp(-z^2),
-// t = 1 / (1 + p z).  Two transcendentals (v_rcp, v_exp) instead of the device library's branchy erff.
-__device__ __forceinline__ float erf_as_f(float x) {
-    const float z = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
+// F.gelu (erf form, attention.py:44) = x Phi(x) with Phi from Abramowitz & Stegun 7.1.26 (|error| <= 7.5e-8 absolute in Phi):
+//   erfc(z) = (a1 t + ... + a5 t^5) exp(-z^2),  t = 1 / (1 + p z),  z = |x| / sqrt(2)
+//   x Phi(x) = max(x, 0) - |x| u,   u = erfc(z) / 2
+// (x >= 0: x (1 - u); x < 0: x u = -|x| u.)  Two transcendentals (v_rcp, v_exp) and ten multiply-adds with the 1/2, 1/sqrt(2)
+// and log2(e) folded into the constants -- four fewer vector instructions per value than 0.5 x (1 + copysign(1 - 2u, x)), and no
+// 1 - (1 - 2u) cancellation for x << 0.  The fused FeedForward (ffn.hip) issues exactly this sequence piecewise.
+constexpr float GELU_P = 0.3275911f * 0.70710678118654752440f;                   // p / sqrt(2)
+constexpr float GELU_A1 = 0.5f * 0.254829592f, GELU_A2 = 0.5f * -0.284496736f, GELU_A3 = 0.5f * 1.421413741f,
+                GELU_A4 = 0.5f * -1.453152027f, GELU_A5 = 0.5f * 1.061405429f;
+constexpr float GELU_K = -0.5f * 1.44269504088896340736f;                         // exp(-x^2 / 2) = exp2(K x^2)
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(GELU_P, ax, 1.0f));
+    float poly = fmaf(GELU_A5, t, GELU_A4);
+    poly = fmaf(poly, t, GELU_A3);
+    poly = fmaf(poly, t, GELU_A2);
+    poly = fmaf(poly, t, GELU_A1);
     poly *= t;
-    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
-    const float r = 1.0f - poly * e;
-    return copysignf(r, x);
+    const float e = __builtin_amdgcn_exp2f(GELU_K * (x * x));
+    return fmaf(-ax, poly * e, fmaxf(x, 0.0f));
 }
-// F.gelu (erf form, attention.py:44)
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f)); }
 
 // max over the 4 lanes {l, l^16, l^32, l^48} with VALU lane swaps (no LDS round trip)
 __device__ __forceinline__ float quad_row_max(float v) {

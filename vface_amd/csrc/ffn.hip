@@ -143,12 +143,16 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     auto issue_w1_op = [&](int tile, int i) {     // piece i of the W1 stage of hidden tile `tile` (wrapped) -> ring slot tile % NW1
         const int base = ((tile % NT) * 32 * C) * 2;
         const unsigned dst = ldsW1 + (unsigned)(((tile % NW1) * W1E + wave * OPS * 512) * 2);
+#if !(defined(FFN_ABL) && FFN_ABL == 4)      // (ablation build: no DMA issue inside the loop -- timing only, results garbage)
         raw_lds_dma16(rW1, dst + i * 1024, w1_off[i], base);
+#endif
     };
     auto issue_w2_op = [&](int st, int i) {       // piece i of W2 stage st = hidden tiles 2 st, 2 st + 1 (wrapped) -> slot st % NW2
         const int base = ((st % (NT / 2)) * 32) * 2;
         const unsigned dst = ldsW2 + (unsigned)(((st % NW2) * W2E + wave * OPS * 512) * 2);
+#if !(defined(FFN_ABL) && FFN_ABL == 4)
         raw_lds_dma16(rW2, dst + i * 1024, w2_off[i], base);
+#endif
     };
     auto issue_w1 = [&](int tile) {
 #pragma unroll
@@ -159,10 +163,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
         for (int i = 0; i < OPS; ++i) issue_w2_op(st, i);
     };
     // fragment reads (A operands of the 32x32x16 MFMA): 32 rows x one 16-byte chunk per lane half
-    auto w1_frag = [&](int tile, int ks) -> V8 {
-        const int c = 2 * ks + fh;
-        const int slot = (c & ~7) | ((c & 7) ^ ((fr >> 1) & 7));
-        return *reinterpret_cast<const V8*>(sW1 + (tile % NW1) * W1E + fr * C + slot * 8);
+    // (the slot of k chunk c = 2 ks + fh is 8 (ks >> 2) + ((2 (ks & 3) + fh) ^ swz): four lane offsets, one per ks & 3, and a
+    // compile-time 128-byte step per ks >> 2 -- one address register per (tile, ks & 3) instead of one vector add per read)
+    int w1_lane[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w1_lane[j] = fr * C + (((2 * j + fh) ^ ((fr >> 1) & 7)) << 3);
+    auto w1_frag_at = [&](const E* const (&base)[4], int ks) -> V8 {
+        return *reinterpret_cast<const V8*>(base[ks & 3] + (ks >> 2) * 64);
     };
     auto w2_frag = [&](int tile, int ot) -> V8 {
         const int row = ot * 32 + fr;
@@ -186,8 +193,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
 
     V8 af[RA], wf[RB], hbE, hbO;         // hbE / hbO: GEGLU results (GEMM 2 B operands) of even / odd tiles
     f16_t accA, accB;                    // GEMM 1 accumulators of even / odd tiles
+    {
+        const E* b0[4];
 #pragma unroll
-    for (int i = 0; i < RA; ++i) af[i] = w1_frag(0, i);
+        for (int j = 0; j < 4; ++j) b0[j] = sW1 + w1_lane[j];
+#pragma unroll
+        for (int i = 0; i < RA; ++i) af[i] = w1_frag_at(b0, i);
+    }
 
     // One interval of the three-deep pipeline: GEMM 1 of tile t (H1) || GEGLU of tile t - 1 (HG) || GEMM 2 of tile t - 2 (H2),
     // one instruction stream: per k16 step one MFMA of GEMM 1, every other step one of GEMM 2, every other step one GEGLU value.
@@ -204,53 +216,59 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
         raw_barrier();
         // (the stages of this interval -- W1 stage t + 3, in even intervals W2 stage t / 2 + 1 -- are issued one DMA instruction
         // at a time inside the k loop below: a burst of them at the top cost each wave the whole CU's address-unit time)
-        float ba[8], bg[8], hv[8];
-        if constexpr (HG) {
-            gap_mfma_result_to_valu(prev);     // tile t - 1's last MFMA -> the vector reads below
-            const float* bp = sB1 + (t - 1) * 32 + fh * 4;
+        float hv[8];
+        const E* wa[4];      // W1 fragment bases of tile t and of tile t + 1 (the window runs RA - 1 steps ahead)
+        const E* wb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            wa[j] = sW1 + (t % NW1) * W1E + w1_lane[j];
+            wb[j] = sW1 + ((t + 1) % NW1) * W1E + w1_lane[j];
+        }
+        if constexpr (HG) gap_mfma_result_to_valu(prev);     // tile t - 1's last MFMA -> the vector reads below
+        if constexpr (H1) {
+            // ff.net[0]'s bias IS the accumulator's initial value (rows of the 32 x 32 layout: register q -> value row
+            // (q & 3) + 8 (q >> 2) + 4 h, register q + 8 its gate row): four broadcast LDS reads straight into the accumulator
+            // registers instead of 16 vector adds per tile beside the MFMAs (hipcc packed them into v_pk_add_f32 -- an
+            // anti-lever beside MFMAs, guide "price of one filler" -- with a v_mov per operand pair)
+            const float* bp = sB1 + t * 32 + fh * 4;
             const float4 v0 = *reinterpret_cast<const float4*>(bp), v1 = *reinterpret_cast<const float4*>(bp + 8);
             const float4 g0 = *reinterpret_cast<const float4*>(bp + 16), g1 = *reinterpret_cast<const float4*>(bp + 24);
-            ba[0] = v0.x; ba[1] = v0.y; ba[2] = v0.z; ba[3] = v0.w; ba[4] = v1.x; ba[5] = v1.y; ba[6] = v1.z; ba[7] = v1.w;
-            bg[0] = g0.x; bg[1] = g0.y; bg[2] = g0.z; bg[3] = g0.w; bg[4] = g1.x; bg[5] = g1.y; bg[6] = g1.z; bg[7] = g1.w;
+            cur[0] = v0.x; cur[1] = v0.y; cur[2] = v0.z; cur[3] = v0.w; cur[4] = v1.x; cur[5] = v1.y; cur[6] = v1.z; cur[7] = v1.w;
+            cur[8] = g0.x; cur[9] = g0.y; cur[10] = g0.z; cur[11] = g0.w; cur[12] = g1.x; cur[13] = g1.y; cur[14] = g1.z; cur[15] = g1.w;
         }
         // GEGLU (attention.py:37-45: x, gate = proj(x).chunk(2); x * gelu(gate), erf form) of tile t - 1's eight hidden units per
         // lane, cut into 24 pieces of 5-7 vector instructions -- piece (value q, stage s) goes into the gap behind the (3 q + s)-th
         // MFMA of the interval.  A wave issues in order: an MFMA behind an MFMA waits for the matrix pipe (32 cycles), and only the
         // instructions BETWEEN two MFMAs run beside the first; the earlier layout (two MFMAs, then a whole value's 22 dependent
         // vector instructions) measured as the plain SUM of matrix and vector time.  The arithmetic and its order are those of
-        // gelu_erf_f (common.hpp): the result is bit-identical to the three-kernel path's epilogue.  Empty asm statements pin each
+        // gelu_erf_f (common.hpp); the bias enters as the accumulator's initial value (below), so a sum differs from the
+        // three-kernel path's (acc + bias) in its last fp32 bit at most: the 16-bit results agree to ~1e-5 rel-L2.  Empty asm statements pin each
         // piece in its gap (volatile asm keeps its order; hipcc otherwise packs pieces pairwise into v_pk_*_f32 and hoists them).
-        float gG[8], gA[8], gX[8], gT[8], gE[8], gP[8];
+        float gG[8], gA[8], gT[8], gE[8], gP[8];
         auto gelu_piece = [&](int idx) {
             if (idx >= 24) return;
             const int q = idx / 3, st = idx % 3;
-            if (st == 0) {
+            if (st == 0) {               // t = 1 / (1 + p |g| / sqrt 2), e = exp(-g^2 / 2)
                 float a = prev[q], gt = prev[q + 8];
                 asm volatile("" : "+v"(a), "+v"(gt));
-                a += ba[q];
-                gt += bg[q];
-                const float xs = gt * 0.70710678118654752440f;
-                const float z = fabsf(xs);
-                float tt = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-                float ee = __builtin_amdgcn_exp2f(-1.44269504088896340736f * z * z);
+                float tt = __builtin_amdgcn_rcpf(fmaf(GELU_P, fabsf(gt), 1.0f));
+                float ee = __builtin_amdgcn_exp2f(GELU_K * (gt * gt));
                 asm volatile("" : "+v"(tt), "+v"(ee));
-                gG[q] = gt; gA[q] = a; gX[q] = xs; gT[q] = tt; gE[q] = ee;
-            } else if (st == 1) {
+                gG[q] = gt; gA[q] = a; gT[q] = tt; gE[q] = ee;
+            } else if (st == 1) {        // the half-scaled polynomial
                 float tt = gT[q];
                 asm volatile("" : "+v"(tt));
-                float poly = fmaf(1.061405429f, tt, -1.453152027f);
-                poly = fmaf(poly, tt, 1.421413741f);
-                poly = fmaf(poly, tt, -0.284496736f);
-                poly = fmaf(poly, tt, 0.254829592f);
+                float poly = fmaf(GELU_A5, tt, GELU_A4);
+                poly = fmaf(poly, tt, GELU_A3);
+                poly = fmaf(poly, tt, GELU_A2);
+                poly = fmaf(poly, tt, GELU_A1);
                 poly *= tt;
                 asm volatile("" : "+v"(poly));
                 gP[q] = poly;
-            } else {
+            } else {                     // value * (max(g, 0) - |g| u)
                 float poly = gP[q];
                 asm volatile("" : "+v"(poly));
-                const float r = 1.0f - poly * gE[q];
-                const float erf_ = copysignf(r, gX[q]);
-                float hq = gA[q] * (0.5f * gG[q] * (1.0f + erf_));
+                float hq = gA[q] * fmaf(-fabsf(gG[q]), poly * gE[q], fmaxf(gG[q], 0.0f));
                 asm volatile("" : "+v"(hq));
                 hv[q] = hq;
             }
@@ -259,12 +277,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             if constexpr (H1) {
-                if (ks == 0) TT::mfma32x32_vzero(cur, af[ks % RA], xf[ks]);
-                else TT::mfma32x32_vacc(cur, af[ks % RA], xf[ks]);
+                TT::mfma32x32_vacc(cur, af[ks % RA], xf[ks]);
                 // refill the window slot of the PREVIOUS MFMA (a load into the registers the MFMA just issued is still reading
                 // waits for it, and everything behind the load with it: measured as matrix + vector time in series): step
                 // ks - 1 + RA of this tile, or of the next (its stage has landed)
-                af[(ks + RA - 1) % RA] = (ks - 1 + RA < KS) ? w1_frag(t, ks - 1 + RA) : w1_frag(t + 1, ks - 1 + RA - KS);
+                af[(ks + RA - 1) % RA] = (ks - 1 + RA < KS) ? w1_frag_at(wa, ks - 1 + RA) : w1_frag_at(wb, ks - 1 + RA - KS);
             }
             if (ks % 4 == 1) issue_w1_op(t + 3, ks / 4);                    // (KS = 4 OPS)
             if constexpr (EVEN) { if (ks % 4 == 3) issue_w2_op(t / 2 + 1, ks / 4); }
