@@ -143,16 +143,12 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     auto issue_w1_op = [&](int tile, int i) {     // piece i of the W1 stage of hidden tile `tile` (wrapped) -> ring slot tile % NW1
         const int base = ((tile % NT) * 32 * C) * 2;
         const unsigned dst = ldsW1 + (unsigned)(((tile % NW1) * W1E + wave * OPS * 512) * 2);
-#if !(defined(FFN_ABL) && FFN_ABL == 4)      // (ablation build: no DMA issue inside the loop -- timing only, results garbage)
         raw_lds_dma16(rW1, dst + i * 1024, w1_off[i], base);
-#endif
     };
     auto issue_w2_op = [&](int st, int i) {       // piece i of W2 stage st = hidden tiles 2 st, 2 st + 1 (wrapped) -> slot st % NW2
         const int base = ((st % (NT / 2)) * 32) * 2;
         const unsigned dst = ldsW2 + (unsigned)(((st % NW2) * W2E + wave * OPS * 512) * 2);
-#if !(defined(FFN_ABL) && FFN_ABL == 4)
         raw_lds_dma16(rW2, dst + i * 1024, w2_off[i], base);
-#endif
     };
     auto issue_w1 = [&](int tile) {
 #pragma unroll
@@ -162,6 +158,34 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
 #pragma unroll
         for (int i = 0; i < OPS; ++i) issue_w2_op(st, i);
     };
+    // Loop-carried scalar state of the two weight streams, advanced by add + wrap at the end of an interval -- written as `tile %
+    // NT` / `st % NW2` of the runtime interval index, hipcc rebuilt every offset per DMA piece by magic-number division (40-60
+    // scalar instructions per interval, each an issue slot of the one wave this SIMD has).
+    //   issue side: the stage an interval issues (W1 stage t + 3; W2 stage t / 2 + 1 in even intervals)
+    int w1i_glob = 3 * 32 * C * 2, w1i_slot = 3 % NW1;                 // byte offset into W1 / ring slot of stage t + 3 at t = 0
+    int w2i_glob = 1 * 32 * 2, w2i_slot = 1 % NW2;                     // the same for W2 stage 1
+    const unsigned ldsW1w = ldsW1 + (unsigned)(wave * OPS * 1024), ldsW2w = ldsW2 + (unsigned)(wave * OPS * 1024);
+    auto issue_w1_piece = [&](int i) {
+#if !(defined(FFN_ABL) && FFN_ABL == 4)      // (ablation build: no DMA issue inside the loop -- timing only, results garbage)
+        raw_lds_dma16(rW1, ldsW1w + (unsigned)(w1i_slot * (W1E * 2) + i * 1024), w1_off[i], w1i_glob);
+#endif
+    };
+    auto issue_w2_piece = [&](int i) {
+#if !(defined(FFN_ABL) && FFN_ABL == 4)
+        raw_lds_dma16(rW2, ldsW2w + (unsigned)(w2i_slot * (W2E * 2) + i * 1024), w2_off[i], w2i_glob);
+#endif
+    };
+    auto advance_w1_issue = [&]() {
+        w1i_glob += 32 * C * 2;
+        if (w1i_glob == NT * 32 * C * 2) w1i_glob = 0;                 // past the end: wrap to stages nobody reads
+        w1i_slot = (w1i_slot + 1) & (NW1 - 1);
+    };
+    auto advance_w2_issue = [&]() {
+        w2i_glob += 32 * 2;
+        if (w2i_glob == (NT / 2) * 32 * 2) w2i_glob = 0;
+        w2i_slot = (w2i_slot + 1 == NW2) ? 0 : w2i_slot + 1;
+    };
+    static_assert((NW1 & (NW1 - 1)) == 0, "W1 ring: a power of two");
     // fragment reads (A operands of the 32x32x16 MFMA): 32 rows x one 16-byte chunk per lane half
     // (the slot of k chunk c = 2 ks + fh is 8 (ks >> 2) + ((2 (ks & 3) + fh) ^ swz): four lane offsets, one per ks & 3, and a
     // compile-time 128-byte step per ks >> 2 -- one address register per (tile, ks & 3) instead of one vector add per read)
@@ -171,11 +195,17 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     auto w1_frag_at = [&](const E* const (&base)[4], int ks) -> V8 {
         return *reinterpret_cast<const V8*>(base[ks & 3] + (ks >> 2) * 64);
     };
-    auto w2_frag = [&](int tile, int ot) -> V8 {
-        const int row = ot * 32 + fr;
-        const int slot = (2 * (tile & 1) + fh) ^ ((row >> 2) & 3);
-        return *reinterpret_cast<const V8*>(sW2 + ((tile >> 1) % NW2) * W2E + row * 32 + slot * 8);
-    };
+    // W2: row ot * 32 + fr, chunk (2 (tile & 1) + fh) ^ ((fr >> 2) & 3) -- a lane offset per tile parity and 2 KiB per ot
+    int w2_lane[2];
+#pragma unroll
+    for (int par = 0; par < 2; ++par) w2_lane[par] = fr * 32 + (((2 * par + fh) ^ ((fr >> 2) & 3)) << 3);
+    auto w2_frag_at = [&](const E* base, int ot) -> V8 { return *reinterpret_cast<const V8*>(base + ot * 1024); };
+    //   read side: ring slot of W1 tile t + 1 (the window reads RA - 1 steps ahead) and of the W2 stage of tile t - 2
+    int w1r_slot = 1 % NW1, w2r_slot = 0;
+    const E* wa[4];          // W1 fragment bases of tile t ...
+    const E* wb[4];          // ... and of tile t + 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wa[j] = sW1 + w1_lane[j]; wb[j] = sW1 + (1 % NW1) * W1E + w1_lane[j]; }
 
     f16_t out[NOT];
 #pragma unroll
@@ -193,13 +223,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
 
     V8 af[RA], wf[RB], hbE, hbO;         // hbE / hbO: GEGLU results (GEMM 2 B operands) of even / odd tiles
     f16_t accA, accB;                    // GEMM 1 accumulators of even / odd tiles
-    {
-        const E* b0[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b0[j] = sW1 + w1_lane[j];
-#pragma unroll
-        for (int i = 0; i < RA; ++i) af[i] = w1_frag_at(b0, i);
-    }
+    for (int i = 0; i < RA; ++i) af[i] = w1_frag_at(wa, i);
 
     // One interval of the three-deep pipeline: GEMM 1 of tile t (H1) || GEGLU of tile t - 1 (HG) || GEMM 2 of tile t - 2 (H2),
     // one instruction stream: per k16 step one MFMA of GEMM 1, every other step one of GEMM 2, every other step one GEGLU value.
@@ -217,13 +242,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
         // (the stages of this interval -- W1 stage t + 3, in even intervals W2 stage t / 2 + 1 -- are issued one DMA instruction
         // at a time inside the k loop below: a burst of them at the top cost each wave the whole CU's address-unit time)
         float hv[8];
-        const E* wa[4];      // W1 fragment bases of tile t and of tile t + 1 (the window runs RA - 1 steps ahead)
-        const E* wb[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            wa[j] = sW1 + (t % NW1) * W1E + w1_lane[j];
-            wb[j] = sW1 + ((t + 1) % NW1) * W1E + w1_lane[j];
-        }
+        // GEMM 2's fragment bases: tile t - 2 (parity of t) in W2 ring slot w2r_slot; the window's look-ahead into tile t - 1 is
+        // the other parity -- of the same stage in even intervals, of the next stage in odd ones
+        const E* w2a = sW2 + w2r_slot * W2E + w2_lane[EVEN ? 0 : 1];
+        const E* w2b = sW2 + (EVEN ? w2r_slot : (w2r_slot + 1 == NW2 ? 0 : w2r_slot + 1)) * W2E + w2_lane[EVEN ? 1 : 0];
         if constexpr (HG) gap_mfma_result_to_valu(prev);     // tile t - 1's last MFMA -> the vector reads below
         if constexpr (H1) {
             // ff.net[0]'s bias IS the accumulator's initial value (rows of the 32 x 32 layout: register q -> value row
@@ -283,8 +305,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
                 // ks - 1 + RA of this tile, or of the next (its stage has landed)
                 af[(ks + RA - 1) % RA] = (ks - 1 + RA < KS) ? w1_frag_at(wa, ks - 1 + RA) : w1_frag_at(wb, ks - 1 + RA - KS);
             }
-            if (ks % 4 == 1) issue_w1_op(t + 3, ks / 4);                    // (KS = 4 OPS)
-            if constexpr (EVEN) { if (ks % 4 == 3) issue_w2_op(t / 2 + 1, ks / 4); }
+            if (ks % 4 == 1) issue_w1_piece(ks / 4);                        // (KS = 4 OPS)
+            if constexpr (EVEN) { if (ks % 4 == 3) issue_w2_piece(ks / 4); }
             if constexpr (HG) {
                 if constexpr (KS >= 16) { gelu_piece(gap); ++gap; }
                 else { for (int u = 0; u < (24 + KS + KS / 2 - 1) / (KS + KS / 2); ++u) { gelu_piece(gap); ++gap; } }
@@ -296,10 +318,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
                     TT::mfma32x32_acc(out[ot], wf[ot % RB], hr);
                     // refill the previous MFMA's slot: tile t - 2's fragment ot - 1 + RB, or the next tile's (tile t - 1: its W2
                     // stage landed intervals ago)
-                    wf[(ot + RB - 1) % RB] = (ot - 1 + RB < NOT) ? w2_frag(t - 2, ot - 1 + RB) : w2_frag(t - 1, ot - 1 + RB - NOT);
+                    wf[(ot + RB - 1) % RB] = (ot - 1 + RB < NOT) ? w2_frag_at(w2a, ot - 1 + RB) : w2_frag_at(w2b, ot - 1 + RB - NOT);
                 }
             } else if (ks >= KS - RB && t == 1) {
-                wf[ks - (KS - RB)] = w2_frag(0, ks - (KS - RB));      // interval 1: GEMM 2's window for tile 0
+                wf[ks - (KS - RB)] = w2_frag_at(sW2 + w2_lane[0], ks - (KS - RB));      // interval 1: GEMM 2's window for tile 0 (stage 0, slot 0)
             }
             if constexpr (HG) {
                 if (ks % 2 == 0) {
@@ -315,6 +337,13 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
             for (int qi = 0; qi < 8; ++qi) hw[qi] = from_f32<E>(hv[qi]);
             gap_valu_result_to_mfma(hw);
         }
+        // the streams' state for interval t + 1
+        advance_w1_issue();
+        if constexpr (EVEN) advance_w2_issue();
+        w1r_slot = (w1r_slot + 1) & (NW1 - 1);                          // ring slot of tile t + 2
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wa[j] = wb[j]; wb[j] = sW1 + w1r_slot * W1E + w1_lane[j]; }
+        if constexpr (H2 && !EVEN) w2r_slot = (w2r_slot + 1 == NW2) ? 0 : w2r_slot + 1;      // tile t - 1 (even) opens the next W2 stage
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
