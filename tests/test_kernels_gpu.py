@@ -210,6 +210,35 @@ def test_attention_shared_scores(dt, dh, sets, n):
     assert rel_l2(out3.cpu().float(), ref3) < TOL[dt]
 
 
+@pytest.mark.parametrize("sets,n", [(1, 500), (1, 4096), (3, 320)])
+def test_attention_dh40_32x32_form(sets, n):
+    """The A/B form of the dh = 40 kernel on mfma 32x32x16 (variant bit 2; never chosen by the dispatcher: measured slower):
+    ragged tail, a spiked key that forces a late rescale, plain and shared-score -- against torch and against the shipped form."""
+    h = hip()
+    dt, dh, heads, Fr = torch.float16, 40, 8, 2
+    B = sets * Fr
+    d = heads * dh
+    qkv = rnd((B, n, 3 * d), 31, dt)
+    qkv[:, (2 * n) // 3, d:2 * d] *= 5.0
+    qd = qkv.to(DEV)
+    scale = dh ** -0.5
+    kw = dict(heads=heads, n=n, nk=n, dh=dh, ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d, ldo=d,
+              bso=n * d, scale=scale)
+    if sets > 1:
+        kw.update(B=Fr, v_sets=sets, set_stride=Fr)
+        qk_map = (torch.arange(B) % Fr).long()
+    else:
+        kw.update(B=B)
+        qk_map = None
+    outs = []
+    for variant in (0, 4):
+        out = torch.zeros(B, n, d, dtype=dt, device=DEV)
+        h.attention(qd, qd[:, :, d:], qd[:, :, 2 * d:], out, variant=variant, **kw)
+        outs.append(out.cpu().float())
+    ref = _attn_ref(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], heads, scale, qk_map, None)
+    assert rel_l2(outs[1], ref) < 1e-3 and rel_l2(outs[1], outs[0]) < 3e-4
+
+
 def test_attention_shared_scores_rejects_unsupported():
     h = hip()
     dh, heads, n, B = 80, 8, 64, 3

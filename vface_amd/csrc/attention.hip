@@ -37,6 +37,13 @@ constexpr int v_pitch_bytes(int dvp) {
     return ((b / 32) & 1) ? b : b + 32;
 }
 
+// W32 form: a 32-lane half reads 4 rows x 64 B per ds_read_b64_tr_b16 -- a pitch of 64 (mod 256) bytes tiles the bank row.
+constexpr int v_pitch_bytes32(int dvp) {
+    int b = round_up(dvp * 2, 64);
+    while (b % 256 != 64 && b % 256 != 192) b += 64;
+    return b;
+}
+
 // G > 1: "shared score" form for the hook's "replace" injection (pnp_utils.py:133-143, :259-262).  There every chunk
 // uses q,k of chunk 0, so softmax(q k^T) is the SAME matrix for the G chunks of a frame and only V differs: one
 // workgroup computes the probabilities once and multiplies them with the G value blocks side by side (a G*DH-wide
@@ -46,24 +53,33 @@ constexpr int v_pitch_bytes(int dvp) {
 // exponential: one VALU op per score less than the exact form.  m_ref follows the running max loosely -- it is raised
 // (with the usual rescale of O) only when a block's max exceeds it by more than 8, so P stays below 2^8 (exact in fp32
 // accumulation; fp16 keeps its relative precision).  Costs one extra fp16 rounding of q.
-template <class TT, int DH, int QT, int G, bool LAZY>
+// W32: the same kernel on mfma_f32_32x32x16 (dh = 40, LAZY only).  A wave's 16 QT queries are QT / 2 tiles of 32; a score tile is
+// 32 keys x 32 queries (lane = query l & 31, half h = l >> 5 holds keys (r & 3) + 8 (r >> 2) + 4 h), so registers 8 j .. 8 j + 7 of
+// a tile are the B operand of the j-th 16-key step of O^T += V^T P^T as they stand.  The kernel is bound by VECTOR ISSUE (64
+// exponentials per lane and block), and every MFMA holds the SIMD's vector issue for 8 cycles whatever its shape: 28 MFMAs of 32
+// cycles per wave and block instead of 56 of 16 / 8 give half the held slots back at 17 % more matrix-pipe time (the 48 value
+// columns become two tiles of 32).  MEASURED SLOWER (690 vs 660 us plain, 457 vs 388 us shared-score): the pipe time it adds
+// costs more than the issue slots it returns -- the two co-resident workgroups' matrix and vector phases do not overlap as
+// freely as that budget assumed.  Kept behind variant bit 2 as a tested A/B form, never chosen by the dispatcher.
+template <class TT, int DH, int QT, int G, bool LAZY, bool W32 = false>
 __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
     using V4 = typename TT::v4;
+    static_assert(!W32 || (LAZY && QT % 2 == 0 && DH % 8 == 0 && DH <= 64), "W32: lazy softmax, pairs of query tiles, one 128-byte K row");
     // QK^T contraction: NKS steps of 32 (mfma 16x16x32) + one step of 16 (mfma 16x16x16) when DH % 32 is 8 or 16,
     // so head dim 40 costs 48 instead of 64, and 80 costs exactly 80.
     constexpr int NKS = DH / 32, TAIL = (DH % 32) ? 1 : 0;
     static_assert(DH % 32 == 0 || DH % 32 == 8 || DH % 32 == 16, "head dim");
     constexpr int DKP = NKS * 32 + TAIL * 16;
     constexpr int DV = G * DH;                       // value columns side by side (G sets)
-    constexpr int DVP = round_up(DV, 16), NC = DVP / 16;
+    constexpr int DVP = W32 ? round_up(DV + 1, 32) : round_up(DV, 16), NC = DVP / 16;
     // spare V column (DVP > DV): filled with ones, so the MFMA that builds O also builds the softmax denominator
     constexpr bool ONES = DVP > DV;
     // K block rows: 128 B (DKP <= 64) or 256 B (DKP <= 128), 16-B slots XOR-swizzled by the row so a ds_read_b128 of
     // 16 keys x one k-chunk is bank-conflict free (same rule as the GEMM tiles); larger head dims keep padded rows.
     constexpr int KROW = k_row_elems(DKP);           // elements
-    constexpr int VROW = v_pitch_bytes(DVP) / 2;     // elements
+    constexpr int VROW = (W32 ? v_pitch_bytes32(DVP) : v_pitch_bytes(DVP)) / 2;     // elements
     constexpr int CPR = DH / 8;                      // 16-B chunks per K row (and per V row of one set)
 
 
@@ -196,6 +212,157 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         }
     };
 
+    if constexpr (W32) {
+        // ================= the 32 x 32 x 16 form (see the template comment) =================
+        constexpr int QT2 = QT / 2;                  // 32-query tiles of this wave
+        constexpr int KS16 = DKP / 16;               // k16 steps of the score MFMAs (dh 40: 3, the last one half zeros)
+        constexpr int NC32 = DVP / 32;               // 32-column value tiles (the ones column included)
+        const int r32 = lane & 31, hh = lane >> 5, cb = (lane >> 4) & 1;
+        // Q fragments: lane (query r32, half hh) holds dh 16 ks + 8 hh .. + 7, scaled by scale * log2(e), zero past DH
+        V8 qf2[QT2][KS16];
+        const float cq = p.scale * 1.44269504088896340736f;
+#pragma unroll
+        for (int qt = 0; qt < QT2; ++qt) {
+            const int q = q0 + qt * 32 + r32;
+#pragma unroll
+            for (int ks = 0; ks < KS16; ++ks) {
+                const int d = ks * 16 + hh * 8;
+                V8 v;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (E)0.0f;
+                if (q < p.n && d < DH) v = *reinterpret_cast<const V8*>(Qg + (long)q * p.ldq + d);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = from_f32<E>(to_f32(v[j]) * cq);
+                qf2[qt][ks] = v;
+            }
+        }
+        f16_t o2[NC32][QT2], cneg2[QT2];
+#pragma unroll
+        for (int qt = 0; qt < QT2; ++qt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cneg2[qt][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC32; ++c)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o2[c][qt][r] = 0.f;
+        }
+        const int nblocks2 = (nk + KVB - 1) / KVB;
+        __syncthreads();  // zero fill (and the ones column) done before the first DMA lands
+        stage_block(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kb = 0; kb < nblocks2; ++kb) {
+            const int cur = kb & 1;
+            if (kb + 1 < nblocks2) stage_block(kb + 1, cur ^ 1);
+            const E* cK = sK + cur * KVB * KROW;
+            const E* cV = sV + cur * KVB * VROW;
+            // ---- S^T = K Q^T - m_ref: s2[kt][qt], lane holds keys 32 kt + (r & 3) + 8 (r >> 2) + 4 hh of query r32
+            f16_t s2[2][QT2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                for (int qt = 0; qt < QT2; ++qt) s2[kt][qt] = cneg2[qt];
+#pragma unroll
+                for (int ks = 0; ks < KS16; ++ks) {
+                    const int row = kt * 32 + r32;
+                    const V8 kf = *reinterpret_cast<const V8*>(cK + row * KROW + k_slot<KROW>(row, ks * 2 + hh) * 8);
+#pragma unroll
+                    for (int qt = 0; qt < QT2; ++qt) s2[kt][qt] = TT::mfma32x32(kf, qf2[qt][ks], s2[kt][qt]);
+                }
+            }
+            // ---- online softmax (fp32, lazy reference)
+            const bool tail = (kb + 1) * KVB > nk;
+            V8 pf2[QT2][2][2];
+#pragma unroll
+            for (int qt = 0; qt < QT2; ++qt) {
+                if (tail) {
+                    int kbase = kb * KVB + hh * 4;
+                    asm volatile("" : "+v"(kbase));
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (kbase + kt * 32 + (r & 3) + 8 * (r >> 2) >= nk) s2[kt][qt][r] = -1e30f;
+                }
+                float mx = -1e30f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s2[kt][qt][r]);
+                if (__any((kb == 0) || (mx > 8.0f))) {
+                    {   // the query's maximum: its other half lives in lane l ^ 32
+                        unsigned u = __builtin_bit_cast(unsigned, mx);
+                        auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+                        mx = fmaxf(__builtin_bit_cast(float, (unsigned)sw[0]), __builtin_bit_cast(float, (unsigned)sw[1]));
+                    }
+                    const bool shift = (kb == 0) || (mx > 8.0f);
+                    const float delta = shift ? mx : 0.f;
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cneg2[qt][r] -= delta;
+#pragma unroll
+                    for (int c = 0; c < NC32; ++c)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o2[c][qt][r] *= alpha;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s2[kt][qt][r] -= delta;
+                }
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        V8 v;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = from_f32<E>(__builtin_amdgcn_exp2f(s2[kt][qt][8 * j + i]));
+                        pf2[qt][kt][j] = v;
+                    }
+            }
+            // ---- O^T += V^T P^T: the j-th 16-key step of key tile kt pairs B k index 8 hh + i with key 16 j + 4 hh + (i & 3) + 8 (i >> 2)
+#pragma unroll
+            for (int c = 0; c < NC32; ++c) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const E* base = cV + (kt * 32 + j * 16 + hh * 4 + (fr >> 2)) * VROW + c * 32 + cb * 16 + (fr & 3) * 4;
+                        const V4 lo = TT::tr_read(base);
+                        const V4 hi = TT::tr_read(base + 8 * VROW);
+                        V8 vf;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { vf[r] = lo[r]; vf[4 + r] = hi[r]; }
+#pragma unroll
+                        for (int qt = 0; qt < QT2; ++qt) o2[c][qt] = TT::mfma32x32(vf, pf2[qt][kt][j], o2[c][qt]);
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // ---- normalise and store: lane (query r32, half hh) holds value columns 32 c + 8 rq + 4 hh .. + 3 in registers 4 rq .. 4 rq + 3
+        E* Og2 = reinterpret_cast<E*>(p.O) + (long)b * p.bso + h * DH;
+#pragma unroll
+        for (int qt = 0; qt < QT2; ++qt) {
+            constexpr int drow = DV % 32;            // the ones column: row drow of value tile DV / 32
+            const float l = __shfl(o2[DV / 32][qt][(drow & 3) + 4 * (drow >> 3)], r32 + 32 * ((drow >> 2) & 1), 64);
+            const float inv = 1.0f / l;
+            const int q = q0 + qt * 32 + r32;
+            if (q >= p.n) continue;
+#pragma unroll
+            for (int c = 0; c < NC32; ++c)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int d0 = c * 32 + rq * 8 + hh * 4;
+                    if (d0 >= DV) continue;
+                    const int g = d0 / DH, d = d0 - g * DH;
+                    V4 ov;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ov[r] = from_f32<E>(o2[c][qt][4 * rq + r] * inv);
+                    *reinterpret_cast<V4*>(Og2 + (long)g * gs * p.bso + (long)q * p.ldo + d) = ov;
+                }
+        }
+        return;
+    }
     f4_t o[NC][QT];
 #pragma unroll
     for (int c = 0; c < NC; ++c)
@@ -408,12 +575,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     }
 }
 
-template <class TT, int DH, int QT, int G = 1, bool LAZY = false>
+template <class TT, int DH, int QT, int G = 1, bool LAZY = false, bool W32 = false>
 int launch(const AttnParams& p, hipStream_t stream) {
-    constexpr int DKP = (DH / 32) * 32 + ((DH % 32) ? 16 : 0), DVP = round_up(G * DH, 16);
-    constexpr int KROW = k_row_elems(DKP), VROW = v_pitch_bytes(DVP) / 2;
+    constexpr int DKP = (DH / 32) * 32 + ((DH % 32) ? 16 : 0), DVP = W32 ? round_up(G * DH + 1, 32) : round_up(G * DH, 16);
+    constexpr int KROW = k_row_elems(DKP), VROW = (W32 ? v_pitch_bytes32(DVP) : v_pitch_bytes(DVP)) / 2;
     constexpr size_t lds = (size_t)(2 * KVB * KROW + 2 * KVB * VROW) * 2;
-    auto kern = attn_kernel<TT, DH, QT, G, LAZY>;
+    auto kern = attn_kernel<TT, DH, QT, G, LAZY, W32>;
     static VfOncePerDevice attr_set;
     if (lds > 64 * 1024 && !attr_set.set_lds(reinterpret_cast<const void*>(kern), (int)lds)) return VF_ERR_LAUNCH;
     dim3 grid(((p.n + 64 * QT - 1) / (64 * QT)) * p.heads * p.B);
@@ -437,7 +604,7 @@ int dispatch_l(const AttnParams& p, hipStream_t stream) {
             case 8: return launch<TT, 8, 2, 3, LAZY>(p, stream);
             case 16: return launch<TT, 16, 2, 3, LAZY>(p, stream);
             case 32: return launch<TT, 32, 2, 3, LAZY>(p, stream);
-            case 40: return launch<TT, 40, 2, 3, LAZY>(p, stream);
+            case 40: return (LAZY && (p.variant & 4)) ? launch<TT, 40, 2, 3, LAZY, LAZY>(p, stream) : launch<TT, 40, 2, 3, LAZY>(p, stream);
             default: return VF_ERR_SHAPE;
         }
     }
@@ -445,13 +612,17 @@ int dispatch_l(const AttnParams& p, hipStream_t stream) {
         case 8: return launch<TT, 8, 2, 1, LAZY>(p, stream);
         case 16: return launch<TT, 16, 2, 1, LAZY>(p, stream);
         case 32: return launch<TT, 32, 2, 1, LAZY>(p, stream);
-        case 40: return (p.variant & 1) ? launch<TT, 40, 2, 1, LAZY>(p, stream) : launch<TT, 40, 4, 1, LAZY>(p, stream);
+        case 40:
+            if (LAZY && (p.variant & 5) == 4) return launch<TT, 40, 4, 1, LAZY, LAZY>(p, stream);      // A/B: the 32 x 32 x 16 form
+            return (p.variant & 1) ? launch<TT, 40, 2, 1, LAZY>(p, stream) : launch<TT, 40, 4, 1, LAZY>(p, stream);
         case 80: return launch<TT, 80, 2, 1, LAZY>(p, stream);
         case 160: return launch<TT, 160, 1, 1, LAZY>(p, stream);
         default: return VF_ERR_SHAPE;
     }
 }
 
+// variant bit 2 (value 4): dh = 40 on the 32 x 32 x 16 form (W32; A/B only: measured 4 % / 18 % SLOWER than the 16 x 16 forms,
+// plain / shared-score -- profiles/r03_d_attention_w32_ab.txt).
 // variant bit 0: 2 query tiles per wave at dh = 40 (A/B); bit 1: the exact-scale softmax (scale applied to the fp32 scores
 // instead of folded into q: one more VALU op per score, one fp16 rounding of q less)
 template <class TT>
