@@ -129,3 +129,20 @@ def test_return_flow_has_the_references_interface(sd):
     tf.set_flow_model(model)
     assert torch.equal(tf.return_flow(video)[0], flows[0])
     tf.set_flow_model(None)
+
+
+def test_flow_bf16_compute_and_input_validation(sd):
+    """bf16 operands (3 fewer mantissa bits: a looser bound), and the shapes the engine refuses."""
+    from vface_amd import hip
+    from vface_amd.raft import RaftEngine
+    eng16 = RaftEngine(sd, torch.bfloat16, DEV)
+    img = synth.synth_normal("raft.flow.img", (3, 3, 128, 128)).clamp(-1, 1)
+    ref = oraft.raft_forward(sd, img[1:], img[:-1], 3)
+    up = eng16.flow(img[1:].to(DEV), img[:-1].to(DEV), 3)
+    assert torch.isfinite(up).all() and rel_l2(up.cpu(), ref) < 5e-2
+    with pytest.raises(hip.VFaceHipError):
+        eng16.flow(img[1:, :, :64, :64].to(DEV), img[:-1, :, :64, :64].to(DEV), 1)      # below 128 x 128
+    with pytest.raises(hip.VFaceHipError):
+        eng16.flow(img[1:, :, :, :124].to(DEV), img[:-1, :, :, :124].to(DEV), 1)       # not a multiple of 8
+    with pytest.raises(hip.VFaceHipError):
+        eng16.flow(img[1:], img[:-1], 1)                                                # host tensors
