@@ -99,6 +99,35 @@ def gemm_case(spec):
     ab(f"gemm {spec}", run, flops=2.0 * M * N * K)
 
 
+def conv_case(spec):
+    """conv:<cin>x<cout>x<H>[:res32] -- 3x3 stride-1 convolution of 24 H x H images (bias; optional fp32 residual stream)."""
+    from vface_amd import packing
+    parts = spec.split(":")
+    cin, cout, H = (int(v) for v in parts[0].split("x"))
+    res32 = "res32" in parts[1:]
+    N = 24
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = (torch.randn(N * H * H, cin, device=DEV, generator=g) * 0.5).half()
+    w = packing.pack_conv3x3(torch.randn(cout, cin, 3, 3, generator=torch.Generator().manual_seed(4)) * (9 * cin) ** -0.5).half().to(DEV)
+    bias = torch.randn(cout, device=DEV, generator=g)
+    out = torch.empty(N * H * H, cout, dtype=torch.float16, device=DEV)
+    kw = dict(nimg=N, H=H, W=H, cin=cin, cout=cout, ldx=cin, ldy=cout, bias=bias)
+    if res32:
+        r32 = torch.randn(N * H * H, cout, device=DEV, generator=g)
+        o32 = torch.empty(N * H * H, cout, device=DEV)
+        kw.update(residual32=r32, out32=o32)
+    run = lambda: hip.conv3x3(x, w, out, **kw)
+    ab(f"conv3x3 {spec}", run, flops=2.0 * N * H * H * cout * 9 * cin)
+    outs = {}
+    for k in LIBS:
+        use(k); out.zero_(); run(); torch.cuda.synchronize()
+        outs[k] = out.clone()
+    ks = list(LIBS)
+    d = (outs[ks[0]].float() - outs[ks[1]].float())
+    print(f"    outputs bit-identical across builds: {torch.equal(outs[ks[0]], outs[ks[1]])}; rel-L2 of the difference {(d.norm() / outs[ks[0]].float().norm()).item():.2e}; "
+          f"elements that differ {(d != 0).float().mean().item():.2e}")
+
+
 if __name__ == "__main__":
     LIBS["base"], LIBS["new"] = bind(sys.argv[1]), bind(sys.argv[2])
     for what in sys.argv[3:] or ["attn40", "attn40s3", "attn80", "attn160"]:
@@ -109,4 +138,5 @@ if __name__ == "__main__":
         elif what == "attn80": attn_case(80, 1024, 24)
         elif what == "attn160": attn_case(160, 256, 24)
         elif what.startswith("gemm:"): gemm_case(what[5:])
+        elif what.startswith("conv:"): conv_case(what[5:])
         else: raise SystemExit(f"unknown case {what}")
