@@ -61,8 +61,12 @@ constexpr int v_pitch_bytes32(int dvp) {
 // columns become two tiles of 32).  MEASURED SLOWER (690 vs 660 us plain, 457 vs 388 us shared-score): the pipe time it adds
 // costs more than the issue slots it returns -- the two co-resident workgroups' matrix and vector phases do not overlap as
 // freely as that budget assumed.  Kept behind variant bit 2 as a tested A/B form, never chosen by the dispatcher.
-template <class TT, int DH, int QT, int G, bool LAZY, bool W32 = false>
-__global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
+// NWV: waves per workgroup, 4 or 8: eight waves share one staged K / V block, so a wave issues half the LDS-DMA pieces per block
+// and the K / V stream through L2 halves, for a barrier across eight waves instead of four.  Measured: nothing for the plain dh = 40
+// kernel (665 vs 665 us; variant bit 3 selects it there), -5 % for the shared-score form, which takes it by default.
+template <class TT, int DH, int QT, int G, bool LAZY, bool W32 = false, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
+    constexpr int NTH = 64 * NWV;
     using E = typename TT::elem;
     using V8 = typename TT::v8;
     using V4 = typename TT::v4;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     // reads per launch at n = 4096, dh = 40 against 0.19 GB of q, k, v).
     int b, h, qtile;
     {
-        const int gx = (p.n + 64 * QT - 1) / (64 * QT);
+        const int gx = (p.n + 16 * NWV * QT - 1) / (16 * NWV * QT);
         const int nwg = gridDim.x, id = blockIdx.x;
         const int q = nwg >> 3, r = nwg & 7, xcd = id & 7, loc = id >> 3;
         const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         h = bh % p.heads;
         b = bh / p.heads;
     }
-    const int q0 = qtile * (64 * QT) + wave * (16 * QT);
+    const int q0 = qtile * (16 * NWV * QT) + wave * (16 * QT);
     const int bqk = p.qk_map ? p.qk_map[b] : b;
     const int gs = p.set_stride;                     // output / value sample of set g: b + g*gs
     const E* Qg = reinterpret_cast<const E*>(p.Q) + (long)bqk * p.bsq + h * DH;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     {
         uint4* z = reinterpret_cast<uint4*>(smem_raw);
         constexpr int total16 = (2 * KVB * KROW + 2 * KVB * VROW) * 2 / 16;
-        for (int i = t; i < total16; i += 256) z[i] = make_uint4(0, 0, 0, 0);
+        for (int i = t; i < total16; i += NTH) z[i] = make_uint4(0, 0, 0, 0);
     }
     if (ONES) {
         __syncthreads();
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     // swizzle is applied on the SOURCE chunk index.  V slots past the value columns are masked out, so the ones column
     // and the zero padding written once at kernel start survive.
     constexpr int SK = KROW / 8, SV = VROW / 8;            // 16-B slots per K / V row
-    constexpr int RK = (KVB * SK + 255) / 256, RV = (KVB * SV + 255) / 256;
+    constexpr int RK = (KVB * SK + NTH - 1) / NTH, RV = (KVB * SV + NTH - 1) / NTH;
     constexpr unsigned OOB = 0xFFFFFFF0u;
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.K), 0, (int)p.k_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.V), 0, (int)p.v_bytes, 0x00020000);
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     bool vact[RV];
 #pragma unroll
     for (int r = 0; r < RK; ++r) {
-        const int id = r * 256 + t;
+        const int id = r * NTH + t;
         const int row = id / SK, sl = id - row * SK;
         int c = sl;
         if (KROW == 64) c = sl ^ ((row >> 1) & 7);
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     }
 #pragma unroll
     for (int r = 0; r < RV; ++r) {
-        const int id = r * 256 + t;
+        const int id = r * NTH + t;
         const int row = id / SV, sl = id - row * SV;
         const int g = sl / CPR, c = sl - g * CPR;
         vrow[r] = row;
@@ -198,16 +202,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
         const int r0 = kb * KVB;
 #pragma unroll
         for (int r = 0; r < RK; ++r) {
-            if (r * 256 + wave * 64 < KVB * SK) {          // wave-uniform: this instruction has slots to fill
+            if (r * NTH + wave * 64 < KVB * SK) {          // wave-uniform: this instruction has slots to fill
                 const unsigned off = (koff[r] != OOB && r0 + krow[r] < nk) ? koff[r] + (unsigned)kb * kstep : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, LDS_PTR(dK + (r * 256 + wave * 64) * 8), 16, off, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, LDS_PTR(dK + (r * NTH + wave * 64) * 8), 16, off, 0, 0, 0);
             }
         }
 #pragma unroll
         for (int r = 0; r < RV; ++r) {
-            if (r * 256 + wave * 64 < KVB * SV) {
+            if (r * NTH + wave * 64 < KVB * SV) {
                 const unsigned off = (r0 + vrow[r] < nk) ? voff[r] + (unsigned)kb * vstep : OOB;
-                if (vact[r]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, LDS_PTR(dV + (r * 256 + wave * 64) * 8), 16, off, 0, 0, 0);
+                if (vact[r]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, LDS_PTR(dV + (r * NTH + wave * 64) * 8), 16, off, 0, 0, 0);
             }
         }
     };
@@ -575,16 +579,16 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(AttnParams p) {
     }
 }
 
-template <class TT, int DH, int QT, int G = 1, bool LAZY = false, bool W32 = false>
+template <class TT, int DH, int QT, int G = 1, bool LAZY = false, bool W32 = false, int NWV = 4>
 int launch(const AttnParams& p, hipStream_t stream) {
     constexpr int DKP = (DH / 32) * 32 + ((DH % 32) ? 16 : 0), DVP = W32 ? round_up(G * DH + 1, 32) : round_up(G * DH, 16);
     constexpr int KROW = k_row_elems(DKP), VROW = (W32 ? v_pitch_bytes32(DVP) : v_pitch_bytes(DVP)) / 2;
     constexpr size_t lds = (size_t)(2 * KVB * KROW + 2 * KVB * VROW) * 2;
-    auto kern = attn_kernel<TT, DH, QT, G, LAZY, W32>;
+    auto kern = attn_kernel<TT, DH, QT, G, LAZY, W32, NWV>;
     static VfOncePerDevice attr_set;
     if (lds > 64 * 1024 && !attr_set.set_lds(reinterpret_cast<const void*>(kern), (int)lds)) return VF_ERR_LAUNCH;
-    dim3 grid(((p.n + 64 * QT - 1) / (64 * QT)) * p.heads * p.B);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    dim3 grid(((p.n + 16 * NWV * QT - 1) / (16 * NWV * QT)) * p.heads * p.B);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * NWV), lds, stream, p);
     return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
 }
 
@@ -604,7 +608,11 @@ int dispatch_l(const AttnParams& p, hipStream_t stream) {
             case 8: return launch<TT, 8, 2, 3, LAZY>(p, stream);
             case 16: return launch<TT, 16, 2, 3, LAZY>(p, stream);
             case 32: return launch<TT, 32, 2, 3, LAZY>(p, stream);
-            case 40: return (LAZY && (p.variant & 4)) ? launch<TT, 40, 2, 3, LAZY, LAZY>(p, stream) : launch<TT, 40, 2, 3, LAZY>(p, stream);
+            case 40:
+                // eight waves per workgroup by default for the shared-score form (one staged K / V block serves 512 queries:
+                // 403 -> 381 us at F = 8, bit-identical -- profiles/r03_g_attention_8wave_ab.txt); variant bit 3: four (A/B)
+                if (LAZY && (p.variant & 4)) return launch<TT, 40, 2, 3, LAZY, LAZY>(p, stream);
+                return (p.variant & 8) ? launch<TT, 40, 2, 3, LAZY>(p, stream) : launch<TT, 40, 2, 3, LAZY, false, 8>(p, stream);
             default: return VF_ERR_SHAPE;
         }
     }
@@ -614,6 +622,7 @@ int dispatch_l(const AttnParams& p, hipStream_t stream) {
         case 32: return launch<TT, 32, 2, 1, LAZY>(p, stream);
         case 40:
             if (LAZY && (p.variant & 5) == 4) return launch<TT, 40, 4, 1, LAZY, LAZY>(p, stream);      // A/B: the 32 x 32 x 16 form
+            if (p.variant & 8) return launch<TT, 40, 4, 1, LAZY, false, 8>(p, stream);                 // A/B: eight waves per workgroup
             return (p.variant & 1) ? launch<TT, 40, 2, 1, LAZY>(p, stream) : launch<TT, 40, 4, 1, LAZY>(p, stream);
         case 80: return launch<TT, 80, 2, 1, LAZY>(p, stream);
         case 160: return launch<TT, 160, 1, 1, LAZY>(p, stream);
