@@ -135,7 +135,7 @@ if __name__ == "__main__":
         what = what.split(":v")[0]
         if what == "attn40": attn_case(40, 4096, 24, variant=var)
         elif what == "attn40s3": attn_case(40, 4096, 8, sets=3, variant=var)
-        elif what == "attn80": attn_case(80, 1024, 24)
+        elif what == "attn80": attn_case(80, 1024, 24, variant=var)
         elif what == "attn160": attn_case(160, 256, 24)
         elif what.startswith("gemm:"): gemm_case(what[5:])
         elif what.startswith("conv:"): conv_case(what[5:])
