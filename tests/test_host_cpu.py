@@ -200,9 +200,12 @@ def test_lightning_style_checkpoint_loads_with_and_without_vae(tmp_path):
                     "hyper_parameters": ModelCheckpoint()}, path)
     finally:
         del sys.modules[fake.__name__]
+    # no silent fallback from the weights-only loader: the Lightning layout needs the explicit flag
+    with pytest.raises(RuntimeError, match="ckpt_stub_unknown_globals"):
+        load_checkpoint(LatentDiffusion(ucfg), path)
     for with_vae in (False, True):
         dst = LatentDiffusion(ucfg, first_stage_config=vcfg if with_vae else None)
-        msg = load_checkpoint(dst, path, with_vae=with_vae)
+        msg = load_checkpoint(dst, path, with_vae=with_vae, stub_unknown_globals=True)
         assert "matched every parameter" in msg
         for k, v in dst.state_dict().items():
             assert torch.equal(v, sd[k]), k
@@ -214,6 +217,48 @@ def test_lightning_style_checkpoint_loads_with_and_without_vae(tmp_path):
     torch.save({"state_dict": {"something.else": torch.zeros(1)}}, path)
     with pytest.raises(RuntimeError, match="not an LDM checkpoint"):
         load_checkpoint(LatentDiffusion(ucfg), path)
+
+
+def test_stub_unpickler_never_calls_a_global_outside_the_allow_list(tmp_path, monkeypatch):
+    """the placeholder unpickler used for Lightning checkpoints must resolve EXACT (module, name) pairs of
+    torch's weights-only allow-list and nothing else -- a pickle that names ``torch.utils.collect_env.run``, ``os.system``,
+    ``builtins.eval``, ``torch.hub.load`` or ``numpy.load`` gets an inert placeholder, and nothing runs."""
+    import os as _os
+    import pickle
+    import torch.utils.collect_env as ce
+    from vface_amd.scripts.VFace_inference_batch import _StubUnpickler
+    called = []
+    monkeypatch.setattr(ce, "run", lambda *a, **k: called.append(("collect_env.run", a)) or (0, "", ""))
+    monkeypatch.setattr(_os, "system", lambda *a, **k: called.append(("os.system", a)) or 0)
+    marker = tmp_path / "pwned"
+    hostile = [
+        b"ctorch.utils.collect_env\nrun\n(Vtouch " + str(marker).encode() + b"\ntR.",      # the advisor's demonstration
+        b"cos\nsystem\n(Vtouch " + str(marker).encode() + b"\ntR.",
+        b"cposix\nsystem\n(Vtouch " + str(marker).encode() + b"\ntR.",
+        b"cbuiltins\neval\n(V__import__('os').system('touch " + str(marker).encode() + b"')\ntR.",
+        b"cbuiltins\nexec\n(Vimport os\ntR.",
+        b"ctorch.hub\nload\n(Vx\nVy\ntR.",
+        b"cnumpy\nload\n(V/etc/passwd\ntR.",
+        b"ctorch.utils.cpp_extension\nload\n(Vx\n(lp0\ntR.",
+        b"csubprocess\ncheck_output\n((Vtouch\nV" + str(marker).encode() + b"\nltR.",
+    ]
+    for payload in hostile:
+        obj = _StubUnpickler.loads(payload)
+        assert type(obj) in _StubUnpickler.Unpickler._stubs.values(), payload       # an inert placeholder instance
+    assert not called and not marker.exists()
+    # what a checkpoint legitimately holds still loads: tensors, OrderedDict, numpy scalars, torch.Size, dtypes
+    import collections
+    import numpy as np
+    good = {"sd": collections.OrderedDict(w=torch.arange(6.).reshape(2, 3)), "step": np.int64(7), "shape": torch.Size([2, 3]),
+            "dt": torch.float16}
+    path = str(tmp_path / "ok.ckpt")
+    torch.save(good, path)
+    back = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_StubUnpickler)
+    assert torch.equal(back["sd"]["w"], good["sd"]["w"]) and back["shape"] == good["shape"] and back["dt"] is torch.float16
+    assert int(back["step"]) == 7
+    # every name the unpickler resolves for real is on torch's list or the six numpy reconstructors: no package-wide rule
+    assert "torch.utils.collect_env.run" not in _StubUnpickler.allowed() and "builtins.eval" not in _StubUnpickler.allowed()
+    assert pickle  # (imported for the payload format above)
 
 
 def _bench_module():

@@ -49,6 +49,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--from-file", type=str, default=None)
     p.add_argument("--config", type=str, default=None, help="project_ffhq.yaml (UNet hyper-parameters)")
     p.add_argument("--ckpt", type=str, default=None, help="last.ckpt; its model.diffusion_model.* keys are loaded")
+    p.add_argument("--ckpt_stub_unknown_globals", action="store_true",
+                   help="read a pytorch_lightning last.ckpt whose non-tensor entries (callbacks, hyper_parameters) the "
+                        "weights-only loader rejects: tensors through torch's own allow-list, every other pickled global as an "
+                        "inert placeholder (nothing outside the allow-list is ever called)")
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--rank", type=int, default=0)
     p.add_argument("--precision", type=str, choices=["full", "autocast"], default="autocast")
@@ -99,17 +103,37 @@ class _StubUnpickler:
     """``pickle_module`` for ``torch.load`` of a checkpoint written by the reference's pytorch_lightning==1.4.2
     (``REFace/environment.yml``): its ``callbacks`` / ``hyper_parameters`` entries pickle CLASS objects (the ModelCheckpoint
     class as a dict key) and omegaconf containers, which ``weights_only=True`` rejects and which are not importable here.
-    Tensors, storages and plain containers unpickle as usual; every other global becomes an inert placeholder class -- no
-    foreign constructor or ``__setstate__`` ever runs, so this is as safe as ``weights_only`` and strictly more tolerant."""
+
+    ``find_class`` resolves EXACTLY the (module, name) pairs of torch's own ``weights_only`` allow-list
+    (``torch._weights_only_unpickler._get_allowed_globals``: the ``_rebuild_*`` helpers, storages, dtypes, ``torch.Size``,
+    ``collections.OrderedDict`` ..) plus the numpy scalar / dtype reconstructors -- never a whole package: every other global,
+    including every other ``torch.*`` / ``numpy.*`` / ``builtins`` name (``torch.utils.collect_env.run``, ``torch.hub.load``,
+    ``numpy.load``, ``os.system`` ..), becomes an inert placeholder class whose construction, call and ``__setstate__`` do
+    nothing.  No callable outside the allow-list is ever invoked (``tests/test_host_cpu.py`` feeds it hostile pickles).
+    It is used only when the caller asks for it (``load_checkpoint(.., stub_unknown_globals=True)`` /
+    ``--ckpt_stub_unknown_globals``), never as a silent fallback."""
     import pickle as _pickle
+
+    _NUMPY_OK = frozenset({("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+                           ("numpy", "dtype"), ("numpy.core.multiarray", "_reconstruct"),
+                           ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray")})
+    _allowed = None
+
+    @classmethod
+    def allowed(cls) -> dict:
+        if cls._allowed is None:
+            from torch._weights_only_unpickler import _get_allowed_globals
+            cls._allowed = dict(_get_allowed_globals())
+        return cls._allowed
 
     class Unpickler(_pickle.Unpickler):
         _stubs: dict = {}
 
         def find_class(self, module, name):
-            root = module.split(".")[0]
-            if root in ("torch", "collections", "builtins", "numpy", "_codecs") and not (root == "builtins" and name in (
-                    "eval", "exec", "compile", "open", "__import__", "getattr", "setattr", "delattr", "input", "breakpoint")):
+            hit = _StubUnpickler.allowed().get(f"{module}.{name}")
+            if hit is not None:
+                return hit
+            if (module, name) in _StubUnpickler._NUMPY_OK:
                 return super().find_class(module, name)
             key = (module, name)
             if key not in self._stubs:
@@ -133,19 +157,30 @@ class _StubUnpickler:
     __name__ = "vface_stub_pickle"
 
 
-def load_checkpoint(model, path: str, with_vae: bool = False) -> str:
+def load_checkpoint(model, path: str, with_vae: bool = False, stub_unknown_globals: bool = False) -> str:
     """Load ``last.ckpt`` of the reference (``VFace_inference_batch.py:118-135``: ``torch.load`` -> ``["state_dict"]`` ->
     ``load_state_dict(strict=False)``) into ``model``.  Only the keys of what this build runs are taken:
     ``model.diffusion_model.*`` always, ``first_stage_model.*`` when the first stage was built (``with_vae``); the CLIP /
     ArcFace / landmark conditioning weights of a full LDM checkpoint are outside the path and ignored.  Unlike the reference's
     non-strict load, a checkpoint that does not cover every parameter of the path raises instead of silently running on
-    default-initialised weights."""
+    default-initialised weights.
+
+    The load is ``weights_only=True``.  A pytorch_lightning checkpoint carries class-keyed callback state that the safe loader
+    rejects: pass ``stub_unknown_globals=True`` (``--ckpt_stub_unknown_globals``) to read it through ``_StubUnpickler`` (exact
+    allow-list, inert placeholders for everything else).  There is no automatic fallback: a file that fails the safe loader
+    raises, naming the flag."""
     import pickle
-    try:
-        ck = torch.load(path, map_location="cpu", weights_only=True)
-    except pickle.UnpicklingError:
-        # Lightning checkpoints carry class-keyed callback state: retry with placeholders for every non-tensor global
+    if stub_unknown_globals:
         ck = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_StubUnpickler)
+    else:
+        try:
+            ck = torch.load(path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError as e:
+            raise RuntimeError(
+                f"{path}: the weights-only loader rejected this checkpoint ({str(e).splitlines()[0][:200]}).  If it is a "
+                "pytorch_lightning checkpoint (callbacks / hyper_parameters pickle class objects), pass "
+                "--ckpt_stub_unknown_globals (load_checkpoint(.., stub_unknown_globals=True)): tensors load through torch's own "
+                "allow-list and every other global becomes an inert placeholder") from e
     sd = ck.get("state_dict", ck) if isinstance(ck, dict) else ck
     prefixes = ("model.diffusion_model.",) + (("first_stage_model.",) if with_vae else ())
     taken = {k: v for k, v in sd.items() if k.startswith(prefixes) and torch.is_tensor(v)}
@@ -188,7 +223,7 @@ def run_synthetic(opt) -> dict:
     else:
         model = LatentDiffusion(cfg)
     if opt.ckpt:
-        print(load_checkpoint(model, opt.ckpt, with_vae=opt.with_vae))
+        print(load_checkpoint(model, opt.ckpt, with_vae=opt.with_vae, stub_unknown_globals=opt.ckpt_stub_unknown_globals))
     else:
         synth.fill_module_(model.unet, seed=0)
         if opt.with_vae:
