@@ -15,7 +15,10 @@ boundary exchange runs over RCCL.
 With --gpus N > 1 the defaults change to what north_star asks the multi-GPU run to measure: the shipped hook
 schedule (`--fusion flow_fix`) at BASELINE config 4's per-GPU share (16 frames per GPU), so the one-neighbour halo
 exchange over RCCL is inside the timed region, and the line carries `exchange: {mode, bytes_per_step,
-wait_ms_per_step}`.
+wait_ms_per_step}`, `ranks_seen` (an all-reduce of 1 over the group) and `scaling_anchor`: the like-for-like
+single-GPU figure of that workload is `python bench.py --gpus 1 --fusion flow_fix --frames 16` (= extra[1] of the
+default N = 1 line), not the default N = 1 `value` (configs[1]: replace, 8 frames).  Every wait on a peer is bounded
+(VFACE_EXCHANGE_TIMEOUT_S, default 120 s): a rank whose neighbour never sends exits non-zero naming it.
 
 Also reported on the same JSON line:
   roofline     -- the kernel family with the largest share of the step (by HIP events on the launch stream around
@@ -329,15 +332,22 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    dist, backend = None, None
+    dist, backend, ranks_seen = None, None, 1
     if world > 1:
         import torch.distributed as dist
+        # every collective / point-to-point wait of the run is bounded (VFACE_EXCHANGE_TIMEOUT_S, default 120 s): under RCCL the
+        # process group's watchdog aborts a rank whose peer never shows up, under gloo FrameShard's waits raise ExchangeTimeout
+        from vface_amd.parallel import process_group_timeout
         if rehearse:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=process_group_timeout())
         else:
-            dist.init_process_group("nccl", device_id=dev)   # "nccl" IS RCCL on ROCm
+            dist.init_process_group("nccl", device_id=dev, timeout=process_group_timeout())   # "nccl" IS RCCL on ROCm
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
         backend = dist.get_backend()
+        one = torch.ones(1, dtype=torch.int32, device="cpu" if rehearse else dev)
+        dist.all_reduce(one)                       # every rank really is in the group: reported as `ranks_seen`
+        ranks_seen = int(one.item())
+        assert ranks_seen == a.gpus, (ranks_seen, a.gpus)
 
     from vface_amd import hip
     from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler, HookPlan
@@ -579,6 +589,13 @@ def main():
                        # swapped frame; at the 2.5 PFLOP/s dense peak that alone would allow 103.6 frames/s per GPU
                        "attention_gemm_roofline_frac": (fps / world) * 24.135e12 / (MFMA_PEAK_TFLOPS * 1e12) if h == 64 else None},
             "exchange": r["exchange"],
+            "ranks_seen": ranks_seen,
+            # the like-for-like single-GPU figure of an N > 1 line: the N = 1 DEFAULT is BASELINE configs[1] (8 frames, replace),
+            # the N > 1 default the shipped schedule at config 4's share (16 frames per GPU, flow_fix)
+            "scaling_anchor": None if world == 1 else (
+                f"N=1 anchor of this workload: `python bench.py --gpus 1 --fusion {a.fusion} --frames {F_}` (also reported by the "
+                f"default N=1 run as extra[1] when fusion=flow_fix, frames=16); the default N=1 `value` is configs[1] "
+                f"(replace, 8 frames) and is NOT the same workload"),
             "inversion": None if inv_ms is None else {
                 "ms_per_step": inv_ms, "steps_timed": a.inv_steps,
                 "note": "DDIM inversion step (hooks off, batch 2F, no guidance), outside the timed region; `value` is "
@@ -616,4 +633,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as ex:
+        from vface_amd.parallel import ExchangeTimeout
+        if isinstance(ex, ExchangeTimeout):
+            # a peer never showed up: say which, and leave with a non-zero code NOW (destroy_process_group would wait for it too)
+            print(f"[bench] FATAL rank {os.environ.get('RANK', 0)}: {ex}", file=sys.stderr, flush=True)
+            os._exit(3)
+        raise

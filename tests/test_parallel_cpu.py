@@ -75,3 +75,89 @@ def test_halo_exchange_gloo_world2(mode):
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+def _spawn(target, world, *args, timeout=120):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    import tempfile
+    store = os.path.join(tempfile.mkdtemp(prefix="vface_rdzv_"), "store")
+    procs = [ctx.Process(target=target, args=(r, world, store, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout)
+    return procs, q
+
+
+def _silent_peer_worker(rank, world, store, q):
+    """Rank 0 never takes part in the exchange; rank 1 must give up within the bound and exit non-zero, naming rank 0."""
+    import sys
+    import time
+    import torch.distributed as dist
+    from vface_amd.parallel import ExchangeTimeout
+    os.environ["VFACE_EXCHANGE_TIMEOUT_S"] = "2"
+    dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world)
+    sh = FrameShard(rank, world, 4, dist)
+    if rank == 0:
+        time.sleep(6)            # alive, but never sends
+        q.put((0, "slept"))
+        q.close(); q.join_thread()
+        os._exit(0)              # (no destroy_process_group: the peer is gone by now)
+    t0 = time.monotonic()
+    try:
+        sh.finish_exchange(sh.start_exchange(torch.zeros(16, 8)))
+    except ExchangeTimeout as e:
+        q.put((1, str(e), time.monotonic() - t0))
+        q.close(); q.join_thread()
+        os._exit(3)
+    q.put((1, "no timeout", 0.0))
+    q.close(); q.join_thread()
+    os._exit(0)
+
+
+def test_peer_that_never_sends_times_out_with_nonzero_exit():
+    """``finish_exchange`` is bounded; a rank whose predecessor never sends raises ``ExchangeTimeout``
+    (message names the peer) and its process exits non-zero instead of sitting in ``wait()`` until the driver's limit."""
+    procs, q = _spawn(_silent_peer_worker, 2, timeout=60)
+    msgs = dict((m[0], m[1:]) for m in (q.get(timeout=5) for _ in range(2)))
+    assert procs[1].exitcode == 3 and procs[0].exitcode == 0
+    text, waited = msgs[1]
+    assert "rank 0" in text and "did not complete within 2 s" in text and waited < 10
+
+
+def _capture_failure_worker(rank, world, store, q):
+    """The collective capture decision (engine._capture) rehearsed on its protocol: a forward makes 2
+    exchanges; rank 0's "capture pass" dies after the first exchange was STARTED.  It must finish that one, drain the second
+    with a dummy slab, and both ranks must reach the same verdict -- after which a further (eager) forward still pairs."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"file://{store}", rank=rank, world_size=world)
+    try:
+        sh = FrameShard(rank, world, 4, dist)
+        slab = lambda v: torch.full((8, 4), float(v))
+        got = []
+        ok = True
+        if rank == 0:
+            h = sh.start_exchange(slab(10))              # exchange 1 of the capture pass: started ..
+            ok = False                                   # .. then the capture raises on this rank
+            sh.drain(h, [slab(-1)])                      # finish the pending one, pair the remaining one with a dummy
+        else:
+            for i in range(2):
+                got.append(sh.finish_exchange(sh.start_exchange(slab(20 + i))))
+        all_ok, over = sh.agree(ok, False)
+        # one decision everywhere: nobody replays a graph; the next forward (eager, 2 exchanges) still pairs up
+        for i in range(2):
+            got.append(sh.finish_exchange(sh.start_exchange(slab(100 * (rank + 1) + i))))
+        vals = [None if g is None else float(g[0, 0]) for g in got]
+        q.put((rank, all_ok, over, vals))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_capture_failure_on_one_rank_is_one_decision_for_all():
+    procs, q = _spawn(_capture_failure_worker, 2)
+    assert [p.exitcode for p in procs] == [0, 0]
+    res = {m[0]: m[1:] for m in (q.get(timeout=5) for _ in range(2))}
+    assert res[0][0] is False and res[1][0] is False and not res[0][1] and not res[1][1]
+    assert res[0][2] == [None, None]                        # rank 0 receives nothing
+    assert res[1][2] == [10.0, -1.0, 100.0, 101.0]          # rank 1: the real slab, the dummy, then the eager forward's two

@@ -219,3 +219,74 @@ def test_segmented_hipgraph_replay_of_sharded_forward_equals_unsharded():
     finally:
         eng.use_graph, eng._graphs = old
         eng.halo_exchange = None
+
+
+@pytest.mark.parametrize("where", ["warmup_done", "mid"])
+def test_capture_failure_on_one_shard_keeps_exchanges_paired_and_results_exact(where, monkeypatch):
+    """a hipGraph capture that fails on ONE shard must not desynchronise the clip.  The failing shard
+    finishes the exchanges its aborted capture pass owed (``FrameShard.drain``: the pending one, then dummies for the rest),
+    takes the collective verdict (``agree``), returns the WARM-UP forward's eps for the capturing call -- no further exchanging
+    forward -- and runs kernel by kernel afterwards.  Checked with the loop-back exchange: every call of every shard equals the
+    unsharded run bit for bit, and shard 1 has made exactly as many exchange calls as a shard whose capture succeeded
+    (warm-up 2 + capture pass 2) on the capturing call."""
+    import warnings
+    from vface_amd import hip
+    from vface_amd.engine import Act
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler
+    from vface_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from vface_amd.ldm.models.pnp_utils import register_spa_attn_injection as reg
+    from vface_amd.parallel import LoopbackShard
+    from vface_amd.utils import synth
+    dev = "cuda:0"
+    total, world, h, w = 4, 2, 32, 32
+    ldm = LatentDiffusion(_cfg())
+    synth.fill_module_(ldm.unet, seed=0)
+    ldm = ldm.to(dev)
+    sampler = DDIMSampler(ldm)
+    sampler.flow_gate = "flow_hw"
+    gflow = synth.synth_flow(total - 1, h, w)
+    eng = ldm.unet.engine
+    keep = {}
+
+    def step(shard, graph):
+        x, ctx = _shard_inputs(total, h, w, shard.first, shard.count, dev)
+        tt = torch.full((3 * shard.count,), 481, dtype=torch.long, device=dev)
+        shard.install(eng, gflow, dev)
+        key = ("flows", shard.rank, shard.world)
+        if key not in keep:
+            keep[key] = [f[None].to(dev) for f in shard.local_flow(gflow)]
+        reg(sampler, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True)
+        reg(sampler, 1, switch_on=True, input_blocks=True, middle_block=False, output_blocks=False, chunks=3,
+            flow=keep[key], block_indices=list(range(9)), fusion="flow_fix", split_ratio_fft=0.8, alpha=0.8)
+        N, C, H, W = x.shape
+        cpad = (C + 7) // 8 * 8
+        xin = torch.empty(N * H * W, cpad, dtype=eng.dtype, device=dev)
+        hip.nchw_to_nhwc(x.float().contiguous(), xin, N=N, C_=C, hw=H * W, cpad=cpad)
+        eng.use_graph = graph
+        shard.begin_forward()
+        return eng.step_forward_nhwc(Act(xin, N, H, W), tt, ctx).clone().reshape(N, H * W, -1)
+
+    old = eng.use_graph, eng._graphs, set(eng._graph_failed)
+    try:
+        eng._graphs = {}
+        full = step(LoopbackShard(0, 1, total, {}), False)
+        store = {}
+        shards = [LoopbackShard(r, world, total, store) for r in range(world)]
+        for call in range(2):
+            for sh in shards:
+                if sh.rank == 1 and call == 0:
+                    monkeypatch.setenv("VFACE_TEST_FAIL_CAPTURE", where)
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    out = step(sh, True)
+                monkeypatch.delenv("VFACE_TEST_FAIL_CAPTURE", raising=False)
+                ref = torch.cat([full[c * total + sh.first:c * total + sh.first + sh.count] for c in range(3)])
+                assert torch.equal(out, ref), f"call {call} rank {sh.rank}: max diff {(out - ref).abs().max().item():.3e}"
+                if call == 0:
+                    # warm-up 2 + capture pass 2 (+ first replay 2 where the capture succeeded)
+                    assert len(store[sh.rank]) == (6 if sh.rank == 0 else 4), (sh.rank, len(store[sh.rank]))
+        assert len(eng._graph_failed) == 1 and len(eng._graphs) == 1
+    finally:
+        eng.use_graph, eng._graphs = old[0], old[1]
+        eng._graph_failed.clear(); eng._graph_failed.update(old[2])
+        eng.halo_exchange = None

@@ -278,6 +278,8 @@ class _GraphSegments:
         self.segments: list = []      # [(CUDAGraph, host_op | None)]
         self.keep: list = []          # tensors the host ops refer to
         self.cur = None
+        self.n_started = 0            # exchanges the capture pass has started for real ..
+        self.pending = None           # .. and the state dict of one that was started and not yet finished
         # what the engine reads from its exchange object
         if inner is not None:
             self.rank, self.world, self.first, self.count = inner.rank, inner.world, inner.first, inner.count
@@ -310,12 +312,16 @@ class _GraphSegments:
             state["h"] = inner.start_exchange(tail, recv=recv)
         self.end(op)
         op()                       # the capture pass exchanges for real too (garbage slabs): the ranks' calls stay paired
+        self.n_started += 1
+        self.pending = state
         self.begin()
         return (state, recv)
 
     def finish_exchange(self, handle):
         state, recv = handle
         inner, eng = self.inner, self.engine
+        if os.environ.get("VFACE_TEST_FAIL_CAPTURE") == "mid":      # (test hook: die with one exchange started, not finished)
+            raise RuntimeError("injected capture failure (VFACE_TEST_FAIL_CAPTURE)")
 
         def op():
             ev = eng.exchange_events
@@ -330,8 +336,25 @@ class _GraphSegments:
                 ev.append((e0, e1))
         self.end(op)
         op()
+        self.pending = None
         self.begin()
         return recv
+
+
+class _CountingExchange:
+    """The frame-shard exchange seen by the warm-up forward of a capture: passes every call through and records the slabs a
+    forward sends (shapes only), so that a capture pass that dies half-way can finish its paired exchanges (``FrameShard.drain``)."""
+
+    def __init__(self, inner):
+        self.inner, self.tails = inner, []
+        self.rank, self.world, self.first, self.count = inner.rank, inner.world, inner.first, inner.count
+
+    def start_exchange(self, tail, recv=None):
+        self.tails.append(tail)
+        return self.inner.start_exchange(tail, recv=recv) if recv is not None else self.inner.start_exchange(tail)
+
+    def finish_exchange(self, handle):
+        return self.inner.finish_exchange(handle)
 
 
 class UNetEngine:
@@ -353,6 +376,7 @@ class UNetEngine:
         # norm3 + FeedForward of the level-0 transformer blocks (C = 320; also the 64- / 128-channel test models) as one
         # activation-stationary kernel (csrc/ffn.hip).  VFACE_FUSE_FFN=0: the three-kernel path (A/B switch).
         self.fuse_ffn = os.environ.get("VFACE_FUSE_FFN", "1") != "0"
+        self._ffn_supported: Dict[tuple, bool] = {}
         self.decompose_attn1 = False                   # bench.py's instrumented pass: vface_attn1_forward's launches call by call
         # fp32 residual stream: residual sums are carried between kernels in fp32, 16-bit copies exist only
         # where a matrix-core operand needs them.  VFACE_STREAM32=0 restores the all-16-bit activations (A/B switch).
@@ -476,7 +500,10 @@ class UNetEngine:
                                                   sd[t + ".attn1.to_v.weight"])),
                 "wo": self.pack_lin(sd, t + ".attn1.to_out.0"),
                 "ff1": {"w": self._w16(ffw), "b": self._f32(ffb)}, "ff2": self.pack_lin(sd, t + ".ff.net.2"),
-                "ff2p": self._w16(packing.pack_ffn_w2(cpu(t + ".ff.net.2.weight"))),   # fused FeedForward (csrc/ffn.hip)
+                # fused FeedForward (csrc/ffn.hip): ff.net[2] in the order GEMM 1's accumulators hand the hidden units over --
+                # packed only for the widths that kernel takes (a C = 1280 block would hold 13 MB of dead copy)
+                "ff2p": (self._w16(packing.pack_ffn_w2(cpu(t + ".ff.net.2.weight")))
+                         if self.fuse_ffn and hip.ffn_fused_width_supported(sd[t + ".norm1.weight"].shape[0]) else None),
                 "a2_out": self.pack_lin(sd, t + ".attn2.to_out.0"), "c": sd[t + ".norm1.weight"].shape[0],
                 "wlin": {}, "attn1_name": t + ".attn1",
                 "qk_src": (sd[t + ".attn1.to_q.weight"], sd[t + ".attn1.to_k.weight"])}
@@ -758,7 +785,7 @@ class UNetEngine:
         t1 = self._attn1(ln, t0, p, cfg, a2vec, N, n, attn1.heads, hw)
         t2 = self._new(M, c)
         t2_32 = self._new(M, c, torch.float32) if want32 else None
-        if self.fuse_ffn and t1.dtype == torch.float32 and hip.ffn_fused_supported(M, c):
+        if self.fuse_ffn and t1.dtype == torch.float32 and p["ff2p"] is not None and self._ffn_ok(M, c):
             # norm3 -> ff.net[0] (GEGLU) -> ff.net[2] -> + x in ONE launch (csrc/ffn.hip): the [M, 4c] hidden matrix never exists
             hip.ffn_fused(t1, p["ln3"][0], p["ln3"][1], p["ff1"]["w"], p["ff1"]["b"], p["ff2p"], p["ff2"]["b"], t2, M=M, C_=c,
                           out32=t2_32)
@@ -768,6 +795,14 @@ class UNetEngine:
         hip.gemm(ln, p["ff1"]["w"], ff, M=M, N=8 * c, K=c, lda=c, ldc=4 * c, bias=p["ff1"]["b"], flags=hip.EPI_GEGLU)
         self._gemm(ff, p["ff2"], t2, hw=n, out32=t2_32, **self._resid(t1))
         return (t2, t2_32) if want32 else t2
+
+    def _ffn_ok(self, M: int, c: int) -> bool:
+        """``vface_ffn_fused_supported`` per (rows, width), asked once (a ctypes call per block per forward otherwise)."""
+        key = (M, c)
+        ok = self._ffn_supported.get(key)
+        if ok is None:
+            ok = self._ffn_supported[key] = bool(hip.ffn_fused_supported(M, c))
+        return ok
 
     def _st(self, x: Act, p: dict, mod, a2_all: torch.Tensor, tgt) -> Act:
         """SpatialTransformer.forward + BasicTransformerBlock._forward (attention.py:278-289, 239-243).
@@ -926,8 +961,10 @@ class UNetEngine:
         A frame-sharded engine (``halo_exchange`` installed: RCCL point-to-point exchange inside the forward) is captured as
         graph SEGMENTS cut at the exchange calls -- [.. fused q|k of chunk 1] send/recv [projections it overlaps] wait
         [warp, attention, .. next hooked layer ..] -- with the two ``isend/irecv`` + ``wait`` pairs issued from the host between
-        segment replays (5 segments and 4 host calls per step instead of ~1200 launches).  Any capture failure runs the eager
-        path for that configuration."""
+        segment replays (5 segments and 4 host calls per step instead of ~1200 launches).  A capture failure (or a pool
+        over the byte budget) runs the eager path for that configuration -- decided ONCE for all ranks of a sharded clip
+        (``FrameShard.agree``), the failing rank first completing the exchanges its aborted pass owed its neighbours
+        (``FrameShard.drain``), and the capturing call returns the warm-up forward's eps instead of running a further forward."""
         if not self.use_graph or x.t32 is not None:
             return self.forward_nhwc(x, timesteps, context)
         self._ensure_packed()
@@ -935,13 +972,21 @@ class UNetEngine:
         ex = self.halo_exchange
         shard_sig = None if ex is None else (id(ex), ex.rank, ex.world, ex.first, ex.count, self.halo_hw,
                                              None if self.halo_flow is None else tuple(self.halo_flow.shape))
-        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, sig,
+        # (every switch that changes the captured launch sequence is part of the key: toggling one on a live engine must not
+        # replay a stale graph)
+        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn,
+               self.decompose_attn1, self.exchange_events is not None, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)
         if g is None:
-            g = None if key in self._graph_failed else self._capture(key, x, timesteps, context, flows)
-            if g is None:
+            if key in self._graph_failed:
                 return self.forward_nhwc(x, timesteps, context)
+            g = self._capture(key, x, timesteps, context, flows)
+            if "eps_only" in g:
+                # no graph for this configuration (capture failed or over budget, on this rank or -- sharded -- on any rank of
+                # the clip: one decision for all).  The warm-up forward already computed this call's eps from the same inputs;
+                # a second forward here would issue exchanges the other ranks do not make.
+                return g["eps_only"]
         else:
             self._graphs[key] = self._graphs.pop(key)      # most recently used last
         cid = (id(context), context._version)
@@ -981,7 +1026,7 @@ class UNetEngine:
         saved_cache = getattr(self, "_a2_cache", None)
         real_exchange, real_halo_flow = self.halo_exchange, self.halo_flow
         own_halo_flow = real_halo_flow.clone() if (real_exchange is not None and real_halo_flow is not None) else None
-        seg = None
+        seg, eps_warm, counting, ok, pool_bytes = None, None, None, True, 0
         try:
             if own_halo_flow is not None:
                 self.halo_flow = own_halo_flow
@@ -994,9 +1039,13 @@ class UNetEngine:
             # exchanges -- every rank of the clip captures at the same step, so the calls pair up.)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
+            if real_exchange is not None:
+                counting = self.halo_exchange = _CountingExchange(real_exchange)
             with torch.cuda.stream(side):
-                self.forward_nhwc(Act(xs, x.N, x.H, x.W), ts, context)
+                eps_warm = self.forward_nhwc(Act(xs, x.N, x.H, x.W), ts, context)
             torch.cuda.current_stream().wait_stream(side)
+            if os.environ.get("VFACE_TEST_FAIL_CAPTURE") == "warmup_done":      # (test hook: a capture that dies before its pass)
+                raise RuntimeError("injected capture failure (VFACE_TEST_FAIL_CAPTURE)")
             # the captured launches write to the split-K workspace / read the zero page that exist NOW: the warm-up above must
             # have grown them to their final size (hip.py grows by REPLACING the tensor)
             ws_before = {k: v.data_ptr() for k, v in hip._splitk_ws.items()}
@@ -1019,19 +1068,32 @@ class UNetEngine:
             import warnings
             if seg is not None:
                 seg.abort()
+            if eps_warm is None:
+                raise            # the warm-up forward itself failed: the eager path is the same code and would fail the same way
             warnings.warn(f"vface_amd: hipGraph capture of the UNet forward failed ({type(e).__name__}: {e}); "
                           "this configuration runs kernel by kernel")
-            self._graph_failed.add(key)
-            return None
+            ok = False
+            if real_exchange is not None:
+                # the other ranks of the clip are in (or past) their capture pass, which exchanges for real: finish the
+                # exchanges this rank's aborted pass still owes them, so every rank has made the same number of calls
+                st = seg.pending if seg is not None else None
+                done = seg.n_started if seg is not None else 0
+                real_exchange.drain(st.pop("h", None) if st else None, counting.tails[done:])
         finally:
             self.halo_exchange, self.halo_flow = real_exchange, real_halo_flow
             for c, f in zip(cfgs, saved_flows):
                 c.flow = f
             self._a2_cache = saved_cache
-        if pool_bytes > self.graph_budget_bytes:      # one forward larger than the whole budget: do not pin it
+        over = ok and pool_bytes > self.graph_budget_bytes      # one forward larger than the whole budget: do not pin it
+        if real_exchange is not None and hasattr(real_exchange, "agree"):
+            # ONE decision for the ranks of a clip (pool_bytes follows each rank's own frame count): a rank that replays
+            # segments and a rank that launches eagerly would still pair, but a rank that RE-RUNS the forward would not
+            all_ok, any_over = real_exchange.agree(ok, over)
+            ok, over = all_ok, any_over
+        if not ok or over:
             self._graph_failed.add(key)
-            del seg, eps
-            return None
+            seg = None
+            return {"eps_only": eps_warm}
         while self._graphs and (len(self._graphs) >= self.graph_capacity or
                                 sum(v["bytes"] for v in self._graphs.values()) + pool_bytes > self.graph_budget_bytes):
             self._graphs.pop(next(iter(self._graphs)))      # least recently used first

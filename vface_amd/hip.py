@@ -474,6 +474,11 @@ def ffn_fused_supported(M: int, C_: int) -> bool:
     return bool(load().vface_ffn_fused_supported(M, C_))
 
 
+def ffn_fused_width_supported(C_: int) -> bool:
+    """Does the fused FeedForward take blocks of this width at all (any row count)?  128 rows = one workgroup's tokens."""
+    return bool(load().vface_ffn_fused_supported(128, C_))
+
+
 def ffn_fused(x32: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor,
               b2: torch.Tensor, out16: Optional[torch.Tensor], *, M: int, C_: int, out32: Optional[torch.Tensor] = None,
               eps: float = 1e-5):

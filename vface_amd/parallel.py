@@ -11,9 +11,28 @@ just before the warp, so it overlaps chunk 2's projection (see ``UNetEngine._att
 """
 from __future__ import annotations
 
+import datetime
+import os
 from typing import Optional
 
 import torch
+
+
+class ExchangeTimeout(RuntimeError):
+    """A boundary exchange did not complete within the bound: the message names this rank and the peer(s) it waited for.
+    Callers (bench.py, the entry script) exit non-zero on it instead of waiting for the driver's limit."""
+
+
+def exchange_timeout_s() -> float:
+    """Bound on one boundary exchange, seconds (``VFACE_EXCHANGE_TIMEOUT_S``, default 120).  Under gloo / host staging it is
+    the ``Work.wait`` timeout; under RCCL the waits are stream-ordered (the host does not block), so the same figure is handed
+    to ``init_process_group(timeout=..)`` (``process_group_timeout``) and RCCL's watchdog aborts the process when a peer never
+    shows up; ``VFACE_EXCHANGE_BLOCKING=1`` polls ``Work.is_completed`` on the host instead and raises ``ExchangeTimeout``."""
+    return float(os.environ.get("VFACE_EXCHANGE_TIMEOUT_S", "120"))
+
+
+def process_group_timeout() -> datetime.timedelta:
+    return datetime.timedelta(seconds=exchange_timeout_s())
 
 
 def frame_range(rank: int, world: int, total: int):
@@ -77,22 +96,77 @@ class FrameShard:
         works = d.batch_isend_irecv(ops) if ops else []
         return ("p2p", works, halo)
 
+    def _peers(self) -> str:
+        peers = ([f"rank {self.rank - 1} (its last-frame slab)"] if self.rank > 0 else []) + \
+                ([f"rank {self.rank + 1} (to take ours)"] if self.rank + 1 < self.world else [])
+        return " and ".join(peers) if self.mode != "allgather" else f"all {self.world} ranks (all-gather)"
+
+    def _wait(self, works) -> None:
+        """Bounded wait on the works of one exchange.  gloo (and any backend whose ``wait`` blocks the host) takes the timeout
+        directly; RCCL's ``wait`` only orders the stream, so the bound there is the process group's own timeout (watchdog),
+        unless ``VFACE_EXCHANGE_BLOCKING=1`` asks for host polling."""
+        limit = exchange_timeout_s()
+        backend = self.dist.get_backend() if hasattr(self.dist, "get_backend") else "gloo"
+        poll = backend != "gloo" and os.environ.get("VFACE_EXCHANGE_BLOCKING") == "1"
+        import time
+        t0 = time.monotonic()
+        for w in works:
+            try:
+                if poll:
+                    while not w.is_completed():
+                        if time.monotonic() - t0 > limit:
+                            raise TimeoutError
+                        time.sleep(1e-4)
+                    w.wait()
+                elif backend == "gloo":
+                    left = max(limit - (time.monotonic() - t0), 1e-3)
+                    if w.wait(datetime.timedelta(seconds=left)) is False:
+                        raise TimeoutError
+                else:
+                    w.wait()
+            except (TimeoutError, RuntimeError) as e:
+                if isinstance(e, TimeoutError) or "time" in str(e).lower():
+                    raise ExchangeTimeout(f"rank {self.rank} of {self.world}: the boundary exchange did not complete within "
+                                          f"{limit:g} s -- waited for {self._peers()}") from e
+                raise
+
     def finish_exchange(self, handle) -> Optional[torch.Tensor]:
-        """Wait for the transfer; returns the previous rank's slab (None on rank 0 / single rank)."""
+        """Wait (bounded: ``exchange_timeout_s``) for the transfer; returns the previous rank's slab (None on rank 0 / single
+        rank).  Raises ``ExchangeTimeout`` naming the peer when it does not arrive."""
         if handle is None:
             return None
         kind, work, buf = handle
         if kind == "host":
-            for w in work:
-                w.wait()
+            self._wait(work)
             halo, dev = buf
             return halo.to(dev) if halo is not None else None
         if kind == "ag":
-            work.wait()
+            self._wait([work])
             return buf[self.rank - 1] if self.rank > 0 else None
-        for w in work:
-            w.wait()
+        self._wait(work)
         return buf
+
+    # ---- one decision for all ranks of a clip (hipGraph capture outcome, ADVICE r3)
+    def agree(self, ok: bool, over_budget: bool = False):
+        """All-reduce two flags over the ranks of the clip: returns ``(every rank ok, any rank over budget)``.  A rank whose
+        capture failed and a rank whose capture succeeded must take ONE decision, or their exchange counts stop pairing."""
+        if self.world == 1:
+            return bool(ok), bool(over_budget)
+        d = self.dist
+        dev = "cuda" if d.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([0 if ok else 1, 1 if over_budget else 0], dtype=torch.int32, device=dev)
+        d.all_reduce(t, op=d.ReduceOp.MAX)
+        bad, over = (int(v) for v in t.cpu())
+        return bad == 0, over != 0
+
+    def drain(self, pending, remaining) -> None:
+        """Finish the paired exchanges of an aborted forward so that the neighbours' calls still match: ``pending`` = a handle
+        that was started and not finished (or None), ``remaining`` = the slabs (tensors shaped like the tails the forward would
+        have sent; contents irrelevant) of the exchanges not yet started."""
+        if pending is not None:
+            self.finish_exchange(pending)
+        for tail in remaining:
+            self.finish_exchange(self.start_exchange(tail))
 
     def slab_bytes_per_step(self, n: int, d: int, layers: int = 2, elem: int = 2) -> int:
         """Bytes this rank SENDS per DDIM step: one ``[n, 2d]`` slab per hooked level-0 layer (none from the last rank)."""
@@ -136,3 +210,6 @@ class LoopbackShard(FrameShard):
         if handle is None or self.rank == 0:
             return None
         return self.store[self.rank - 1][handle[1]]
+
+    def agree(self, ok: bool, over_budget: bool = False):
+        return bool(ok), bool(over_budget)      # one process: its own verdict is everybody's
