@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VFACE_ABI_VERSION 4   /* 4: + vface_ffn_fused, the flow-producer glue (vface_im2col .. vface_convex_upsample), the paste-back entry points; nothing of 3 changed */
+#define VFACE_ABI_VERSION 5   /* 5: + vface_groupnorm_apply_from_cols; nothing of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
 
 #define VFACE_OK 0
 #define VFACE_ERR_ARG (-1)
@@ -193,6 +193,12 @@ int vface_groupnorm_coeffs_from_cols(const float* colstats, int64_t ld_colstats,
 int vface_groupnorm_apply(const void* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
                           void* y, int64_t ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype,
                           void* stream);
+/* vface_groupnorm_finalize_cols + vface_groupnorm_apply in ONE launch: every workgroup forms the (mean, rstd) of its image's
+ * groups from the producer's column sums itself (same summation order as vface_groupnorm_finalize_cols: identical bits), so no
+ * statistics launch sits between a producer and its GroupNorm.  Needs hw % 64 == 0, C <= 4096. */
+int vface_groupnorm_apply_from_cols(const void* x, int64_t ldx, const float* colstats, int64_t ld_colstats, float eps,
+                                    const float* gamma, const float* beta, void* y, int64_t ldy, int nimg, int hw, int C,
+                                    int groups, int silu, int in_f32, int dtype, void* stream);
 
 /* Flow-guided temporal smoothing of a token-major map [F][h*w][C] (temporal_flow.py:40-53,222-237):
  *   dst[f] = alpha * src[f] + one_minus_alpha * bilinear(src[f-1], (x + dx, y + dy)); dst[0] = src[0]

@@ -423,6 +423,43 @@ def test_conv_colstats_feed_groupnorm(N_, cout):
     assert cs[:, :32].abs().max() == 0 and cs[:, 32 + cout:].abs().max() == 0
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("C,H,nimg,in32,silu,eps", [(320, 64, 3, True, True, 1e-5), (640, 32, 2, False, True, 1e-5),
+                                                    (1280, 8, 5, True, False, 1e-6), (2560, 16, 2, False, True, 1e-5),
+                                                    (64, 8, 1, True, True, 1e-5)])
+def test_groupnorm_apply_from_cols_equals_finalize_then_apply_bit_for_bit(dt, C, H, nimg, in32, silu, eps):
+    """VERDICT r3 next #1c: the statistics launch between a producer and its GroupNorm is folded into the normalisation launch
+    (vface_groupnorm_apply_from_cols).  Same summation order by construction, so: the same output bits as
+    vface_groupnorm_finalize_cols + vface_groupnorm_apply, from column sums laid out as a column slice of a wider buffer, for the
+    fp32 carrier and the 16-bit copy as input; and within tolerance of torch's group_norm."""
+    h = hip()
+    hw = H * H
+    x = rnd((nimg * hw, C), 11, torch.float32, 1.5) + 0.3
+    xin = x.to(DEV) if in32 else x.to(dt).to(DEV)
+    xs = xin.float()
+    # the producer's column sums: per 64-row slice, per channel, (sum, sum of squares) of the values as stored
+    sl = xs.reshape(nimg * hw // 64, 64, C)
+    cs_wide = torch.zeros(nimg * hw // 64, C + 16, 2, dtype=torch.float32, device=DEV)
+    cs = cs_wide[:, 8:8 + C]
+    cs[..., 0] = sl.sum(1)
+    cs[..., 1] = (sl * sl).sum(1)
+    g = rnd((C,), 12, torch.float32, 0.5).to(DEV) + 1.0
+    b = rnd((C,), 13, torch.float32, 0.2).to(DEV)
+    y2 = torch.empty(nimg * hw, C, dtype=dt, device=DEV)
+    y1 = torch.empty_like(y2)
+    st = h.groupnorm_stats_from_cols(cs, nimg=nimg, hw=hw, C_=C, eps=eps)
+    h.groupnorm_apply(xin, st, g, b, y2, nimg=nimg, hw=hw, C_=C, ldx=C, ldy=C, silu=silu)
+    h.groupnorm_apply(xin, None, g, b, y1, nimg=nimg, hw=hw, C_=C, ldx=C, ldy=C, silu=silu, colstats=cs, eps=eps)
+    assert torch.equal(y1, y2)
+    ref = F.group_norm(xs.cpu().reshape(nimg, hw, C).permute(0, 2, 1), 32, g.cpu(), b.cpu(), eps)
+    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1).reshape(nimg * hw, C)
+    assert rel_l2(y1.float().cpu(), ref) < TOL[dt]
+    # the folded coefficients of the fused-conv path come from the same sums
+    ab = h.groupnorm_coeffs_from_cols(cs, g, b, nimg=nimg, hw=hw, C_=C, eps=eps)
+    a_ref = (st[..., 1].repeat_interleave(C // 32, 1) * g[None])
+    assert torch.equal(ab[..., 0], a_ref)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("cin,cout,H,nimg", [(1280, 1280, 8, 6), (640, 320, 8, 5), (2560, 1280, 8, 3)])
 def test_conv3x3_split_k(cin, cout, H, nimg):

@@ -187,6 +187,14 @@ int vface_groupnorm_apply(const void* x, int64_t ldx, const float* stats, const 
     return vf_launch_gn_apply(x, ldx, stats, gamma, beta, y, ldy, nimg, hw, C, groups, silu, in_f32, dtype, S(stream));
 }
 
+int vface_groupnorm_apply_from_cols(const void* x, int64_t ldx, const float* colstats, int64_t ld_colstats, float eps,
+                                    const float* gamma, const float* beta, void* y, int64_t ldy, int nimg, int hw, int C,
+                                    int groups, int silu, int in_f32, int dtype, void* stream) {
+    if (!colstats) return VFACE_ERR_ARG;
+    return vf_launch_gn_apply(x, ldx, nullptr, gamma, beta, y, ldy, nimg, hw, C, groups, silu, in_f32, dtype, S(stream),
+                              colstats, ld_colstats, eps);
+}
+
 int vface_flow_warp(const void* src, int64_t ld_src, int64_t fs_src, const void* prev, int64_t ld_prev,
                     const float* flow, const float* flow_prev, void* dst, int64_t ld_dst, int64_t fs_dst, int F,
                     int h, int w, int C, float alpha, float one_minus_alpha, int flags, int32_t* dbg_x0,

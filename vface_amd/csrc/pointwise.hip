@@ -153,27 +153,55 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk
 }
 
 // y = silu?( x * a[c] + b[c] ) with a = rstd * gamma, b = beta - mean * rstd * gamma held in registers per thread
-// (mean, rstd) from producer-side column statistics: colstats[slice][ld][2] with 64-row slices, hw % 64 == 0
+// (mean, rstd) from producer-side column statistics: colstats[slice][ld][2] with 64-row slices, hw % 64 == 0.
+// The summation ORDER is one definition shared by gn_finalize_cols, gn_coeffs_cols and the prologue of
+// gn_apply_kernel<.., COLS = true>, so the three paths agree bit for bit: per channel, the slices of the image in slice order;
+// per group, its channels in channel order; all in double.
+__device__ __forceinline__ void gn_channel_sums(const float* __restrict__ colstats, long ld, int spi, int img, int c,
+                                                double& s, double& q) {
+    const float* p = colstats + ((long)img * spi * ld + c) * 2;
+    const long step = ld * 2;
+    s = 0.0; q = 0.0;
+    int sl = 0;
+    for (; sl + 8 <= spi; sl += 8) {      // eight independent loads in flight, added in slice order
+        float2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(p + (long)(sl + u) * step);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s += v[u].x; q += v[u].y; }
+    }
+    for (; sl < spi; ++sl) {
+        const float2 v = *reinterpret_cast<const float2*>(p + (long)sl * step);
+        s += v.x; q += v.y;
+    }
+}
+
+__device__ __forceinline__ void gn_group_finish(const double* __restrict__ chs, const double* __restrict__ chq, int cpg, int hw,
+                                                float eps, float& meanf, float& rstdf) {
+    double s = 0.0, q = 0.0;
+    for (int c = 0; c < cpg; ++c) { s += chs[c]; q += chq[c]; }
+    const double count = (double)hw * cpg;
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    meanf = (float)mean;
+    rstdf = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+constexpr int GN_MAX_CPG = 256;   // channels per group the one-block-per-group kernels take (C <= 8192 at 32 groups)
+
 __global__ __launch_bounds__(64) void gn_finalize_cols_kernel(const float* __restrict__ colstats, long ld, int hw, int C,
                                                               int groups, float eps, float* __restrict__ stats) {
     const int img = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
     const int cpg = C / groups, spi = hw / 64;
-    const int total = cpg * spi;
-    double s = 0.0, q = 0.0;
-    for (int i = lane; i < total; i += 64) {
-        const int sl = i / cpg, c = g * cpg + (i - sl * cpg);
-        const float2 v = *reinterpret_cast<const float2*>(colstats + (((long)img * spi + sl) * ld + c) * 2);
-        s += v.x; q += v.y;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    __shared__ double chs[GN_MAX_CPG], chq[GN_MAX_CPG];
+    for (int c = lane; c < cpg; c += 64) gn_channel_sums(colstats, ld, spi, img, g * cpg + c, chs[c], chq[c]);
+    __syncthreads();
     if (lane == 0) {
-        const double count = (double)hw * cpg;
-        const double mean = s / count;
-        double var = q / count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        stats[((long)img * groups + g) * 2] = (float)mean;
-        stats[((long)img * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        float meanf, rstd;
+        gn_group_finish(chs, chq, cpg, hw, eps, meanf, rstd);
+        stats[((long)img * groups + g) * 2] = meanf;
+        stats[((long)img * groups + g) * 2 + 1] = rstd;
     }
 }
 
@@ -185,39 +213,47 @@ __global__ __launch_bounds__(64) void gn_coeffs_cols_kernel(const float* __restr
                                                             const float* __restrict__ beta, float* __restrict__ ab) {
     const int img = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
     const int cpg = C / groups, spi = hw / 64;
-    const int total = cpg * spi;
-    double s = 0.0, q = 0.0;
-    for (int i = lane; i < total; i += 64) {
-        const int sl = i / cpg, c = g * cpg + (i - sl * cpg);
-        const float2 v = *reinterpret_cast<const float2*>(colstats + (((long)img * spi + sl) * ld + c) * 2);
-        s += v.x; q += v.y;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
-    const double count = (double)hw * cpg;
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    __shared__ double chs[GN_MAX_CPG], chq[GN_MAX_CPG];
+    __shared__ float mr[2];
+    for (int c = lane; c < cpg; c += 64) gn_channel_sums(colstats, ld, spi, img, g * cpg + c, chs[c], chq[c]);
+    __syncthreads();
+    if (lane == 0) gn_group_finish(chs, chq, cpg, hw, eps, mr[0], mr[1]);
+    __syncthreads();
+    const float meanf = mr[0], rstd = mr[1];
     for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
         const float a = rstd * gamma[c];
         *reinterpret_cast<float2*>(ab + ((long)img * C + c) * 2) = make_float2(a, beta[c] - meanf * a);
     }
 }
 
-template <class TT, bool IN32>
+// COLS: `stats` is the producer's column statistics (ld_cs pairs per slice row) and the workgroup forms the (mean, rstd) of its
+// image's groups itself, in LDS, before the pixel loop -- the gn_finalize_cols launch between a producer and its GroupNorm
+// (61 launches of ~6-8 us per UNet forward, pure latency) disappears.  Each of the four waves takes groups/4 groups; the
+// colstats of one image are 8 * C * hw / 64 bytes, read from L2: thread = channel (coalesced rows of the slice matrix), then one
+// thread per group sums its channels from LDS (dynamic shared memory: 16 * C bytes).
+template <class TT, bool IN32, bool COLS>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ x, long ldx,
                                                        const float* __restrict__ stats,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        typename TT::elem* __restrict__ y, long ldy, int hw, int C,
-                                                       int groups, int silu, int pix_per_block) {
+                                                       int groups, int silu, int pix_per_block, long ld_cs, float eps) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
     const int img = blockIdx.y, t = threadIdx.x;
     const int c8 = C / 8, cpg = C / groups;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(hw, p0 + pix_per_block);
+    __shared__ float s_st[128];
+    extern __shared__ double s_ch[];      // COLS: [2][C]
     const float* st = stats + (long)img * groups * 2;
+    if constexpr (COLS) {
+        const int spi = hw / 64;
+        for (int c = t; c < C; c += 256) gn_channel_sums(stats, ld_cs, spi, img, c, s_ch[c], s_ch[C + c]);
+        __syncthreads();
+        if (t < groups) gn_group_finish(s_ch + t * cpg, s_ch + C + t * cpg, cpg, hw, eps, s_st[2 * t], s_st[2 * t + 1]);
+        __syncthreads();
+        st = s_st;
+    }
     const long xb = (long)img * hw * ldx;
     E* yb = y + (long)img * hw * ldy;
     const int CPB = min(c8, 256), PP = 256 / CPB;
@@ -790,16 +826,18 @@ int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int gro
 int vf_launch_gn_coeffs_cols(const float* colstats, long ld, int nimg, int hw, int C, int groups, float eps, const float* gamma,
                              const float* beta, float* ab, hipStream_t stream) {
     if (!colstats || !gamma || !beta || !ab || nimg <= 0 || hw <= 0 || C <= 0 || groups <= 0) return VF_ERR_ARG;
-    if ((hw & 63) || groups > 64 || C % groups || (ld & 1)) return VF_ERR_SHAPE;
+    if ((hw & 63) || groups > 64 || C % groups || (ld & 1) || C / groups > GN_MAX_CPG) return VF_ERR_SHAPE;
     hipLaunchKernelGGL(gn_coeffs_cols_kernel, dim3(groups, nimg), dim3(64), 0, stream, colstats, ld, hw, C, groups, eps, gamma, beta, ab);
     return ok();
 }
 
 int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y,
-                       long ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype, hipStream_t stream) {
-    if (!x || !stats || !gamma || !beta || !y || nimg <= 0 || hw <= 0) return VF_ERR_ARG;
+                       long ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype, hipStream_t stream,
+                       const float* colstats, long ld_cs, float eps) {
+    if (!x || (!stats && !colstats) || !gamma || !beta || !y || nimg <= 0 || hw <= 0) return VF_ERR_ARG;
     if ((C & 7) || (ldx & (in_f32 ? 3 : 7)) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VF_ERR_ALIGN;
     if (groups > 64 || C % groups) return VF_ERR_SHAPE;
+    if (colstats && ((hw & 63) || ld_cs < C || ((uintptr_t)colstats & 7) || C > 4096)) return VF_ERR_SHAPE;
     // enough workgroups to fill 256 CUs several times over, but long enough pixel loops to amortise the
     // per-thread scale/shift set-up
     int ppb = 128;
@@ -807,8 +845,13 @@ int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float*
     dim3 grid((hw + ppb - 1) / ppb, nimg);
     DISPATCH_DTYPE(dtype, {
         using E = typename TT::elem;
-        if (in_f32) hipLaunchKernelGGL((gn_apply_kernel<TT, true>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
-        else hipLaunchKernelGGL((gn_apply_kernel<TT, false>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
+        if (colstats) {
+            if (in_f32) hipLaunchKernelGGL((gn_apply_kernel<TT, true, true>), grid, dim3(256), (size_t)C * 16, stream, x, ldx, colstats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb, ld_cs, eps);
+            else hipLaunchKernelGGL((gn_apply_kernel<TT, false, true>), grid, dim3(256), (size_t)C * 16, stream, x, ldx, colstats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb, ld_cs, eps);
+        } else {
+            if (in_f32) hipLaunchKernelGGL((gn_apply_kernel<TT, true, false>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb, 0L, 0.f);
+            else hipLaunchKernelGGL((gn_apply_kernel<TT, false, false>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb, 0L, 0.f);
+        }
     });
     return ok();
 }
@@ -993,7 +1036,7 @@ int vf_launch_adain(const void* a, long lda, const void* b, long ldb, void* dst,
 int vf_launch_gn_finalize_cols(const float* colstats, long ld, int nimg, int hw, int C, int groups, float eps, float* stats,
                                hipStream_t stream) {
     if (!colstats || !stats || nimg <= 0 || hw <= 0 || C <= 0 || groups <= 0) return VF_ERR_ARG;
-    if ((hw & 63) || (C % groups) || ld < C) return VF_ERR_SHAPE;
+    if ((hw & 63) || (C % groups) || ld < C || C / groups > GN_MAX_CPG) return VF_ERR_SHAPE;
     hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(groups, nimg), dim3(64), 0, stream, colstats, ld, hw, C, groups, eps, stats);
     return ok();
 }

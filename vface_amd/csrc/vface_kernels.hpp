@@ -127,8 +127,10 @@ int vf_launch_gn_coeffs_cols(const float* colstats, long ld, int nimg, int hw, i
 int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
                        float* stats, int in_f32, int dtype, hipStream_t stream);
 int vf_gn_partial_floats(int nimg, int hw, int C, int groups);
+// colstats != nullptr: the statistics are formed inside the launch from producer-side column sums (stats is then unused)
 int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y,
-                       long ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype, hipStream_t stream);
+                       long ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype, hipStream_t stream,
+                       const float* colstats = nullptr, long ld_cs = 0, float eps = 0.f);
 int vf_launch_flow_warp(const void* src, long ld_src, long fs_src, const void* prev, long ld_prev,
                         const float* flow, const float* flow_prev, void* dst, long ld_dst, long fs_dst, int F, int h,
                         int w, int C, float alpha, float one_minus_alpha, int flags, int* dbg_x0, int* dbg_y0, int dtype,

@@ -295,9 +295,13 @@ class _GraphSegments:
         self.cur = None
 
     def abort(self):
+        """End a capture that will not be used.  ``capture_end`` must run on the CAPTURING stream: the exception that brings us
+        here has already unwound the ``with torch.cuda.stream(..)`` block, and ending the capture from another stream is a
+        fatal HIP error (process abort), not a Python exception."""
         if self.cur is not None:
             try:
-                self.cur.capture_end()
+                with torch.cuda.stream(self.stream):
+                    self.cur.capture_end()
             except Exception:
                 pass
             self.cur = None
@@ -388,6 +392,9 @@ class UNetEngine:
         # the ~70 vector instructions per 1-KiB patch piece sit in the K-tile period's critical path -- 28.22 vs 27.49 ms per
         # DDIM step (conv 9.46 vs 7.77 ms, gn_apply 0 vs 1.0 ms), DESIGN 4 -- so it is opt-in.
         self.fuse_gn = os.environ.get("VFACE_FUSE_GN", "off")
+        # GroupNorm statistics formed inside the normalisation launch (vface_groupnorm_apply_from_cols) instead of by a
+        # gn_finalize_cols launch between the producer and its GroupNorm: same bits.  VFACE_FOLD_GN_STATS=0: two launches (A/B).
+        self.fold_gn_stats = os.environ.get("VFACE_FOLD_GN_STATS", "1") != "0"
         # hipGraph replay of the UNet forward of a DDIM step (step_forward_nhwc): capture once per (batch, resolution, hook
         # configuration, context shape) and replay -- the default since round 3 (bit-equal to kernel-by-kernel launches, one
         # host call per step instead of ~1200; what bench.py times); VFACE_GRAPH=0 launches kernel by kernel.  The C ABI is
@@ -578,11 +585,16 @@ class UNetEngine:
 
     def _gn(self, x: Act, gn, eps: float, silu: bool) -> Act:
         src = x.src
+        y = self._new(x.M, x.C)
+        if x.cs is not None and self.fold_gn_stats:
+            # statistics from the producer's column sums INSIDE the normalisation launch (no finalize launch in between)
+            hip.groupnorm_apply(src, None, gn[0], gn[1], y, nimg=x.N, hw=x.hw, C_=x.C, ldx=src.stride(0), ldy=x.C, silu=silu,
+                                colstats=x.cs, eps=eps)
+            return Act(y, x.N, x.H, x.W)
         if x.cs is not None:
             st = hip.groupnorm_stats_from_cols(x.cs, nimg=x.N, hw=x.hw, C_=x.C, eps=eps)
         else:
             st = hip.groupnorm_stats(src, nimg=x.N, hw=x.hw, C_=x.C, ldx=src.stride(0), eps=eps)
-        y = self._new(x.M, x.C)
         hip.groupnorm_apply(src, st, gn[0], gn[1], y, nimg=x.N, hw=x.hw, C_=x.C, ldx=src.stride(0), ldy=x.C, silu=silu)
         return Act(y, x.N, x.H, x.W)
 
@@ -974,7 +986,7 @@ class UNetEngine:
                                              None if self.halo_flow is None else tuple(self.halo_flow.shape))
         # (every switch that changes the captured launch sequence is part of the key: toggling one on a live engine must not
         # replay a stale graph)
-        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn,
+        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fold_gn_stats,
                self.decompose_attn1, self.exchange_events is not None, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)

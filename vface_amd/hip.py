@@ -63,6 +63,8 @@ SIGNATURES = {
     "vface_groupnorm_stats": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _i32, _vp]),
     "vface_groupnorm_coeffs_from_cols": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "vface_groupnorm_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "vface_groupnorm_apply_from_cols": (C.c_int, [_vp, _i64, _vp, _i64, _f32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
+                                                  _i32, _vp]),
     "vface_flow_warp": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                                   _f32, _i32, _vp, _vp, _i32, _vp]),
     "vface_flow_to_latent": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -123,7 +125,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.vface_abi_version() != 4:
+    if lib.vface_abi_version() != 5:
         raise VFaceHipError("libvface_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -290,8 +292,17 @@ def groupnorm_coeffs_from_cols(colstats: torch.Tensor, gamma: torch.Tensor, beta
     return ab
 
 
-def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor,
-                    *, nimg: int, hw: int, C_: int, ldx: int, ldy: int, groups: int = 32, silu: bool = False):
+def groupnorm_apply(x: torch.Tensor, stats: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor,
+                    *, nimg: int, hw: int, C_: int, ldx: int, ldy: int, groups: int = 32, silu: bool = False,
+                    colstats: Optional[torch.Tensor] = None, eps: float = 1e-5):
+    """``colstats`` (the producer's column sums, ``[nimg*hw/64, C(view), 2]`` fp32) instead of ``stats``: statistics and
+    normalisation in one launch (``vface_groupnorm_apply_from_cols``)."""
+    if colstats is not None:
+        rc = load().vface_groupnorm_apply_from_cols(_p(x), ldx, _p(colstats), colstats.stride(0) // 2, eps, _p(gamma), _p(beta),
+                                                    _p(out), ldy, nimg, hw, C_, groups, int(silu),
+                                                    int(x.dtype == torch.float32), dtype_code(out.dtype), _stream())
+        _check(rc, "vface_groupnorm_apply_from_cols")
+        return
     rc = load().vface_groupnorm_apply(_p(x), ldx, _p(stats), _p(gamma), _p(beta), _p(out), ldy, nimg, hw, C_, groups,
                                       int(silu), int(x.dtype == torch.float32), dtype_code(out.dtype), _stream())
     _check(rc, "vface_groupnorm_apply")
