@@ -112,6 +112,7 @@ class FamilyTimer:
       gemm       gemm_kernel<T, MODE_PLAIN, ..>: every Linear / 1x1 conv (sub-classes: `ff1` = the GEGLU projection, `n320` = the
                  level-0 projections with N = 320, `other`); FLOPs = 2 M N K as executed (incl. the folded FSAI K = 2d);
                  `ffn_fused` = ffn_fused_kernel (ffn.hip): LayerNorm + both FeedForward GEMMs + residual of a level-0 block;
+                 `st_front` = st_front_kernel (stfront.hip): GroupNorm-apply + proj_in + LayerNorm + attn1 projection of a level-0 block;
       attention  attn_kernel<T, DH, ..> by head dim; FLOPs = the ALGORITHMIC 4 n nk dh per (output sample, head) --
                  the shared-score form executes fewer;
       norm       layernorm / groupnorm apply+finalize: HBM-bound, reported in GB/s of algorithmic bytes."""
@@ -182,6 +183,17 @@ class FamilyTimer:
                 return call()
             timer._timed("gemm", "ffn_fused", 24.0 * M * C_ * C_, 1, call)
         hip.ffn_fused = ffn_fused
+        orig_front = hip.st_front
+
+        def st_front(x32, gn_ab, wcat, b_in, gamma, beta, t0, qkv, *, M, C_, hw, NQ, rows_full, nq_lo=0, **kw):
+            # GroupNorm-apply + proj_in + LayerNorm + the attn1 projection of a level-0 SpatialTransformer in one launch:
+            # 2 M C C (proj_in) + 2 C (rows_full NQ + (M - rows_full) (NQ - nq_lo)) FLOPs as executed
+            call = lambda: orig_front(x32, gn_ab, wcat, b_in, gamma, beta, t0, qkv, M=M, C_=C_, hw=hw, NQ=NQ, rows_full=rows_full,
+                                      nq_lo=nq_lo, **kw)
+            if not timer.on:
+                return call()
+            timer._timed("gemm", "st_front", 2.0 * M * C_ * C_ + 2.0 * C_ * (rows_full * NQ + (M - rows_full) * (NQ - nq_lo)), 1, call)
+        hip.st_front = st_front
         orig_attn = hip.attention
 
         def attention(q, k, v, out, *, B, heads, n, nk, dh, v_sets=1, **kw):
@@ -217,6 +229,16 @@ class FamilyTimer:
                          nbytes=float(nimg) * (hw // 64) * C_ * 8)
             return box[0]
         hip.groupnorm_stats_from_cols = groupnorm_stats_from_cols
+        orig_gco = hip.groupnorm_coeffs_from_cols
+
+        def groupnorm_coeffs_from_cols(colstats, gamma, beta, *, nimg, hw, C_, **kw):
+            if not timer.on:
+                return orig_gco(colstats, gamma, beta, nimg=nimg, hw=hw, C_=C_, **kw)
+            box = []
+            timer._timed("norm", "groupnorm_finalize", 0.0, 1, lambda: box.append(orig_gco(colstats, gamma, beta, nimg=nimg, hw=hw, C_=C_, **kw)),
+                         nbytes=float(nimg) * (hw // 64) * C_ * 8)
+            return box[0]
+        hip.groupnorm_coeffs_from_cols = groupnorm_coeffs_from_cols
         orig_fw = hip.flow_warp
 
         def flow_warp(src, dst, flow, *, F, h, w, C_, **kw):
@@ -560,7 +582,7 @@ def main():
             return o
 
         by_family = {k: fam_total(k) for k in ("gemm", "conv", "attention", "norm")}
-        by_family["gemm"]["kernel"] = "gemm_kernel<T, MODE_PLAIN, NT, DB, PERSIST, RM> (gemm.hip): every Linear / 1x1 conv, + ffn_fused_kernel<T, C> (ffn.hip): the level-0 FeedForward in one launch; FLOPs as executed (2 M N K)"
+        by_family["gemm"]["kernel"] = "gemm_kernel<T, MODE_PLAIN, NT, DB, PERSIST, RM> (gemm.hip): every Linear / 1x1 conv, + ffn_fused_kernel<T, C> (ffn.hip): the level-0 FeedForward in one launch + st_front_kernel<T, C> (stfront.hip): GroupNorm-apply, proj_in, LayerNorm and the attn1 projection of a level-0 block in one launch; FLOPs as executed (2 M N K)"
         by_family["conv"]["kernel"] = "conv_patch_kernel<T, NT, KH, KW, ..> (conv.hip) + gemm_kernel<T, MODE_CONV_*> (im2col); FLOPs as executed"
         by_family["attention"]["kernel"] = "attn_kernel<T, DH, QT, G, LAZY> (attention.hip); algorithmic FLOPs 4 n nk dh per (output sample, head)"
         by_family["norm"]["kernel"] = "layernorm_kernel, gn_apply_kernel, gn_finalize_cols, flow_warp_kernel (pointwise.hip): HBM-bound, algorithmic bytes"
@@ -568,7 +590,7 @@ def main():
         mfma_fams = ("gemm", "conv", "attention")
         dom = max(mfma_fams, key=lambda k: by_family[k]["ms"])
         d = by_family[dom]
-        prefixes = {"gemm": ("gemm_kernel<F16, 0,", "gemm_kernel<BF16, 0,", "ffn_fused_kernel"), "conv": ("conv_patch_kernel", "gemm_kernel<F16, 1,", "gemm_kernel<F16, 2,"),
+        prefixes = {"gemm": ("gemm_kernel<F16, 0,", "gemm_kernel<BF16, 0,", "ffn_fused_kernel", "st_front_kernel"), "conv": ("conv_patch_kernel", "gemm_kernel<F16, 1,", "gemm_kernel<F16, 2,"),
                     "attention": ("attn_kernel",)}[dom]
         traffic, traffic_src = traffic_from_profiles(prefixes, F_ == 8 and h == 64 and a.fusion == "replace" and a.dtype == "fp16" and world == 1)
         out = {

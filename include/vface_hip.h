@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VFACE_ABI_VERSION 5   /* 5: + vface_groupnorm_apply_from_cols; nothing of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
+#define VFACE_ABI_VERSION 5   /* 5: + vface_st_front; nothing of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
 
 #define VFACE_OK 0
 #define VFACE_ERR_ARG (-1)
@@ -193,12 +193,6 @@ int vface_groupnorm_coeffs_from_cols(const float* colstats, int64_t ld_colstats,
 int vface_groupnorm_apply(const void* x, int64_t ldx, const float* stats, const float* gamma, const float* beta,
                           void* y, int64_t ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype,
                           void* stream);
-/* vface_groupnorm_finalize_cols + vface_groupnorm_apply in ONE launch: every workgroup forms the (mean, rstd) of its image's
- * groups from the producer's column sums itself (same summation order as vface_groupnorm_finalize_cols: identical bits), so no
- * statistics launch sits between a producer and its GroupNorm.  Needs hw % 64 == 0, C <= 4096. */
-int vface_groupnorm_apply_from_cols(const void* x, int64_t ldx, const float* colstats, int64_t ld_colstats, float eps,
-                                    const float* gamma, const float* beta, void* y, int64_t ldy, int nimg, int hw, int C,
-                                    int groups, int silu, int in_f32, int dtype, void* stream);
 
 /* Flow-guided temporal smoothing of a token-major map [F][h*w][C] (temporal_flow.py:40-53,222-237):
  *   dst[f] = alpha * src[f] + one_minus_alpha * bilinear(src[f-1], (x + dx, y + dy)); dst[0] = src[0]
@@ -329,6 +323,21 @@ int vface_ffn_fused_supported(int64_t M, int C);
 int vface_ffn_fused(const float* x32, int64_t ldx, const float* gamma, const float* beta, float eps, const void* W1, const float* b1,
                     const void* W2p, const float* b2, void* out16, int64_t ldo, float* out32, int64_t ldo32, int M, int C,
                     int dtype, void* stream);
+
+/* Fused FRONT of a SpatialTransformer (attention.py:278-284 norm -> proj_in -> tokens; :239 norm1; :179-183 to_q / to_k / to_v of
+ * attn1), one launch for GroupNorm-apply + proj_in + LayerNorm + the attn1 projection on token matrices with C in {64, 128, 320}:
+ *   t0  = (x32 * a[img] + b[img])_16 @ W_in^T + b_in            fp32 [M][C]   (the carrier the attn1 out-projection adds to)
+ *   qkv = LayerNorm(t0; gamma, beta, eps)_16 @ W_p^T            16-bit [M][ldq], projection column j at qkv[:, j]
+ * (a, b) = vface_groupnorm_coeffs_from_cols of x's producer (fp32 pairs [nimg][ld_ab][2]); hw = rows per image, M % 128 == 0,
+ * hw % 128 == 0.  Wcat = [C + NQ][C] 16-bit: the C rows of proj_in, then the NQ projection rows with their k columns permuted
+ * inside every aligned block of 16: position 8 h + j holds original column 8 (j >> 2) + 4 h + (j & 3) (packing.ffn_w2_perm).
+ * Rows [0, rows_full) get projection columns [0, NQ), the others only [nq_lo, NQ) (the hook's "replace": chunks >= 1 project V
+ * only, pnp_utils.py:133-142); rows_full % 128 == 0, NQ % 32 == 0, nq_lo % 32 == 0.  ln (optional): LayerNorm(t0) as a 16-bit
+ * matrix too (what the dual-source projections of the hook's linear fusions read).  No workspace; capturable. */
+int vface_st_front_supported(int64_t M, int C, int hw);
+int vface_st_front(const float* x32, int64_t ldx, const float* gn_ab, int64_t ld_ab, int hw, const void* Wcat, const float* b_in,
+                   const float* gamma, const float* beta, float eps, float* t0, int64_t ldt0, void* qkv, int64_t ldq, void* ln,
+                   int64_t ldln, int M, int C, int NQ, int rows_full, int nq_lo, int dtype, void* stream);
 
 /* fusion="temporal" (pnp_utils.py:59-90,145-154): 5-tap Gaussian (sigma 1, renormalised at the clip ends) over the
  * FRAME axis of src [F][n][C] (chunk 0's q|k), written to dst1 and dst2 (chunk 1 and chunk 2). */

@@ -423,41 +423,33 @@ def test_conv_colstats_feed_groupnorm(N_, cout):
     assert cs[:, :32].abs().max() == 0 and cs[:, 32 + cout:].abs().max() == 0
 
 
-@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("C,H,nimg,in32,silu,eps", [(320, 64, 3, True, True, 1e-5), (640, 32, 2, False, True, 1e-5),
-                                                    (1280, 8, 5, True, False, 1e-6), (2560, 16, 2, False, True, 1e-5),
-                                                    (64, 8, 1, True, True, 1e-5)])
-def test_groupnorm_apply_from_cols_equals_finalize_then_apply_bit_for_bit(dt, C, H, nimg, in32, silu, eps):
-    """VERDICT r3 next #1c: the statistics launch between a producer and its GroupNorm is folded into the normalisation launch
-    (vface_groupnorm_apply_from_cols).  Same summation order by construction, so: the same output bits as
-    vface_groupnorm_finalize_cols + vface_groupnorm_apply, from column sums laid out as a column slice of a wider buffer, for the
-    fp32 carrier and the 16-bit copy as input; and within tolerance of torch's group_norm."""
+@pytest.mark.parametrize("C,H,nimg,eps", [(320, 64, 3, 1e-5), (640, 32, 2, 1e-5), (1280, 8, 5, 1e-6), (2560, 16, 2, 1e-5),
+                                          (64, 8, 1, 1e-5), (1920, 32, 1, 1e-5)])
+def test_groupnorm_stats_from_cols_one_block_per_image(C, H, nimg, eps):
+    """Round 4: gn_finalize_cols / gn_coeffs_cols run one 1024-thread block per image (every load of a thread in flight at
+    once) instead of one 64-thread block per (image, group).  Against fp64 sums of the same column statistics (laid out as a
+    column slice of a wider buffer), and the two kernels against each other bit for bit (one summation order)."""
     h = hip()
     hw = H * H
-    x = rnd((nimg * hw, C), 11, torch.float32, 1.5) + 0.3
-    xin = x.to(DEV) if in32 else x.to(dt).to(DEV)
-    xs = xin.float()
-    # the producer's column sums: per 64-row slice, per channel, (sum, sum of squares) of the values as stored
-    sl = xs.reshape(nimg * hw // 64, 64, C)
+    x = (rnd((nimg * hw, C), 11, torch.float32, 1.5) + 0.3).to(DEV)
+    sl = x.reshape(nimg * hw // 64, 64, C)
     cs_wide = torch.zeros(nimg * hw // 64, C + 16, 2, dtype=torch.float32, device=DEV)
     cs = cs_wide[:, 8:8 + C]
     cs[..., 0] = sl.sum(1)
     cs[..., 1] = (sl * sl).sum(1)
+    st = h.groupnorm_stats_from_cols(cs, nimg=nimg, hw=hw, C_=C, eps=eps)
+    c64 = cs.double().cpu().reshape(nimg, hw // 64, 32, C // 32, 2).sum(dim=(1, 3))
+    cnt = hw * (C // 32)
+    mean = c64[..., 0] / cnt
+    rstd = 1.0 / torch.sqrt((c64[..., 1] / cnt - mean * mean).clamp_min(0) + eps)
+    assert torch.allclose(st[..., 0].cpu().double(), mean, rtol=1e-6, atol=1e-7)
+    assert torch.allclose(st[..., 1].cpu().double(), rstd, rtol=1e-6, atol=1e-7)
     g = rnd((C,), 12, torch.float32, 0.5).to(DEV) + 1.0
     b = rnd((C,), 13, torch.float32, 0.2).to(DEV)
-    y2 = torch.empty(nimg * hw, C, dtype=dt, device=DEV)
-    y1 = torch.empty_like(y2)
-    st = h.groupnorm_stats_from_cols(cs, nimg=nimg, hw=hw, C_=C, eps=eps)
-    h.groupnorm_apply(xin, st, g, b, y2, nimg=nimg, hw=hw, C_=C, ldx=C, ldy=C, silu=silu)
-    h.groupnorm_apply(xin, None, g, b, y1, nimg=nimg, hw=hw, C_=C, ldx=C, ldy=C, silu=silu, colstats=cs, eps=eps)
-    assert torch.equal(y1, y2)
-    ref = F.group_norm(xs.cpu().reshape(nimg, hw, C).permute(0, 2, 1), 32, g.cpu(), b.cpu(), eps)
-    ref = (F.silu(ref) if silu else ref).permute(0, 2, 1).reshape(nimg * hw, C)
-    assert rel_l2(y1.float().cpu(), ref) < TOL[dt]
-    # the folded coefficients of the fused-conv path come from the same sums
     ab = h.groupnorm_coeffs_from_cols(cs, g, b, nimg=nimg, hw=hw, C_=C, eps=eps)
-    a_ref = (st[..., 1].repeat_interleave(C // 32, 1) * g[None])
+    a_ref = st[..., 1].repeat_interleave(C // 32, 1) * g[None]
     assert torch.equal(ab[..., 0], a_ref)
+    assert torch.equal(ab[..., 1], b[None] - st[..., 0].repeat_interleave(C // 32, 1) * a_ref)
 
 
 @pytest.mark.gpu
@@ -1038,6 +1030,78 @@ def test_ffn_fused_vs_reference_and_vs_three_kernel_path(dt, M, C):
     print(f"ffn fused M={M} C={C} {dt}: fp32 out {e32:.2e}, 16-bit out {e16:.2e}; three-kernel path {e3:.2e}; fused vs three-kernel {e_vs3:.2e}")
     assert torch.equal(out16, out32.to(dt)), "the 16-bit output is the single rounding of the fp32 sum"
     assert e32 < TOL[dt] and e32 < 1.5 * e3 + 1e-5 and e_vs3 < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,C,hw,rows_full,nq_lo,want_ln", [(256, 64, 128, 256, 0, False), (768, 128, 256, 256, 256, True),
+                                                            (1024, 320, 256, 1024, 0, False), (3072, 320, 1024, 1024, 640, True),
+                                                            (128 * 300, 320, 128 * 100, 128 * 100, 640, False)])
+def test_st_front_vs_reference_and_vs_four_kernel_path(dt, M, C, hw, rows_full, nq_lo, want_ln):
+    """VERDICT r3 next #1a/b: GroupNorm-apply -> proj_in -> LayerNorm -> attn1 projection as one launch (csrc/stfront.hip,
+    ``vface_st_front``; attention.py:278-284, 239, 179-183).  Against an fp64 torch computation on the same 16-bit-rounded
+    operands (t0 < 2e-6: fp32 accumulation; qkv within the 16-bit bound), against the four launches it replaces (gn_apply, GEMM,
+    layernorm, GEMM), on column-sliced column statistics, with the hook's row split (rows >= rows_full project columns >= nq_lo
+    only and leave the others untouched), for one workgroup per token tile and for the persistent form (more tiles than CUs)."""
+    h = hip()
+    from vface_amd.packing import pack_st_front
+    nimg = M // hw
+    x = (rnd((M, C), 21, torch.float32, 1.3) + 0.25 * rnd((1, C), 22, torch.float32)).to(DEV)
+    w_in = rnd((C, C), 23, dt, 1 / math.sqrt(C))
+    b_in = rnd((C,), 24, torch.float32, 0.1)
+    w_p = rnd((3 * C, C), 25, dt, 1 / math.sqrt(C))
+    gng, gnb = rnd((C,), 26, torch.float32, 0.3) + 1.0, rnd((C,), 27, torch.float32, 0.2)
+    lng, lnb = rnd((C,), 28, torch.float32, 0.3) + 1.0, rnd((C,), 29, torch.float32, 0.2)
+    sl = x.reshape(M // 64, 64, C)
+    cs = torch.zeros(M // 64, C + 16, 2, dtype=torch.float32, device=DEV)[:, 8:8 + C]
+    cs[..., 0] = sl.sum(1)
+    cs[..., 1] = (sl * sl).sum(1)
+    ab = h.groupnorm_coeffs_from_cols(cs, gng.to(DEV), gnb.to(DEV), nimg=nimg, hw=hw, C_=C, eps=1e-6)
+    t0 = torch.zeros(M, C, dtype=torch.float32, device=DEV)
+    SENT = 7.0
+    qkv = torch.full((M, 3 * C + 8), SENT, dtype=dt, device=DEV)[:, :3 * C]       # a strided view: ldq = 3C + 8
+    ln = torch.zeros(M, C, dtype=dt, device=DEV) if want_ln else None
+    wcat = pack_st_front(w_in.float(), w_p.float()).to(dt).to(DEV)
+    h.st_front(x, ab, wcat, b_in.to(DEV), lng.to(DEV), lnb.to(DEV), t0, qkv, M=M, C_=C, hw=hw, NQ=3 * C, rows_full=rows_full,
+               nq_lo=nq_lo, ln=ln)
+    torch.cuda.synchronize()
+    # ---- fp64 reference on the same rounded operands
+    abc = ab.cpu().double()
+    a_row = abc[..., 0].repeat_interleave(hw, 0)
+    b_row = abc[..., 1].repeat_interleave(hw, 0)
+    y16 = (x.cpu() * a_row.float() + b_row.float()).to(dt).double()       # gn_apply's arithmetic: fp32 multiply-add, one rounding
+    t0_ref = y16 @ w_in.double().t() + b_in.double()
+    assert rel_l2(t0.cpu().double(), t0_ref) < 2e-6
+    t0d = t0.cpu().double()
+    mu = t0d.mean(1, keepdim=True)
+    var = ((t0d - mu) ** 2).mean(1, keepdim=True)
+    ln_ref = ((t0d - mu) / torch.sqrt(var + 1e-5) * lng.double() + lnb.double())
+    if want_ln:
+        assert rel_l2(ln.cpu().double(), ln_ref) < TOL[dt]
+    q_ref = ln_ref.to(dt).double() @ w_p.double().t()
+    got = qkv.cpu().double()
+    assert rel_l2(got[:rows_full], q_ref[:rows_full]) < TOL[dt]
+    if rows_full < M:
+        assert rel_l2(got[rows_full:, nq_lo:], q_ref[rows_full:, nq_lo:]) < TOL[dt]
+        assert (qkv[rows_full:, :nq_lo] == SENT).all()          # columns this row range does not project stay untouched
+    # ---- the four launches it replaces
+    st = h.groupnorm_stats_from_cols(cs, nimg=nimg, hw=hw, C_=C, eps=1e-6)
+    g16 = torch.empty(M, C, dtype=dt, device=DEV)
+    h.groupnorm_apply(x, st, gng.to(DEV), gnb.to(DEV), g16, nimg=nimg, hw=hw, C_=C, ldx=C, ldy=C, silu=False)
+    t0b = torch.empty(M, C, dtype=torch.float32, device=DEV)
+    h.gemm(g16, w_in.to(DEV), None, M=M, N=C, K=C, lda=C, ldc=0, bias=b_in.to(DEV), out32=t0b, rows_per_sample=hw)
+    assert rel_l2(t0.cpu(), t0b.cpu()) < 2e-6
+    l16 = torch.empty(M, C, dtype=dt, device=DEV)
+    h.layernorm(t0b, lng.to(DEV), lnb.to(DEV), l16, M=M, C_=C, ldx=C, ldy=C)
+    qb = torch.empty(M, 3 * C, dtype=dt, device=DEV)
+    h.gemm(l16, w_p.to(DEV), qb, M=M, N=3 * C, K=C, lda=C, ldc=3 * C)
+    assert rel_l2(got[:rows_full], qb.cpu().double()[:rows_full]) < 1.5 * TOL[dt]
+
+
+def test_st_front_rejects_what_it_cannot_run():
+    h = hip()
+    assert h.st_front_supported(1024, 320, 256) and h.st_front_supported(128, 64, 128)
+    assert not h.st_front_supported(1024, 640, 256) and not h.st_front_supported(1000, 320, 250) \
+        and not h.st_front_supported(1024, 320, 192)
 
 
 def test_ffn_fused_rejects_what_it_cannot_run():

@@ -187,14 +187,6 @@ int vface_groupnorm_apply(const void* x, int64_t ldx, const float* stats, const 
     return vf_launch_gn_apply(x, ldx, stats, gamma, beta, y, ldy, nimg, hw, C, groups, silu, in_f32, dtype, S(stream));
 }
 
-int vface_groupnorm_apply_from_cols(const void* x, int64_t ldx, const float* colstats, int64_t ld_colstats, float eps,
-                                    const float* gamma, const float* beta, void* y, int64_t ldy, int nimg, int hw, int C,
-                                    int groups, int silu, int in_f32, int dtype, void* stream) {
-    if (!colstats) return VFACE_ERR_ARG;
-    return vf_launch_gn_apply(x, ldx, nullptr, gamma, beta, y, ldy, nimg, hw, C, groups, silu, in_f32, dtype, S(stream),
-                              colstats, ld_colstats, eps);
-}
-
 int vface_flow_warp(const void* src, int64_t ld_src, int64_t fs_src, const void* prev, int64_t ld_prev,
                     const float* flow, const float* flow_prev, void* dst, int64_t ld_dst, int64_t fs_dst, int F,
                     int h, int w, int C, float alpha, float one_minus_alpha, int flags, int32_t* dbg_x0,
@@ -371,6 +363,18 @@ int vface_ffn_fused(const float* x32, int64_t ldx, const float* gamma, const flo
     p.x32 = x32; p.ldx = ldx; p.gamma = gamma; p.beta = beta; p.eps = eps; p.W1 = W1; p.b1 = b1; p.W2p = W2p; p.b2 = b2;
     p.out16 = out16; p.ldo = ldo; p.out32 = out32; p.ldo32 = ldo32; p.M = M; p.C = C;
     return vf_launch_ffn_fused(p, dtype, S(stream));
+}
+
+int vface_st_front_supported(int64_t M, int C, int hw) { return vf_st_front_supported((long)M, C, hw) ? 1 : 0; }
+
+int vface_st_front(const float* x32, int64_t ldx, const float* gn_ab, int64_t ld_ab, int hw, const void* Wcat, const float* b_in,
+                   const float* gamma, const float* beta, float eps, float* t0, int64_t ldt0, void* qkv, int64_t ldq, void* ln,
+                   int64_t ldln, int M, int C, int NQ, int rows_full, int nq_lo, int dtype, void* stream) {
+    StFrontParams p{};
+    p.x32 = x32; p.ldx = ldx; p.ab = gn_ab; p.ld_ab = ld_ab; p.hw = hw; p.Wcat = Wcat; p.b_in = b_in; p.gamma = gamma; p.beta = beta;
+    p.eps = eps; p.t0 = t0; p.ldt0 = ldt0; p.qkv = qkv; p.ldq = ldq; p.ln = ln; p.ldln = ldln; p.M = M; p.C = C; p.NQ = NQ;
+    p.rows_full = rows_full; p.nq_lo = nq_lo;
+    return vf_launch_st_front(p, dtype, S(stream));
 }
 
 int vface_temporal_gauss(const void* src, int64_t ld_src, int64_t fs_src, void* dst1, void* dst2, int64_t ld_dst,

@@ -136,6 +136,7 @@ __device__ __forceinline__ void raw_barrier() { __builtin_amdgcn_s_barrier(); }
 // it (guide 5.7 item 3) -- whereas this pins every producer of `x` above the nop and every consumer below it.
 template <class T> __device__ __forceinline__ void gap_mfma_result_to_valu(T& x) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(x)); }
 template <class T> __device__ __forceinline__ void gap_valu_result_to_mfma(T& x) { asm volatile("s_nop 3" : "+v"(x)); }
+template <class T> __device__ __forceinline__ void gap_valu_result_to_acc_mfma(T& x) { asm volatile("s_nop 3" : "+a"(x)); }   // v_accvgpr_write -> MFMA SrcC
 template <class T> __device__ __forceinline__ void gap_acc_result_to_valu(T& x) { asm volatile("s_nop 15\n\ts_nop 3" : "+a"(x)); }
 
 // One LDS-DMA instruction (16 bytes per lane, lane-linear LDS destination) as inline asm: through the builtin, hipcc treats the

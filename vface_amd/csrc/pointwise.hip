@@ -154,106 +154,97 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk
 
 // y = silu?( x * a[c] + b[c] ) with a = rstd * gamma, b = beta - mean * rstd * gamma held in registers per thread
 // (mean, rstd) from producer-side column statistics: colstats[slice][ld][2] with 64-row slices, hw % 64 == 0.
-// The summation ORDER is one definition shared by gn_finalize_cols, gn_coeffs_cols and the prologue of
-// gn_apply_kernel<.., COLS = true>, so the three paths agree bit for bit: per channel, the slices of the image in slice order;
-// per group, its channels in channel order; all in double.
-__device__ __forceinline__ void gn_channel_sums(const float* __restrict__ colstats, long ld, int spi, int img, int c,
-                                                double& s, double& q) {
-    const float* p = colstats + ((long)img * spi * ld + c) * 2;
+// ONE block of GN_FIN_T threads per image (round 4; before: one 64-thread block per (image, group) whose ten loads per lane and
+// double-precision butterfly made 5.9-7.9 us of pure latency, 61 times per UNet forward): thread = (channel, slice group), every
+// load of a thread issued before the first add -- one L2 round trip -- then a fixed-order combine through LDS.  The summation
+// ORDER is a function of (C, hw) only and is shared by gn_finalize_cols and gn_coeffs_cols (bit-identical statistics): per
+// channel and slice group sg, slices sg, sg + SG, .. in order; per group, channels in order, slice groups in order; all in double.
+constexpr int GN_FIN_T = 1024;
+__device__ __forceinline__ void gn_image_stats(const float* __restrict__ colstats, long ld, int hw, int C, int groups, float eps,
+                                               int img, double* __restrict__ part /* [SG][C][2] */, float* __restrict__ mr /* [groups][2] */) {
+    const int t = threadIdx.x, spi = hw / 64, cpg = C / groups;
+    const int SG = (GN_FIN_T / C) > 0 ? min(GN_FIN_T / C, spi) : 1;
+    const float* base = colstats + (long)img * spi * ld * 2;
     const long step = ld * 2;
-    s = 0.0; q = 0.0;
-    int sl = 0;
-    for (; sl + 8 <= spi; sl += 8) {      // eight independent loads in flight, added in slice order
-        float2 v[8];
+    for (int i = t; i < SG * C; i += GN_FIN_T) {
+        const int sg = i / C, c = i - sg * C;
+        const float* p = base + (long)c * 2;
+        double s = 0.0, q = 0.0;
+        int sl = sg;
+        for (; sl + 15 * SG < spi; sl += 16 * SG) {        // sixteen loads in flight, added in slice order
+            float2 v[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2*>(p + (long)(sl + u) * step);
+            for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float2*>(p + (long)(sl + u * SG) * step);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { s += v[u].x; q += v[u].y; }
+            for (int u = 0; u < 16; ++u) { s += v[u].x; q += v[u].y; }
+        }
+        for (; sl + 3 * SG < spi; sl += 4 * SG) {
+            float2 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float2*>(p + (long)(sl + u * SG) * step);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s += v[u].x; q += v[u].y; }
+        }
+        for (; sl < spi; sl += SG) {
+            const float2 v = *reinterpret_cast<const float2*>(p + (long)sl * step);
+            s += v.x; q += v.y;
+        }
+        part[(long)i * 2] = s; part[(long)i * 2 + 1] = q;
     }
-    for (; sl < spi; ++sl) {
-        const float2 v = *reinterpret_cast<const float2*>(p + (long)sl * step);
-        s += v.x; q += v.y;
-    }
-}
-
-__device__ __forceinline__ void gn_group_finish(const double* __restrict__ chs, const double* __restrict__ chq, int cpg, int hw,
-                                                float eps, float& meanf, float& rstdf) {
-    double s = 0.0, q = 0.0;
-    for (int c = 0; c < cpg; ++c) { s += chs[c]; q += chq[c]; }
-    const double count = (double)hw * cpg;
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    meanf = (float)mean;
-    rstdf = (float)(1.0 / sqrt(var + (double)eps));
-}
-
-constexpr int GN_MAX_CPG = 256;   // channels per group the one-block-per-group kernels take (C <= 8192 at 32 groups)
-
-__global__ __launch_bounds__(64) void gn_finalize_cols_kernel(const float* __restrict__ colstats, long ld, int hw, int C,
-                                                              int groups, float eps, float* __restrict__ stats) {
-    const int img = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
-    const int cpg = C / groups, spi = hw / 64;
-    __shared__ double chs[GN_MAX_CPG], chq[GN_MAX_CPG];
-    for (int c = lane; c < cpg; c += 64) gn_channel_sums(colstats, ld, spi, img, g * cpg + c, chs[c], chq[c]);
     __syncthreads();
-    if (lane == 0) {
-        float meanf, rstd;
-        gn_group_finish(chs, chq, cpg, hw, eps, meanf, rstd);
-        stats[((long)img * groups + g) * 2] = meanf;
-        stats[((long)img * groups + g) * 2 + 1] = rstd;
+    if (t < groups) {
+        double s = 0.0, q = 0.0;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c)
+            for (int sg = 0; sg < SG; ++sg) { s += part[((long)sg * C + c) * 2]; q += part[((long)sg * C + c) * 2 + 1]; }
+        const double count = (double)hw * cpg;
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mr[2 * t] = (float)mean;
+        mr[2 * t + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(GN_FIN_T) void gn_finalize_cols_kernel(const float* __restrict__ colstats, long ld, int hw, int C,
+                                                                    int groups, float eps, float* __restrict__ stats) {
+    extern __shared__ double gn_part[];
+    __shared__ float mr[128];
+    const int img = blockIdx.x;
+    gn_image_stats(colstats, ld, hw, C, groups, eps, img, gn_part, mr);
+    if ((int)threadIdx.x < 2 * groups) stats[(long)img * groups * 2 + threadIdx.x] = mr[threadIdx.x];
 }
 
 // gn_finalize_cols + the per-channel scale / shift of gn_apply in one launch: ab[img][c] = (rstd * gamma[c], beta[c] - mean * a) --
-// bit for bit the a[j], b[j] gn_apply_kernel forms, so a convolution that applies them to its operand in LDS (conv.hip) sees
-// exactly what the separate normalisation pass would have stored.
-__global__ __launch_bounds__(64) void gn_coeffs_cols_kernel(const float* __restrict__ colstats, long ld, int hw, int C, int groups,
-                                                            float eps, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ ab) {
-    const int img = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
-    const int cpg = C / groups, spi = hw / 64;
-    __shared__ double chs[GN_MAX_CPG], chq[GN_MAX_CPG];
-    __shared__ float mr[2];
-    for (int c = lane; c < cpg; c += 64) gn_channel_sums(colstats, ld, spi, img, g * cpg + c, chs[c], chq[c]);
-    __syncthreads();
-    if (lane == 0) gn_group_finish(chs, chq, cpg, hw, eps, mr[0], mr[1]);
-    __syncthreads();
-    const float meanf = mr[0], rstd = mr[1];
-    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
-        const float a = rstd * gamma[c];
-        *reinterpret_cast<float2*>(ab + ((long)img * C + c) * 2) = make_float2(a, beta[c] - meanf * a);
+// bit for bit the a[j], b[j] gn_apply_kernel forms, so a kernel that applies them to its operand itself (conv.hip's fused
+// GroupNorm, stfront.hip) sees exactly what the separate normalisation pass would have stored.
+__global__ __launch_bounds__(GN_FIN_T) void gn_coeffs_cols_kernel(const float* __restrict__ colstats, long ld, int hw, int C, int groups,
+                                                                  float eps, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ ab) {
+    extern __shared__ double gn_part[];
+    __shared__ float mr[128];
+    const int img = blockIdx.x, cpg = C / groups;
+    gn_image_stats(colstats, ld, hw, C, groups, eps, img, gn_part, mr);
+    for (int c = threadIdx.x; c < C; c += GN_FIN_T) {
+        const int g = c / cpg;
+        const float a = mr[2 * g + 1] * gamma[c];
+        *reinterpret_cast<float2*>(ab + ((long)img * C + c) * 2) = make_float2(a, beta[c] - mr[2 * g] * a);
     }
 }
 
-// COLS: `stats` is the producer's column statistics (ld_cs pairs per slice row) and the workgroup forms the (mean, rstd) of its
-// image's groups itself, in LDS, before the pixel loop -- the gn_finalize_cols launch between a producer and its GroupNorm
-// (61 launches of ~6-8 us per UNet forward, pure latency) disappears.  Each of the four waves takes groups/4 groups; the
-// colstats of one image are 8 * C * hw / 64 bytes, read from L2: thread = channel (coalesced rows of the slice matrix), then one
-// thread per group sums its channels from LDS (dynamic shared memory: 16 * C bytes).
-template <class TT, bool IN32, bool COLS>
+template <class TT, bool IN32>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ x, long ldx,
                                                        const float* __restrict__ stats,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        typename TT::elem* __restrict__ y, long ldy, int hw, int C,
-                                                       int groups, int silu, int pix_per_block, long ld_cs, float eps) {
+                                                       int groups, int silu, int pix_per_block) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
     const int img = blockIdx.y, t = threadIdx.x;
     const int c8 = C / 8, cpg = C / groups;
     const int p0 = blockIdx.x * pix_per_block, p1 = min(hw, p0 + pix_per_block);
-    __shared__ float s_st[128];
-    extern __shared__ double s_ch[];      // COLS: [2][C]
     const float* st = stats + (long)img * groups * 2;
-    if constexpr (COLS) {
-        const int spi = hw / 64;
-        for (int c = t; c < C; c += 256) gn_channel_sums(stats, ld_cs, spi, img, c, s_ch[c], s_ch[C + c]);
-        __syncthreads();
-        if (t < groups) gn_group_finish(s_ch + t * cpg, s_ch + C + t * cpg, cpg, hw, eps, s_st[2 * t], s_st[2 * t + 1]);
-        __syncthreads();
-        st = s_st;
-    }
     const long xb = (long)img * hw * ldx;
     E* yb = y + (long)img * hw * ldy;
     const int CPB = min(c8, 256), PP = 256 / CPB;
@@ -823,21 +814,27 @@ int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int gro
     return ok();
 }
 
+static size_t gn_fin_lds(int C, int hw) {
+    const int spi = hw / 64;
+    int sg = GN_FIN_T / C;
+    if (sg < 1) sg = 1;
+    if (sg > spi) sg = spi;
+    return (size_t)sg * C * 2 * sizeof(double);
+}
+
 int vf_launch_gn_coeffs_cols(const float* colstats, long ld, int nimg, int hw, int C, int groups, float eps, const float* gamma,
                              const float* beta, float* ab, hipStream_t stream) {
     if (!colstats || !gamma || !beta || !ab || nimg <= 0 || hw <= 0 || C <= 0 || groups <= 0) return VF_ERR_ARG;
-    if ((hw & 63) || groups > 64 || C % groups || (ld & 1) || C / groups > GN_MAX_CPG) return VF_ERR_SHAPE;
-    hipLaunchKernelGGL(gn_coeffs_cols_kernel, dim3(groups, nimg), dim3(64), 0, stream, colstats, ld, hw, C, groups, eps, gamma, beta, ab);
+    if ((hw & 63) || groups > 64 || C % groups || ld < C || C > 3840) return VF_ERR_SHAPE;
+    hipLaunchKernelGGL(gn_coeffs_cols_kernel, dim3(nimg), dim3(GN_FIN_T), gn_fin_lds(C, hw), stream, colstats, ld, hw, C, groups, eps, gamma, beta, ab);
     return ok();
 }
 
 int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y,
-                       long ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype, hipStream_t stream,
-                       const float* colstats, long ld_cs, float eps) {
-    if (!x || (!stats && !colstats) || !gamma || !beta || !y || nimg <= 0 || hw <= 0) return VF_ERR_ARG;
+                       long ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype, hipStream_t stream) {
+    if (!x || !stats || !gamma || !beta || !y || nimg <= 0 || hw <= 0) return VF_ERR_ARG;
     if ((C & 7) || (ldx & (in_f32 ? 3 : 7)) || (ldy & 7) || (((uintptr_t)x | (uintptr_t)y) & 15)) return VF_ERR_ALIGN;
     if (groups > 64 || C % groups) return VF_ERR_SHAPE;
-    if (colstats && ((hw & 63) || ld_cs < C || ((uintptr_t)colstats & 7) || C > 4096)) return VF_ERR_SHAPE;
     // enough workgroups to fill 256 CUs several times over, but long enough pixel loops to amortise the
     // per-thread scale/shift set-up
     int ppb = 128;
@@ -845,13 +842,8 @@ int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float*
     dim3 grid((hw + ppb - 1) / ppb, nimg);
     DISPATCH_DTYPE(dtype, {
         using E = typename TT::elem;
-        if (colstats) {
-            if (in_f32) hipLaunchKernelGGL((gn_apply_kernel<TT, true, true>), grid, dim3(256), (size_t)C * 16, stream, x, ldx, colstats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb, ld_cs, eps);
-            else hipLaunchKernelGGL((gn_apply_kernel<TT, false, true>), grid, dim3(256), (size_t)C * 16, stream, x, ldx, colstats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb, ld_cs, eps);
-        } else {
-            if (in_f32) hipLaunchKernelGGL((gn_apply_kernel<TT, true, false>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb, 0L, 0.f);
-            else hipLaunchKernelGGL((gn_apply_kernel<TT, false, false>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb, 0L, 0.f);
-        }
+        if (in_f32) hipLaunchKernelGGL((gn_apply_kernel<TT, true>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
+        else hipLaunchKernelGGL((gn_apply_kernel<TT, false>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
     });
     return ok();
 }
@@ -1036,7 +1028,7 @@ int vf_launch_adain(const void* a, long lda, const void* b, long ldb, void* dst,
 int vf_launch_gn_finalize_cols(const float* colstats, long ld, int nimg, int hw, int C, int groups, float eps, float* stats,
                                hipStream_t stream) {
     if (!colstats || !stats || nimg <= 0 || hw <= 0 || C <= 0 || groups <= 0) return VF_ERR_ARG;
-    if ((hw & 63) || (C % groups) || ld < C || C / groups > GN_MAX_CPG) return VF_ERR_SHAPE;
-    hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(groups, nimg), dim3(64), 0, stream, colstats, ld, hw, C, groups, eps, stats);
+    if ((hw & 63) || groups > 64 || (C % groups) || ld < C || C > 3840) return VF_ERR_SHAPE;
+    hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(nimg), dim3(GN_FIN_T), gn_fin_lds(C, hw), stream, colstats, ld, hw, C, groups, eps, stats);
     return ok();
 }

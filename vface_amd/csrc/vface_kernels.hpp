@@ -102,6 +102,24 @@ struct FfnParams {
 bool vf_ffn_fused_supported(long M, int C);
 int vf_launch_ffn_fused(const FfnParams& p, int dtype, hipStream_t stream);
 
+// stfront.hip: GroupNorm-apply -> proj_in -> (t0 out) -> LayerNorm -> attn1 projection, one launch; C in {64, 128, 320}
+struct StFrontParams {
+    const float* x32; long ldx;      // [M][C] fp32: the SpatialTransformer's input (residual-stream carrier)
+    const float* ab; long ld_ab;     // GroupNorm (scale, shift) pairs [nimg][ld_ab][2] (vface_groupnorm_coeffs_from_cols)
+    int hw;                          // rows per image (a multiple of 128)
+    const void* Wcat;                // [C + NQ][C] 16-bit: proj_in rows, then the projection rows with k columns in ffn_w2_perm order
+    const float* b_in;               // [C] proj_in bias
+    const float* gamma; const float* beta; float eps;   // norm1
+    float* t0; long ldt0;            // [M][C] fp32 out: proj_in(GroupNorm(x)) + bias
+    void* qkv; long ldq;             // [M][ldq] 16-bit out: projection column j at qkv[:, j]
+    void* ln; long ldln;             // optional [M][C] 16-bit out: LayerNorm(t0)
+    int M, C, NQ;
+    int rows_full, nq_lo;            // rows [0, rows_full): projection columns [0, NQ); the other rows: columns [nq_lo, NQ)
+    int gridA;                       // filled by the launcher
+};
+bool vf_st_front_supported(long M, int C, int hw);
+int vf_launch_st_front(const StFrontParams& p, int dtype, hipStream_t stream);
+
 struct AttnParams {
     const void* Q; const void* K; const void* V;  // [B][n][ld*], head h at column h*dh
     long ldq, ldk, ldv;           // row (token) strides in elements
@@ -127,10 +145,8 @@ int vf_launch_gn_coeffs_cols(const float* colstats, long ld, int nimg, int hw, i
 int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int groups, float eps, float* partial,
                        float* stats, int in_f32, int dtype, hipStream_t stream);
 int vf_gn_partial_floats(int nimg, int hw, int C, int groups);
-// colstats != nullptr: the statistics are formed inside the launch from producer-side column sums (stats is then unused)
 int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float* gamma, const float* beta, void* y,
-                       long ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype, hipStream_t stream,
-                       const float* colstats = nullptr, long ld_cs = 0, float eps = 0.f);
+                       long ldy, int nimg, int hw, int C, int groups, int silu, int in_f32, int dtype, hipStream_t stream);
 int vf_launch_flow_warp(const void* src, long ld_src, long fs_src, const void* prev, long ld_prev,
                         const float* flow, const float* flow_prev, void* dst, long ld_dst, long fs_dst, int F, int h,
                         int w, int C, float alpha, float one_minus_alpha, int flags, int* dbg_x0, int* dbg_y0, int dtype,

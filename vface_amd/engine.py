@@ -380,6 +380,11 @@ class UNetEngine:
         # norm3 + FeedForward of the level-0 transformer blocks (C = 320; also the 64- / 128-channel test models) as one
         # activation-stationary kernel (csrc/ffn.hip).  VFACE_FUSE_FFN=0: the three-kernel path (A/B switch).
         self.fuse_ffn = os.environ.get("VFACE_FUSE_FFN", "1") != "0"
+        # GroupNorm-apply -> proj_in -> LayerNorm -> attn1 projection of the level-0 SpatialTransformers (C = 320; also the 64- /
+        # 128-channel test models) as one activation-stationary kernel (csrc/stfront.hip): four launches and four HBM round trips
+        # of the token matrix less per block.  VFACE_FUSE_FRONT=0: the separate launches (A/B switch).
+        self.fuse_front = os.environ.get("VFACE_FUSE_FRONT", "1") != "0"
+        self._front_supported: Dict[tuple, bool] = {}
         self._ffn_supported: Dict[tuple, bool] = {}
         self.decompose_attn1 = False                   # bench.py's instrumented pass: vface_attn1_forward's launches call by call
         # fp32 residual stream: residual sums are carried between kernels in fp32, 16-bit copies exist only
@@ -392,9 +397,6 @@ class UNetEngine:
         # the ~70 vector instructions per 1-KiB patch piece sit in the K-tile period's critical path -- 28.22 vs 27.49 ms per
         # DDIM step (conv 9.46 vs 7.77 ms, gn_apply 0 vs 1.0 ms), DESIGN 4 -- so it is opt-in.
         self.fuse_gn = os.environ.get("VFACE_FUSE_GN", "off")
-        # GroupNorm statistics formed inside the normalisation launch (vface_groupnorm_apply_from_cols) instead of by a
-        # gn_finalize_cols launch between the producer and its GroupNorm: same bits.  VFACE_FOLD_GN_STATS=0: two launches (A/B).
-        self.fold_gn_stats = os.environ.get("VFACE_FOLD_GN_STATS", "1") != "0"
         # hipGraph replay of the UNet forward of a DDIM step (step_forward_nhwc): capture once per (batch, resolution, hook
         # configuration, context shape) and replay -- the default since round 3 (bit-equal to kernel-by-kernel launches, one
         # host call per step instead of ~1200; what bench.py times); VFACE_GRAPH=0 launches kernel by kernel.  The C ABI is
@@ -520,6 +522,13 @@ class UNetEngine:
         d.update({"gn": (self._f32(sd[prefix + ".norm.weight"]), self._f32(sd[prefix + ".norm.bias"])),
                   "proj_in": self.pack_lin(sd, prefix + ".proj_in", conv=True),
                   "proj_out": self.pack_lin(sd, prefix + ".proj_out", conv=True)})
+        c = d["c"]
+        d["front_w"] = None
+        if self.fuse_front and hip.st_front_supported(128, c, 128):      # (the widths csrc/stfront.hip takes)
+            t = prefix + ".transformer_blocks.0.attn1"
+            w_in = sd[prefix + ".proj_in.weight"].detach().float().cpu().reshape(c, c)
+            w_p = packing.pack_qkv(sd[t + ".to_q.weight"], sd[t + ".to_k.weight"], sd[t + ".to_v.weight"]).detach().float().cpu()
+            d["front_w"] = self._w16(packing.pack_st_front(w_in, w_p))
         return d
 
     def _param_version(self):
@@ -585,16 +594,11 @@ class UNetEngine:
 
     def _gn(self, x: Act, gn, eps: float, silu: bool) -> Act:
         src = x.src
-        y = self._new(x.M, x.C)
-        if x.cs is not None and self.fold_gn_stats:
-            # statistics from the producer's column sums INSIDE the normalisation launch (no finalize launch in between)
-            hip.groupnorm_apply(src, None, gn[0], gn[1], y, nimg=x.N, hw=x.hw, C_=x.C, ldx=src.stride(0), ldy=x.C, silu=silu,
-                                colstats=x.cs, eps=eps)
-            return Act(y, x.N, x.H, x.W)
         if x.cs is not None:
             st = hip.groupnorm_stats_from_cols(x.cs, nimg=x.N, hw=x.hw, C_=x.C, eps=eps)
         else:
             st = hip.groupnorm_stats(src, nimg=x.N, hw=x.hw, C_=x.C, ldx=src.stride(0), eps=eps)
+        y = self._new(x.M, x.C)
         hip.groupnorm_apply(src, st, gn[0], gn[1], y, nimg=x.N, hw=x.hw, C_=x.C, ldx=src.stride(0), ldy=x.C, silu=silu)
         return Act(y, x.N, x.H, x.W)
 
@@ -795,6 +799,11 @@ class UNetEngine:
             raise hip.VFaceHipError("attn1.forward was replaced by a closure this engine does not know; use "
                                     "vface_amd.ldm.models.pnp_utils.register_spa_attn_injection")
         t1 = self._attn1(ln, t0, p, cfg, a2vec, N, n, attn1.heads, hw)
+        return self._ffn(t1, p, n, want32)
+
+    def _ffn(self, t1: torch.Tensor, p: dict, n: int, want32: bool = False):
+        """``x + ff(norm3(x))`` (attention.py:243) on the block's running sum ``t1`` (fp32 with the residual stream, else 16-bit)."""
+        c, M = p["c"], t1.shape[0]
         t2 = self._new(M, c)
         t2_32 = self._new(M, c, torch.float32) if want32 else None
         if self.fuse_ffn and t1.dtype == torch.float32 and p["ff2p"] is not None and self._ffn_ok(M, c):
@@ -802,11 +811,96 @@ class UNetEngine:
             hip.ffn_fused(t1, p["ln3"][0], p["ln3"][1], p["ff1"]["w"], p["ff1"]["b"], p["ff2p"], p["ff2"]["b"], t2, M=M, C_=c,
                           out32=t2_32)
             return (t2, t2_32) if want32 else t2
+        ln = self._new(M, c)
         hip.layernorm(t1, p["ln3"][0], p["ln3"][1], ln, M=M, C_=c, ldx=c, ldy=c)
         ff = self._new(M, 4 * c)
         hip.gemm(ln, p["ff1"]["w"], ff, M=M, N=8 * c, K=c, lda=c, ldc=4 * c, bias=p["ff1"]["b"], flags=hip.EPI_GEGLU)
         self._gemm(ff, p["ff2"], t2, hw=n, out32=t2_32, **self._resid(t1))
         return (t2, t2_32) if want32 else t2
+
+    def _st_front(self, x: Act, p: dict, attn1, a2vec: torch.Tensor) -> Optional[torch.Tensor]:
+        """The SpatialTransformer up to and including its transformer block, with the FRONT -- GroupNorm-apply, proj_in,
+        LayerNorm (norm1) and attn1's projection -- as ONE launch (csrc/stfront.hip) instead of four: needs the fp32 carrier
+        and the producer's column statistics of ``x`` and a width the kernel takes.  Returns the block's last running sum
+        (16-bit, proj_out's operand), or None when this layer does not qualify (the caller then runs the separate launches).
+        What follows the front is the launch sequence of ``vface_attn1_forward`` (capi.cpp) minus its first two GEMMs: the
+        dual-source projections of the hook's linear fusions (they read the LayerNorm output the front also writes then), the flow
+        warp -- with the boundary exchange between chunk 1's fused projection and the warp when frames are sharded --, the
+        attention kernel, the out-projection into the fp32 stream, then norm3 + FeedForward."""
+        c, N, n, M = p["c"], x.N, x.hw, x.M
+        if not self.fuse_front or p.get("front_w") is None or x.t32 is None or x.cs is None:
+            return None
+        key = (M, c, n)
+        ok = self._front_supported.get(key)
+        if ok is None:
+            ok = self._front_supported[key] = bool(hip.st_front_supported(M, c, n))
+        if not ok:
+            return None
+        cfg = getattr(attn1, "_vface_cfg", None)
+        fw = attn1.__dict__.get("forward")
+        if fw is not None and not getattr(fw, "_vface", False):
+            raise hip.VFaceHipError("attn1.forward was replaced by a closure this engine does not know; use "
+                                    "vface_amd.ldm.models.pnp_utils.register_spa_attn_injection")
+        pl = plan_fusion(cfg, N, n, self.halo_hw if self.halo_exchange is not None else None)
+        if pl["staged"]:
+            return None      # "temporal" / "adaIn" edit a full q,k,v buffer with their own kernels
+        d, heads = c, attn1.heads
+        fusion, chunks, flow, alpha, v_fixed = pl["fusion"], pl["chunks"], pl["flow"], pl["alpha"], pl["v_fixed"]
+        F_ = N // chunks
+        Fn = F_ * n
+        hw = pl["warp_hw"]
+        sharded = hw is not None and self.halo_exchange is not None
+        if hw is None:
+            flow = None
+        ab = hip.groupnorm_coeffs_from_cols(x.cs, p["gn"][0], p["gn"][1], nimg=N, hw=n, C_=c, eps=1e-6)
+        t0 = self._new(M, c, torch.float32)
+        qkv = self._new(M, 3 * d)
+        ln = self._new(M, c) if fusion == hip.FUSION_LINEAR else None
+        hip.st_front(x.t32, ab, p["front_w"], p["proj_in"]["b"], p["ln1"][0], p["ln1"][1], t0, qkv, M=M, C_=c, hw=n, NQ=3 * d,
+                     rows_full=M if fusion == hip.FUSION_NONE else Fn, nq_lo=0 if fusion == hip.FUSION_NONE else 2 * d, ln=ln)
+        if fusion == hip.FUSION_LINEAR:
+            wlin = self._wlin(p, *pl["wlin"])
+            ldl = ln.stride(0)
+
+            def fused(ch, dst):
+                hip.gemm(ln[ch * Fn:], wlin, dst, M=Fn, N=2 * d, K=2 * d, lda=ldl, ldc=dst.stride(0), ldw=2 * d, a2=ln, lda2=ldl, k1=d,
+                         split_k=False)
+            T = self._new(Fn, 2 * d) if (flow is not None or sharded) else None
+            halo = None
+            if sharded:
+                fused(1, T)
+                handle = self.halo_exchange.start_exchange(T[(F_ - 1) * n:])
+                for ch in range(2, chunks):
+                    fused(ch, qkv[ch * Fn:(ch + 1) * Fn, :2 * d])
+                ev = self.exchange_events if not isinstance(self.halo_exchange, _GraphSegments) else None
+                if ev is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                halo = self.halo_exchange.finish_exchange(handle)
+                if ev is not None:
+                    e1.record()
+                    ev.append((e0, e1))
+            else:
+                for ch in range(1, chunks):
+                    fused(ch, T if (T is not None and ch == 1) else qkv[ch * Fn:(ch + 1) * Fn, :2 * d])
+            if T is not None:
+                hip.flow_warp(T, qkv[Fn:2 * Fn, :2 * d], flow, F=F_, h=hw[0], w=hw[1], C_=2 * d, ld_src=2 * d, fs_src=n * 2 * d,
+                              ld_dst=3 * d, fs_dst=n * 3 * d, alpha=alpha, prev=halo, ld_prev=2 * d,
+                              flow_prev=self.halo_flow if halo is not None else None)
+        att = self._new(M, d)
+        kw = dict(heads=heads, n=n, nk=n, dh=d // heads, ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d,
+                  bsv=n * 3 * d, ldo=d, bso=n * d,
+                  scale=float(np.float32(1.0) / np.sqrt(np.float32(d // heads))))   # fp32 arithmetic, as capi.cpp computes it
+        v_map = self._map("v_fixed", N, F_) if v_fixed else None
+        if fusion == hip.FUSION_REPLACE and hip.load().vface_attention_shared_scores_supported(d // heads, chunks):
+            hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=F_, v_map=v_map, v_sets=chunks, set_stride=F_, **kw)
+        else:
+            hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=N,
+                          qk_map=self._map("qk_replace", N, F_) if fusion == hip.FUSION_REPLACE else None, v_map=v_map, **kw)
+        t1 = self._new(M, c, torch.float32)
+        hip.gemm(att, p["wo"]["w"], None, M=M, N=d, K=d, lda=d, ldc=0, bias=p["wo"]["b"], rowbias=a2vec, rows_per_sample=n,
+                 split_k=False, residual32=t0, out32=t1)
+        return self._ffn(t1, p, n)
 
     def _ffn_ok(self, M: int, c: int) -> bool:
         """``vface_ffn_fused_supported`` per (rows, width), asked once (a ctypes call per block per forward otherwise)."""
@@ -822,6 +916,12 @@ class UNetEngine:
         only -- LayerNorm and the next residual add read that; its last value feeds proj_out as a 16-bit operand."""
         N, n, c = x.N, x.hw, p["c"]
         s32 = self.stream32 and c % 8 == 0
+        a, b = p["a2_slice"]
+        t2 = self._st_front(x, p, mod.transformer_blocks[0].attn1, a2_all[:, a:b]) if s32 else None
+        if t2 is not None:
+            out, cs, o32 = self._new_target(x.M, c, x.hw) if tgt is None else tgt
+            self._gemm(t2, p["proj_out"], out, colstats=cs, hw=x.H * x.W, out32=o32, **self._resid(x))
+            return Act(out, x.N, x.H, x.W, cs, o32)
         g = self._gn(x, p["gn"], 1e-6, False)
         t0 = self._new(x.M, c, torch.float32 if s32 else None)
         if s32:
@@ -986,7 +1086,7 @@ class UNetEngine:
                                              None if self.halo_flow is None else tuple(self.halo_flow.shape))
         # (every switch that changes the captured launch sequence is part of the key: toggling one on a live engine must not
         # replay a stale graph)
-        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fold_gn_stats,
+        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front,
                self.decompose_attn1, self.exchange_events is not None, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)

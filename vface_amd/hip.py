@@ -63,8 +63,6 @@ SIGNATURES = {
     "vface_groupnorm_stats": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _i32, _i32, _vp]),
     "vface_groupnorm_coeffs_from_cols": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "vface_groupnorm_apply": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "vface_groupnorm_apply_from_cols": (C.c_int, [_vp, _i64, _vp, _i64, _f32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32,
-                                                  _i32, _vp]),
     "vface_flow_warp": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _f32,
                                   _f32, _i32, _vp, _vp, _i32, _vp]),
     "vface_flow_to_latent": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
@@ -88,6 +86,9 @@ SIGNATURES = {
                                       _vp, _vp, _sz, _vp, _i32, _vp, _s32p]),
     "vface_ffn_fused_supported": (C.c_int, [_i64, _i32]),
     "vface_ffn_fused": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "vface_st_front_supported": (C.c_int, [_i64, _i32, _i32]),
+    "vface_st_front": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32,
+                                 _i32, _i32, _i32, _vp]),
     "vface_temporal_gauss": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp]),
     "vface_adain_workspace_bytes": (_sz, [_i64, _i32]),
     "vface_adain_fusion": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _vp, _sz, _i32, _vp]),
@@ -292,17 +293,8 @@ def groupnorm_coeffs_from_cols(colstats: torch.Tensor, gamma: torch.Tensor, beta
     return ab
 
 
-def groupnorm_apply(x: torch.Tensor, stats: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor,
-                    *, nimg: int, hw: int, C_: int, ldx: int, ldy: int, groups: int = 32, silu: bool = False,
-                    colstats: Optional[torch.Tensor] = None, eps: float = 1e-5):
-    """``colstats`` (the producer's column sums, ``[nimg*hw/64, C(view), 2]`` fp32) instead of ``stats``: statistics and
-    normalisation in one launch (``vface_groupnorm_apply_from_cols``)."""
-    if colstats is not None:
-        rc = load().vface_groupnorm_apply_from_cols(_p(x), ldx, _p(colstats), colstats.stride(0) // 2, eps, _p(gamma), _p(beta),
-                                                    _p(out), ldy, nimg, hw, C_, groups, int(silu),
-                                                    int(x.dtype == torch.float32), dtype_code(out.dtype), _stream())
-        _check(rc, "vface_groupnorm_apply_from_cols")
-        return
+def groupnorm_apply(x: torch.Tensor, stats: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor,
+                    *, nimg: int, hw: int, C_: int, ldx: int, ldy: int, groups: int = 32, silu: bool = False):
     rc = load().vface_groupnorm_apply(_p(x), ldx, _p(stats), _p(gamma), _p(beta), _p(out), ldy, nimg, hw, C_, groups,
                                       int(silu), int(x.dtype == torch.float32), dtype_code(out.dtype), _stream())
     _check(rc, "vface_groupnorm_apply")
@@ -483,6 +475,23 @@ def attn1_forward(x, wqkv, wlin, wo, bo, out, *, B, n, d, heads, chunks, fusion,
 
 def ffn_fused_supported(M: int, C_: int) -> bool:
     return bool(load().vface_ffn_fused_supported(M, C_))
+
+
+def st_front_supported(M: int, C_: int, hw: int) -> bool:
+    return bool(load().vface_st_front_supported(M, C_, hw))
+
+
+def st_front(x32: torch.Tensor, gn_ab: torch.Tensor, wcat: torch.Tensor, b_in: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+             t0: torch.Tensor, qkv: torch.Tensor, *, M: int, C_: int, hw: int, NQ: int, rows_full: int, nq_lo: int = 0,
+             ln: Optional[torch.Tensor] = None, eps: float = 1e-5):
+    """GroupNorm-apply -> proj_in (-> ``t0`` fp32) -> LayerNorm -> attn1 projection (-> ``qkv`` 16-bit) in one launch
+    (csrc/stfront.hip).  ``gn_ab``: ``groupnorm_coeffs_from_cols`` of the producer of ``x32``; ``wcat``: ``packing.pack_st_front``."""
+    if x32.dtype != torch.float32 or t0.dtype != torch.float32 or gn_ab.dtype != torch.float32:
+        raise VFaceHipError("st_front: x32, t0 and gn_ab are fp32")
+    rc = load().vface_st_front(_p(x32), x32.stride(0), _p(gn_ab), gn_ab.stride(0) // 2, hw, _p(wcat), _p(b_in), _p(gamma), _p(beta), eps,
+                               _p(t0), t0.stride(0), _p(qkv), qkv.stride(0), _p(ln) if ln is not None else None,
+                               ln.stride(0) if ln is not None else 0, M, C_, NQ, rows_full, nq_lo, dtype_code(qkv.dtype), _stream())
+    _check(rc, "vface_st_front")
 
 
 def ffn_fused_width_supported(C_: int) -> bool:

@@ -92,6 +92,15 @@ def pack_ffn_w2(w2: torch.Tensor) -> torch.Tensor:
     return w2[:, ffn_w2_perm(w2.shape[1])].contiguous()
 
 
+def pack_st_front(w_in: torch.Tensor, w_proj: torch.Tensor) -> torch.Tensor:
+    """Weights of the fused SpatialTransformer front (csrc/stfront.hip): ``proj_in`` rows ``[C, C]`` (its k index is the channel,
+    as the GroupNorm'd activations are read), then the attn1 projection rows ``[NQ, C]`` with their k columns in ``ffn_w2_perm``
+    order -- the order in which the LayerNorm'd accumulator tile of ``proj_in`` becomes that GEMM's B operand."""
+    c = w_in.shape[0]
+    assert w_in.shape == (c, c) and w_proj.shape[1] == c
+    return torch.cat([w_in, w_proj[:, ffn_w2_perm(c)]], 0).contiguous()
+
+
 def pack_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor) -> torch.Tensor:
     return torch.cat([wq, wk, wv], 0).contiguous()
 
