@@ -182,6 +182,10 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontParams p) {
                 for (int j = 0; j < 8; ++j) o[j] = from_f32<E>(v[ks][j] * am[j] + bm[j]);
                 xf[ks] = o;
             }
+            // EVERY fragment's conversion stays above this point: hipcc otherwise sinks them between the inline-asm MFMAs of the
+            // first stage, whose operand reads it cannot see (a v_cvt_pk one instruction ahead of the MFMA that reads its result)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xf[ks]));
             gap_valu_result_to_mfma(xf[KS - 1]);
         }
         // ---- IN: proj_in, one output-channel tile per stage; the bias is the accumulator's initial value
@@ -267,6 +271,8 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontParams p) {
                     }
                 }
             }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xf[ks]));
             gap_valu_result_to_mfma(xf[KS - 1]);
         }
         // ---- Q: the projection, one 32-column tile per stage
