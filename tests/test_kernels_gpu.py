@@ -425,10 +425,10 @@ def test_conv_colstats_feed_groupnorm(N_, cout):
 
 @pytest.mark.parametrize("C,H,nimg,eps", [(320, 64, 3, 1e-5), (640, 32, 2, 1e-5), (1280, 8, 5, 1e-6), (2560, 16, 2, 1e-5),
                                           (64, 8, 1, 1e-5), (1920, 32, 1, 1e-5)])
-def test_groupnorm_stats_from_cols_one_block_per_image(C, H, nimg, eps):
-    """Round 4: gn_finalize_cols / gn_coeffs_cols run one 1024-thread block per image (every load of a thread in flight at
-    once) instead of one 64-thread block per (image, group).  Against fp64 sums of the same column statistics (laid out as a
-    column slice of a wider buffer), and the two kernels against each other bit for bit (one summation order)."""
+def test_groupnorm_stats_and_coeffs_from_cols(C, H, nimg, eps):
+    """gn_finalize_cols / gn_coeffs_cols against fp64 sums of the same column statistics (laid out as a column slice of a
+    wider buffer), and the two kernels against each other bit for bit (one summation order: the fused SpatialTransformer front
+    and the fused-GroupNorm convolution apply the coefficients gn_apply would have formed)."""
     h = hip()
     hw = H * H
     x = (rnd((nimg * hw, C), 11, torch.float32, 1.5) + 0.3).to(DEV)

@@ -153,82 +153,55 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, int nchunk
 }
 
 // y = silu?( x * a[c] + b[c] ) with a = rstd * gamma, b = beta - mean * rstd * gamma held in registers per thread
-// (mean, rstd) from producer-side column statistics: colstats[slice][ld][2] with 64-row slices, hw % 64 == 0.
-// ONE block of GN_FIN_T threads per image (round 4; before: one 64-thread block per (image, group) whose ten loads per lane and
-// double-precision butterfly made 5.9-7.9 us of pure latency, 61 times per UNet forward): thread = (channel, slice group), every
-// load of a thread issued before the first add -- one L2 round trip -- then a fixed-order combine through LDS.  The summation
-// ORDER is a function of (C, hw) only and is shared by gn_finalize_cols and gn_coeffs_cols (bit-identical statistics): per
-// channel and slice group sg, slices sg, sg + SG, .. in order; per group, channels in order, slice groups in order; all in double.
-constexpr int GN_FIN_T = 1024;
-__device__ __forceinline__ void gn_image_stats(const float* __restrict__ colstats, long ld, int hw, int C, int groups, float eps,
-                                               int img, double* __restrict__ part /* [SG][C][2] */, float* __restrict__ mr /* [groups][2] */) {
-    const int t = threadIdx.x, spi = hw / 64, cpg = C / groups;
-    const int SG = (GN_FIN_T / C) > 0 ? min(GN_FIN_T / C, spi) : 1;
-    const float* base = colstats + (long)img * spi * ld * 2;
-    const long step = ld * 2;
-    for (int i = t; i < SG * C; i += GN_FIN_T) {
-        const int sg = i / C, c = i - sg * C;
-        const float* p = base + (long)c * 2;
-        double s = 0.0, q = 0.0;
-        int sl = sg;
-        for (; sl + 15 * SG < spi; sl += 16 * SG) {        // sixteen loads in flight, added in slice order
-            float2 v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const float2*>(p + (long)(sl + u * SG) * step);
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { s += v[u].x; q += v[u].y; }
-        }
-        for (; sl + 3 * SG < spi; sl += 4 * SG) {
-            float2 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float2*>(p + (long)(sl + u * SG) * step);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { s += v[u].x; q += v[u].y; }
-        }
-        for (; sl < spi; sl += SG) {
-            const float2 v = *reinterpret_cast<const float2*>(p + (long)sl * step);
-            s += v.x; q += v.y;
-        }
-        part[(long)i * 2] = s; part[(long)i * 2 + 1] = q;
+// (mean, rstd) from producer-side column statistics: colstats[slice][ld][2] with 64-row slices, hw % 64 == 0
+__global__ __launch_bounds__(64) void gn_finalize_cols_kernel(const float* __restrict__ colstats, long ld, int hw, int C,
+                                                              int groups, float eps, float* __restrict__ stats) {
+    const int img = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+    const int cpg = C / groups, spi = hw / 64;
+    const int total = cpg * spi;
+    double s = 0.0, q = 0.0;
+    for (int i = lane; i < total; i += 64) {
+        const int sl = i / cpg, c = g * cpg + (i - sl * cpg);
+        const float2 v = *reinterpret_cast<const float2*>(colstats + (((long)img * spi + sl) * ld + c) * 2);
+        s += v.x; q += v.y;
     }
-    __syncthreads();
-    if (t < groups) {
-        double s = 0.0, q = 0.0;
-        for (int c = t * cpg; c < (t + 1) * cpg; ++c)
-            for (int sg = 0; sg < SG; ++sg) { s += part[((long)sg * C + c) * 2]; q += part[((long)sg * C + c) * 2 + 1]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    if (lane == 0) {
         const double count = (double)hw * cpg;
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
-        mr[2 * t] = (float)mean;
-        mr[2 * t + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        stats[((long)img * groups + g) * 2] = (float)mean;
+        stats[((long)img * groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
-    __syncthreads();
-}
-
-__global__ __launch_bounds__(GN_FIN_T) void gn_finalize_cols_kernel(const float* __restrict__ colstats, long ld, int hw, int C,
-                                                                    int groups, float eps, float* __restrict__ stats) {
-    extern __shared__ double gn_part[];
-    __shared__ float mr[128];
-    const int img = blockIdx.x;
-    gn_image_stats(colstats, ld, hw, C, groups, eps, img, gn_part, mr);
-    if ((int)threadIdx.x < 2 * groups) stats[(long)img * groups * 2 + threadIdx.x] = mr[threadIdx.x];
 }
 
 // gn_finalize_cols + the per-channel scale / shift of gn_apply in one launch: ab[img][c] = (rstd * gamma[c], beta[c] - mean * a) --
-// bit for bit the a[j], b[j] gn_apply_kernel forms, so a kernel that applies them to its operand itself (conv.hip's fused
-// GroupNorm, stfront.hip) sees exactly what the separate normalisation pass would have stored.
-__global__ __launch_bounds__(GN_FIN_T) void gn_coeffs_cols_kernel(const float* __restrict__ colstats, long ld, int hw, int C, int groups,
-                                                                  float eps, const float* __restrict__ gamma,
-                                                                  const float* __restrict__ beta, float* __restrict__ ab) {
-    extern __shared__ double gn_part[];
-    __shared__ float mr[128];
-    const int img = blockIdx.x, cpg = C / groups;
-    gn_image_stats(colstats, ld, hw, C, groups, eps, img, gn_part, mr);
-    for (int c = threadIdx.x; c < C; c += GN_FIN_T) {
-        const int g = c / cpg;
-        const float a = mr[2 * g + 1] * gamma[c];
-        *reinterpret_cast<float2*>(ab + ((long)img * C + c) * 2) = make_float2(a, beta[c] - mr[2 * g] * a);
+// bit for bit the a[j], b[j] gn_apply_kernel forms, so a convolution that applies them to its operand in LDS (conv.hip) sees
+// exactly what the separate normalisation pass would have stored.
+__global__ __launch_bounds__(64) void gn_coeffs_cols_kernel(const float* __restrict__ colstats, long ld, int hw, int C, int groups,
+                                                            float eps, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ ab) {
+    const int img = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+    const int cpg = C / groups, spi = hw / 64;
+    const int total = cpg * spi;
+    double s = 0.0, q = 0.0;
+    for (int i = lane; i < total; i += 64) {
+        const int sl = i / cpg, c = g * cpg + (i - sl * cpg);
+        const float2 v = *reinterpret_cast<const float2*>(colstats + (((long)img * spi + sl) * ld + c) * 2);
+        s += v.x; q += v.y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+    const double count = (double)hw * cpg;
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float meanf = (float)mean, rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+        const float a = rstd * gamma[c];
+        *reinterpret_cast<float2*>(ab + ((long)img * C + c) * 2) = make_float2(a, beta[c] - meanf * a);
     }
 }
 
@@ -814,19 +787,11 @@ int vf_launch_gn_stats(const void* x, long ldx, int nimg, int hw, int C, int gro
     return ok();
 }
 
-static size_t gn_fin_lds(int C, int hw) {
-    const int spi = hw / 64;
-    int sg = GN_FIN_T / C;
-    if (sg < 1) sg = 1;
-    if (sg > spi) sg = spi;
-    return (size_t)sg * C * 2 * sizeof(double);
-}
-
 int vf_launch_gn_coeffs_cols(const float* colstats, long ld, int nimg, int hw, int C, int groups, float eps, const float* gamma,
                              const float* beta, float* ab, hipStream_t stream) {
     if (!colstats || !gamma || !beta || !ab || nimg <= 0 || hw <= 0 || C <= 0 || groups <= 0) return VF_ERR_ARG;
-    if ((hw & 63) || groups > 64 || C % groups || ld < C || C > 3840) return VF_ERR_SHAPE;
-    hipLaunchKernelGGL(gn_coeffs_cols_kernel, dim3(nimg), dim3(GN_FIN_T), gn_fin_lds(C, hw), stream, colstats, ld, hw, C, groups, eps, gamma, beta, ab);
+    if ((hw & 63) || groups > 64 || C % groups || (ld & 1)) return VF_ERR_SHAPE;
+    hipLaunchKernelGGL(gn_coeffs_cols_kernel, dim3(groups, nimg), dim3(64), 0, stream, colstats, ld, hw, C, groups, eps, gamma, beta, ab);
     return ok();
 }
 
@@ -1028,7 +993,7 @@ int vf_launch_adain(const void* a, long lda, const void* b, long ldb, void* dst,
 int vf_launch_gn_finalize_cols(const float* colstats, long ld, int nimg, int hw, int C, int groups, float eps, float* stats,
                                hipStream_t stream) {
     if (!colstats || !stats || nimg <= 0 || hw <= 0 || C <= 0 || groups <= 0) return VF_ERR_ARG;
-    if ((hw & 63) || groups > 64 || (C % groups) || ld < C || C > 3840) return VF_ERR_SHAPE;
-    hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(nimg), dim3(GN_FIN_T), gn_fin_lds(C, hw), stream, colstats, ld, hw, C, groups, eps, stats);
+    if ((hw & 63) || (C % groups) || ld < C) return VF_ERR_SHAPE;
+    hipLaunchKernelGGL(gn_finalize_cols_kernel, dim3(groups, nimg), dim3(64), 0, stream, colstats, ld, hw, C, groups, eps, stats);
     return ok();
 }
