@@ -397,7 +397,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_workload(F_, fusion, n_steps, n_warm, instrument, inv_steps, graph=True, res=None):
+    def run_workload(F_, fusion, n_steps, n_warm, instrument, inv_steps, graph=True, res=None, drop=False):
         """W untimed + exactly K timed DDIM steps of an F-frame clip per GPU at resolution `res`; returns per-rank wall
         seconds etc.  graph=True: the UNet forward of a step replayed from a hipGraph (UNetEngine.step_forward_nhwc: the
         product default) -- no per-launch events can be recorded inside a graph, so `instrument=True` (events around every
@@ -406,6 +406,7 @@ def main():
         # the reference's flow gate (4096 tokens) only ever fires at 512 x 512: other resolutions use the generalised one
         sampler.flow_gate = "reference" if h == 64 else "flow_hw"
         sampler.hook_plan = HookPlan(fusion=fusion, enabled=fusion != "none")
+        sampler.drop_dead_branches = bool(drop)     # (extras only: the headline always runs the full 3F batch)
         eng.use_graph, eng._graphs, eng._graph_failed = bool(graph), {}, set()
         eng.decompose_attn1 = bool(instrument)
         shard = FrameShard(rank, world, F_ * world, dist, mode=a.exchange)
@@ -491,6 +492,7 @@ def main():
                    f"hipGraph replay in {nseg} segments cut at the halo exchanges, the RCCL send / recv / wait calls issued from the host "
                    "between them (engine._GraphSegments)"))
         eng.exchange_events = None
+        sampler.drop_dead_branches = False
         return {"ms_step": el / n_steps * 1e3, "enqueue_ms": t_enq / n_steps * 1e3, "inv_ms": inv_ms, "elapsed": el,
                 "launch": launch, "exchange": exch, "h": h}
 
@@ -537,6 +539,22 @@ def main():
                            "unet_algorithmic_tflops": 3 * f2 * UNET_GFLOP[e["h"]] * 1e9 / (e["ms_step"] * 1e-3) / 1e12})
             log(f"  {e['ms_step']:.2f} ms/step = {extras[-1]['frames_per_s']:.2f} frames/s "
                 f"({extras[-1]['unet_algorithmic_tflops']:.0f} TFLOP/s algorithmic)")
+    # exact dead-branch elimination, reported BESIDE the headline and never as `value`: BASELINE's metric
+    # defines a swapped frame as 50 x 3 sample-forwards; the sampler drops the recon branch's x_prev and the inversion's source
+    # half, so the same outputs (bit-identical: tests/test_unet_gpu.py::test_drop_recon_is_bit_identical) need 2 + 1 of 3 + 2
+    dead = None
+    if world == 1 and not a.no_extras and a.res == 512:
+        log(f"extra: dead-branch elimination ({F_} frames, fusion={a.fusion}: sampling on [uncond;cond], inversion on the target half) ...")
+        e = run_workload(F_, a.fusion, a.extra_steps, 2, False, a.inv_steps, graph=not a.eager, drop=True)
+        dead = {"note": "sampler.drop_dead_branches: sampling on [uncond ; cond] (2F samples per step: the recon third's x_prev is dropped "
+                        "by the sampler and no hook mode reads chunk 2), inversion on the target half (F samples: only it is saved); "
+                        "outputs bit-identical to the full batches; NOT the metric's definition of a frame (3 sample-forwards per step)",
+                "frames_per_gpu": F_, "fusion": a.fusion, "steps": a.extra_steps, "sampling_ms_per_step": e["ms_step"],
+                "sampling_frames_per_s": F_ / (a.ddim_steps * e["ms_step"] / 1e3), "inversion_ms_per_step": e["inv_ms"],
+                "frames_per_s_sampling_plus_inversion": None if e["inv_ms"] is None else F_ / (a.ddim_steps * (e["ms_step"] + e["inv_ms"]) / 1e3),
+                "full_batch_sampling_ms_per_step": ms_step, "full_batch_inversion_ms_per_step": inv_ms}
+        log(f"  sampling {e['ms_step']:.2f} ms/step (full batch {ms_step:.2f}), inversion "
+            f"{e['inv_ms'] if e['inv_ms'] is not None else float('nan'):.2f} ms/step (full batch {inv_ms if inv_ms is not None else float('nan'):.2f})")
     eng.use_graph, eng._graphs = False, {}     # (frees the captured graphs' activation pools)
     # the widened pipeline end to end, outside the metric: VAE encode -> RAFT-shaped flow -> 50-step DDIM inversion
     # -> 50-step sampling with the shipped flow_fix schedule -> VAE decode -> paste-back, through the CLI's own code path
@@ -551,10 +569,17 @@ def main():
             res_ = cli.run_synthetic(opt)
             st = res_["batches"][-1]["stage_seconds"]        # the second batch: graphs captured, caches warm
             tot = sum(st.values())
+            opt2 = cli.build_parser().parse_args(["--synthetic", "--with_vae", "--raft_flow", "--paste_back", "--skip_save", "--n_frames", "16",
+                                                  "--n_samples", "8", "--fusion", "flow_fix", "--ddim_steps", str(a.ddim_steps),
+                                                  "--Base_dir", "/tmp/vface_bench_e2e", "--drop_dead_branches"])
+            st2 = cli.run_synthetic(opt2)["batches"][-1]["stage_seconds"]
             e2e = {"workload": "8 frames 512x512 -> 1024x1024 pasted frames: VAE encode, flow (7 pairs, 20 updates), 50-step inversion (2F "
                                "samples), 50-step sampling (flow_fix), VAE decode, paste-back incl. the background's VAE round trip; "
                                "synthetic weights and frames; conditioning encoders, face alignment and video I/O are not part of it",
-                   "stage_seconds": st, "seconds_per_8_frames": tot, "frames_per_s": 8.0 / tot}
+                   "stage_seconds": st, "seconds_per_8_frames": tot, "frames_per_s": 8.0 / tot,
+                   "with_drop_dead_branches": {"stage_seconds": st2, "seconds_per_8_frames": sum(st2.values()),
+                                               "frames_per_s": 8.0 / sum(st2.values()),
+                                               "note": "the same pipeline with --drop_dead_branches (bit-identical frames)"}}
             log(f"  {tot:.2f} s per 8 frames = {8.0 / tot:.2f} frames/s end to end: " + ", ".join(f"{k} {v * 1e3:.0f} ms" for k, v in st.items()))
         except Exception as ex:       # an extra never costs the metric line
             e2e = {"error": f"{type(ex).__name__}: {ex}"}
@@ -624,6 +649,7 @@ def main():
                         "sampling only, as BASELINE's metric",
                 "frames_per_s_sampling_plus_inversion": (F_ * world) / (a.ddim_steps * (ms_step + inv_ms) / 1e3)},
             "extra": extras,
+            "dead_branch_elimination": dead,
             "end_to_end": e2e,
             "instrumented_pass": {"launch": "kernel by kernel, HIP events around every GEMM / convolution / attention / norm launch (what `roofline` "
                                             "is computed from; vface_attn1_forward's launches issued call by call, bit-identical)",

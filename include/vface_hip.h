@@ -368,15 +368,18 @@ int vface_softmax_rows(const float* scores, int64_t ld_s, void* P, int64_t ld_p,
 int vface_vae_sample(const float* moments, int64_t ld_moments, const float* noise, float* z, int F, int hw, int zc,
                      float scale, void* stream);
 int vface_cast_f32(const float* src, void* dst, int64_t count, int dtype, void* stream);
-/* ddim_w_inv.py:633,654-655: x_in = cat[cat[x,inp,mask], cat[x,inp,mask], cat[inv_t,inp,mask]] -> NHWC [3F][hw][cpad] */
+/* ddim_w_inv.py:633,654-655: x_in = cat[cat[x,inp,mask], cat[x,inp,mask], cat[inv_t,inp,mask]] -> NHWC [3F][hw][cpad].
+ * inv == NULL: only [uncond ; cond] = [2F][hw][cpad] (the recon third of the batch is a pure sink of the sampler -- its x_prev is
+ * dropped, ddim_w_inv.py:703-707,738, and no hook mode reads chunk 2 -- so a caller may leave it out: exact). */
 int vface_pack_unet_input(const float* x, const float* inv, const float* inpaint, const float* mask, void* out, int F,
                           int h, int w, int cpad, int dtype, void* stream);
 int vface_nchw_to_nhwc(const float* x, void* out, int N, int C, int hw, int cpad, int dtype, void* stream);
 int vface_nhwc_to_nchw_f32(const float* x, int64_t ldx, float* out, int N, int C, int hw, void* stream);
 /* ddim_w_inv.py:666-667,686-700: guidance + x0 prediction + x_{t-1}; eps = NHWC fp32 UNet output of
  * [uncond ; cond ; recon]; x, inv, outputs NCHW fp32 [F][C][hw].  pred_x0 / x_prev_recon / noise optional.
- * single_branch != 0: eps holds ONE branch [F] and is used unguided -- with a_t = a(t - T/S), a_prev = a(t),
- * sigma 0 this is the inversion update of ddim_invert (ddim_w_inv.py:436-449). */
+ * single_branch == 1: eps holds ONE branch [F] and is used unguided -- with a_t = a(t - T/S), a_prev = a(t),
+ * sigma 0 this is the inversion update of ddim_invert (ddim_w_inv.py:436-449).  single_branch == 2: eps holds [uncond ; cond]
+ * only ([2F]: see vface_pack_unet_input with inv == NULL); x_prev_recon is then not written. */
 int vface_ddim_step(const float* eps, int64_t lde, const float* x, const float* inv, float* x_prev, float* pred_x0,
                     float* x_prev_recon, int F, int C, int hw, float scale, float a_t, float a_prev, float sigma_t,
                     float sqrt_one_minus_at, const float* noise, int single_branch, void* stream);

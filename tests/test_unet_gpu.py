@@ -579,6 +579,82 @@ def test_config1_full_unet_single_frame_256x256_twenty_steps_vs_oracle():
     assert torch.isfinite(img).all() and err < SMALL_BOUND
 
 
+DROP_MODES = ["off", "replace", "fft", "flow_fix", "fft_vfixed", "mix", "temporal", "adaIn"]
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("fusion", DROP_MODES)
+def test_drop_recon_is_bit_identical(small, fusion, graph):
+    """exact dead-branch elimination.  The recon third of every sampling batch is a pure sink
+    (REFace ddim_w_inv.py:667,703-707: e_t_recon only feeds x_prev_recon, and :738 returns x_prev, pred_x0 without it;
+    pnp_utils.py:136-142,195-199,255-256: every hook mode writes INTO chunk 2, never reads it), so
+    ``sampler.drop_dead_branches`` runs the UNet on [uncond ; cond] only: x_prev and pred_x0 of a 3-step loop must be
+    ``torch.equal`` to the full-batch run for EVERY fusion mode, kernel by kernel and through hipGraph replay."""
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import HookPlan
+    ldm, sampler, sd = small
+    eng = ldm.unet.engine
+    F_, h, w = 2, 32, 32
+    d = lambda v: v.to(DEV)
+    x_T = d(synth.synth_normal("drop.xT", (F_, 4, h, w)))
+    c, uc, tc = (d(synth.synth_normal(f"drop.{k}", (F_, 1, 768))) for k in ("c", "uc", "tc"))
+    inp = d(synth.synth_normal("drop.inpaint", (F_, 4, h, w)) * 0.18215)
+    mask = d(synth.synth_mask(F_, h, w))
+    flow = [synth.synth_flow(F_ - 1, h, w)[i][None] for i in range(F_ - 1)]
+    inv = {int(s_): d(synth.synth_normal(f"drop.inv.{int(s_)}", (F_, 4, h, w))) for s_ in oddim.ddim_timesteps(50)}
+
+    def run(drop):
+        sampler.drop_dead_branches = drop
+        sampler.hook_plan = HookPlan(fusion=fusion, enabled=fusion != "off")
+        torch.manual_seed(7)
+        img, inter = sampler.sample(S=50, batch_size=F_, shape=[4, h, w], conditioning=c, target_conditioning=tc,
+                                    inverse_results_dir=inv, verbose=False, unconditional_guidance_scale=3.0,
+                                    unconditional_conditioning=uc, eta=0.0, x_T=x_T, flow=flow, log_every_t=1,
+                                    test_model_kwargs={"inpaint_image": inp, "inpaint_mask": mask}, max_steps=3)
+        return img.clone(), [t.clone() for t in inter["pred_x0"]]
+
+    old = sampler.hook_plan, eng.use_graph, eng._graphs, sampler.drop_dead_branches
+    try:
+        eng.use_graph, eng._graphs = graph, {}
+        full, full_p0 = run(False)
+        cut, cut_p0 = run(True)
+        assert torch.equal(full, cut), (fusion, (full - cut).abs().max().item())
+        assert len(full_p0) == len(cut_p0) and all(torch.equal(a, b) for a, b in zip(full_p0, cut_p0))
+        assert eng.live_chunks is None
+        if graph:
+            assert not eng._graph_failed and len(eng._graphs) == 2      # one graph per batch shape
+    finally:
+        sampler.hook_plan, eng.use_graph, eng._graphs, sampler.drop_dead_branches = old
+
+
+def test_drop_source_half_of_inversion_is_bit_identical(small):
+    """The inversion batch is [target ; source] but only ``nosie[:batch_size]`` is ever saved (REFace ddim_w_inv.py:464-486) and
+    the entry point re-loads x_noisy from those files (VFace_inference_batch.py:531-543): with ``drop_dead_branches`` the loop
+    runs on the target half alone and must save the same bits."""
+    ldm, sampler, sd = small
+    F_, h, w = 2, 32, 32
+    d = lambda v: v.to(DEV)
+    c, tc = (d(synth.synth_normal(f"drop.{k}", (F_, 1, 768))) for k in ("c", "tc"))
+    inp = d(synth.synth_normal("drop.inpaint", (F_, 4, h, w)) * 0.18215)
+    mask = d(synth.synth_mask(F_, h, w))
+    x0 = d(synth.synth_normal("drop.z2", (2 * F_, 4, h, w)))
+    stores = []
+    old = sampler.drop_dead_branches
+    try:
+        for drop in (False, True):
+            sampler.drop_dead_branches = drop
+            st = {}
+            xn, _ = sampler.ddim_invert(x=x0, cond=torch.cat([tc, c], 0), S=50, shape=[4, h, w], inverse_dir=st, batch_size=F_,
+                                        test_model_kwargs={"inpaint_image": torch.cat([inp] * 2), "inpaint_mask": torch.cat([mask] * 2)},
+                                        max_steps=3)
+            stores.append((st, xn.clone()))
+    finally:
+        sampler.drop_dead_branches = old
+    (a, xa), (b, xb) = stores
+    assert sorted(a) == sorted(b) == [1, 21, 41]
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert xb.shape[0] == F_ and torch.equal(xa[:F_], xb)
+
+
 @pytest.mark.parametrize("mode", ["off", "in_replace", "in_fft", "in_flow_fix", "in_fft_vfixed"])
 def test_decomposed_attn1_equals_one_call_form_bit_for_bit(small, mode):
     """bench.py's instrumented pass issues the launches of ``vface_attn1_forward`` call by call (UNetEngine._attn1_decomposed)

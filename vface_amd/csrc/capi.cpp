@@ -288,7 +288,7 @@ int vface_attn1_forward(const void* x, int64_t ldx, const void* Wqkv, const void
     if (fusion == VFACE_FUSION_LINEAR && (!Wlin || (d % 64))) return VFACE_ERR_SHAPE;
     if (v_fixed && !v_map) return VFACE_ERR_ARG;
     const bool warp = fusion == VFACE_FUSION_LINEAR && flow != nullptr;
-    if (warp && (h * w != n || chunks != 3)) return VFACE_ERR_SHAPE;
+    if (warp && (h * w != n || chunks < 2 || chunks > 3)) return VFACE_ERR_SHAPE;      // (2: a batch without the recon third)
     hipStream_t st = S(stream);
     const size_t esz = 2;
     const long F = B / chunks, Fn = F * n;

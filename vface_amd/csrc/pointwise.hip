@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void temporal_gauss_kernel(const typename TT::
 #pragma unroll
         for (int j = 0; j < 8; ++j) o8[j] = from_f32<E>(acc[j] / wt);
         *reinterpret_cast<V8*>(dst1 + (long)f * fs_dst + tok * ld_dst + cc) = o8;
-        *reinterpret_cast<V8*>(dst2 + (long)f * fs_dst + tok * ld_dst + cc) = o8;
+        if (dst2) *reinterpret_cast<V8*>(dst2 + (long)f * fs_dst + tok * ld_dst + cc) = o8;
     }
 }
 
@@ -565,7 +565,7 @@ __global__ void pack_input_kernel(const float* __restrict__ x, const float* __re
                                   const float* __restrict__ inpaint, const float* __restrict__ mask,
                                   typename TT::elem* __restrict__ out, int F, int hw, int cpad) {
     using E = typename TT::elem;
-    const long total = (long)3 * F * hw * cpad;
+    const long total = (long)(inv ? 3 : 2) * F * hw * cpad;      // inv == nullptr: [uncond ; cond] only (no recon chunk)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % cpad);
         const long pi = i / cpad;
@@ -622,15 +622,16 @@ __global__ void ddim_step_kernel(const float* __restrict__ eps, long lde, const 
         const int c = (int)(fc % C);
         const int f = (int)(fc / C);
         const float eu = eps[((long)f * hw + pix) * lde + c];
-        // single: eps holds one branch only (DDIM inversion, no guidance, ddim_w_inv.py:426-427)
-        const float ec = single ? eu : eps[((long)(F + f) * hw + pix) * lde + c];
+        // single == 1: eps holds one branch only (DDIM inversion, no guidance, ddim_w_inv.py:426-427); single == 2: eps holds
+        // [uncond ; cond] only -- the recon branch, whose x_prev the sampler drops (ddim_w_inv.py:703-707,738), was not computed
+        const float ec = single == 1 ? eu : eps[((long)(F + f) * hw + pix) * lde + c];
         const float er = single ? eu : eps[((long)(2 * F + f) * hw + pix) * lde + c];
-        const float e_t = single ? eu : eu + scale * (ec - eu);
+        const float e_t = single == 1 ? eu : eu + scale * (ec - eu);
         const float p0 = (x[i] - sqrt_1m_at * e_t) / sqrt_at;
         const float nz = noise ? sigma_t * noise[i] : 0.f;
         x_prev[i] = sqrt_ap * p0 + dir * e_t + nz;
         if (pred_x0) pred_x0[i] = p0;
-        if (x_prev_recon && inv) {
+        if (x_prev_recon && inv && !single) {
             const float e_r = er + scale * (er - eu);
             const float p0r = (inv[i] - sqrt_1m_at * e_r) / sqrt_at;
             x_prev_recon[i] = sqrt_ap * p0r + dir * e_r;
@@ -894,9 +895,9 @@ int vf_launch_cast(const float* src, void* dst, long count, int dtype, hipStream
 
 int vf_launch_pack_input(const float* x, const float* inv, const float* inpaint, const float* mask, void* out,
                          int F, int h, int w, int cpad, int dtype, hipStream_t stream) {
-    if (!x || !inv || !inpaint || !mask || !out || F <= 0 || h <= 0 || w <= 0) return VF_ERR_ARG;
+    if (!x || !inpaint || !mask || !out || F <= 0 || h <= 0 || w <= 0) return VF_ERR_ARG;
     if (cpad < 9 || (cpad & 7)) return VF_ERR_SHAPE;
-    const long total = (long)3 * F * h * w * cpad;
+    const long total = (long)(inv ? 3 : 2) * F * h * w * cpad;
     DISPATCH_DTYPE(dtype, {
         using E = typename TT::elem;
         hipLaunchKernelGGL((pack_input_kernel<TT>), dim3(grid_for(total)), dim3(256), 0, stream, x, inv, inpaint, mask, (E*)out, F, h * w, cpad);
@@ -924,7 +925,7 @@ int vf_launch_nhwc_to_nchw_f32(const float* x, long ldx, float* out, int N, int 
 int vf_launch_ddim_step(const float* eps, long lde, const float* x, const float* inv, float* x_prev, float* pred_x0,
                         float* x_prev_recon, int F, int C, int hw, float scale, float a_t, float a_prev, float sigma_t,
                         float sqrt_1m_at, const float* noise, int single, hipStream_t stream) {
-    if (!eps || !x || !x_prev || F <= 0 || C <= 0 || hw <= 0 || lde < C) return VF_ERR_ARG;
+    if (!eps || !x || !x_prev || F <= 0 || C <= 0 || hw <= 0 || lde < C || single < 0 || single > 2) return VF_ERR_ARG;
     const long total = (long)F * C * hw;
     hipLaunchKernelGGL(ddim_step_kernel, dim3(grid_for(total)), dim3(256), 0, stream, eps, lde, x, inv, x_prev, pred_x0,
                        x_prev_recon, F, C, hw, scale, a_t, a_prev, sigma_t, sqrt_1m_at, noise, single);
@@ -945,7 +946,7 @@ int vf_launch_copy2d(const void* src, long lds_, void* dst, long ldd, long rows,
 
 int vf_launch_temporal_gauss(const void* src, long ld_src, long fs_src, void* dst1, void* dst2, long ld_dst, long fs_dst,
                              int F, int n, int C, int dtype, hipStream_t stream) {
-    if (!src || !dst1 || !dst2 || F <= 0 || n <= 0 || C <= 0) return VF_ERR_ARG;
+    if (!src || !dst1 || F <= 0 || n <= 0 || C <= 0) return VF_ERR_ARG;      // (dst2 optional: a batch without its last chunk)
     if ((C & 7) || (ld_src & 7) || (ld_dst & 7) || (fs_src & 7) || (fs_dst & 7)) return VF_ERR_ALIGN;
     if (((uintptr_t)src | (uintptr_t)dst1 | (uintptr_t)dst2) & 15) return VF_ERR_ALIGN;
     const long total = (long)n * (C / 8);

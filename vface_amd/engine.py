@@ -119,11 +119,15 @@ def flow_gate_hw(cfg: HookCfg, n: int, flow_hw):
     return (h, w) if n == h * w else None
 
 
-def plan_fusion(cfg: Optional[HookCfg], N: int, n: int, clip_flow_hw=None) -> dict:
+def plan_fusion(cfg: Optional[HookCfg], N: int, n: int, clip_flow_hw=None, live: Optional[int] = None) -> dict:
     """Map a hook configuration onto the kernels' mechanisms (pnp_utils.py:129-262).
     Returns fusion code, chunks, which folded weight to use, and the flow / v-broadcast options.  ``clip_flow_hw``: the
     flow field's (h, w) when frames are sharded (a one-frame shard has no local field but still takes part in the
-    boundary exchange): ``warp_hw`` is then set even when ``flow`` is None."""
+    boundary exchange): ``warp_hw`` is then set even when ``flow`` is None.
+    ``live``: the batch holds only the first ``live`` of the hook's ``chunks`` chunks (the sampler left the recon third out:
+    every hook mode edits chunk k >= 1 from chunk 0 and chunk k alone, pnp_utils.py:133-262, so the chunks that ARE there
+    compute exactly what they compute in the full batch); the plan's ``chunks`` is then ``live``, its fusion still the one the
+    hook's own ``chunks`` selects."""
     pl = {"fusion": hip.FUSION_NONE, "chunks": 1, "wlin": None, "flow": None, "alpha": 0.8, "v_fixed": False,
           "staged": None, "warp_hw": None}
     if cfg is None or not cfg.switch_on:
@@ -131,9 +135,12 @@ def plan_fusion(cfg: Optional[HookCfg], N: int, n: int, clip_flow_hw=None) -> di
     chunks = cfg.chunks
     if chunks not in (2, 3):
         return pl  # the reference edits nothing for other values
-    if N % chunks:
-        raise hip.VFaceHipError(f"hooked attn1: batch {N} is not divisible by chunks={chunks}")
-    pl["chunks"] = chunks
+    there = chunks if live is None else live
+    if not 1 <= there <= chunks:
+        raise hip.VFaceHipError(f"hooked attn1: {there} live chunks of chunks={chunks}")
+    if N % there:
+        raise hip.VFaceHipError(f"hooked attn1: batch {N} is not divisible by its {there} chunk(s) (hook chunks={chunks})")
+    pl["chunks"] = there
     f = cfg.fusion
     if chunks == 2 or f == "replace":
         pl["fusion"] = hip.FUSION_REPLACE
@@ -146,8 +153,8 @@ def plan_fusion(cfg: Optional[HookCfg], N: int, n: int, clip_flow_hw=None) -> di
             hw = flow_gate_hw(cfg, n, fhw)
             if hw is not None:
                 nf = cfg.flow.shape[0] if cfg.flow is not None else 0
-                if nf != N // chunks - 1:
-                    raise RuntimeError(f"flow has {nf} fields for {N // chunks} frames "
+                if nf != N // there - 1:
+                    raise RuntimeError(f"flow has {nf} fields for {N // there} frames "
                                        "(align_by_flow needs F-1, temporal_flow.py:231-233)")
                 pl["flow"], pl["alpha"], pl["warp_hw"] = cfg.flow, cfg.alpha, hw
     elif f == "mix":
@@ -156,24 +163,28 @@ def plan_fusion(cfg: Optional[HookCfg], N: int, n: int, clip_flow_hw=None) -> di
         pl["staged"] = f  # edits that are not a sample map or a folded weight: separate kernels on the qkv buffer
     else:
         pl["chunks"] = 1  # unknown fusion strings edit nothing in the reference
+    if pl["chunks"] == 1 and pl["fusion"] != hip.FUSION_NONE:
+        pl["fusion"], pl["wlin"], pl["flow"], pl["warp_hw"], pl["v_fixed"] = hip.FUSION_NONE, None, None, None, False   # chunk 0 alone: unedited
     return pl
 
 
 def staged_attn1(x16: torch.Tensor, wqkv, wo, bo, out, *, B, n, d, heads, mode, rowbias=None, residual=None,
-                 residual32=None, out32=None):
+                 residual32=None, out32=None, chunks: int = 3):
     """Hooked attn1 for fusion modes that edit q,k with their own kernels ("temporal", "adaIn"; pnp_utils.py:145-160):
     full projection -> edit chunk 1 / chunk 2 q,k in the qkv buffer -> attention -> out-projection."""
     dev, dt = x16.device, x16.dtype
-    c = B // 3
+    c = B // chunks          # (chunks < 3: the batch came without its last chunk(s), plan_fusion `live`)
     Fn = c * n
     qkv = torch.empty(B * n, 3 * d, dtype=dt, device=dev)
     hip.gemm(x16, wqkv, qkv, M=B * n, N=3 * d, K=x16.shape[1], lda=x16.stride(0), ldc=3 * d)
-    if mode == "temporal":
-        hip.temporal_gauss(qkv, qkv[Fn:], qkv[2 * Fn:], F=c, n=n, C_=2 * d, ld_src=3 * d, fs_src=n * 3 * d, ld_dst=3 * d,
-                           fs_dst=n * 3 * d)
+    if mode == "temporal" and chunks > 1:
+        hip.temporal_gauss(qkv, qkv[Fn:], qkv[2 * Fn:] if chunks > 2 else None, F=c, n=n, C_=2 * d, ld_src=3 * d, fs_src=n * 3 * d,
+                           ld_dst=3 * d, fs_dst=n * 3 * d)
+    elif mode == "temporal":
+        pass
     elif mode == "adaIn":
         for col in (0, d):  # q then k
-            for ch in (1, 2):
+            for ch in range(1, chunks):
                 own = qkv[ch * Fn:(ch + 1) * Fn, col:col + d]
                 hip.adain_fusion(qkv[:Fn, col:col + d], own, own, rows=Fn, C_=d, lda=3 * d, ldb=3 * d, ldd=3 * d)
     else:
@@ -387,6 +398,9 @@ class UNetEngine:
         self._front_supported: Dict[tuple, bool] = {}
         self._ffn_supported: Dict[tuple, bool] = {}
         self.decompose_attn1 = False                   # bench.py's instrumented pass: vface_attn1_forward's launches call by call
+        # the batch holds only the first `live_chunks` chunks of the hooks' three (the sampler's dead-branch elimination leaves
+        # the recon third out: DDIMSampler.drop_dead_branches); None = every chunk is there
+        self.live_chunks: Optional[int] = None
         # fp32 residual stream: residual sums are carried between kernels in fp32, 16-bit copies exist only
         # where a matrix-core operand needs them.  VFACE_STREAM32=0 restores the all-16-bit activations (A/B switch).
         self.stream32 = os.environ.get("VFACE_STREAM32", "1") != "0"
@@ -679,14 +693,14 @@ class UNetEngine:
         out = None if s32 else self._new(N * n, d)
         out32 = self._new(N * n, d, torch.float32) if s32 else None
         res_kw = {"residual32": resid, "out32": out32} if s32 else {"residual": resid, "ldr": resid.stride(0)}
-        pl = plan_fusion(cfg, N, n, self.halo_hw if self.halo_exchange is not None else None)
+        pl = plan_fusion(cfg, N, n, self.halo_hw if self.halo_exchange is not None else None, self.live_chunks)
         if pl["staged"]:
             if self.halo_exchange is not None:
                 raise NotImplementedError(f"fusion={pl['staged']!r} couples frames beyond one neighbour (temporal: +-2 "
                                           "frames; adaIn: a global std) and is not sharded across GPUs")
             kw = {"residual32": resid, "out32": out32} if s32 else {"residual": resid}
             return staged_attn1(xln, p["wqkv"], p["wo"]["w"], p["wo"]["b"], out, B=N, n=n, d=d, heads=heads,
-                                mode=pl["staged"], rowbias=a2vec, **kw)
+                                mode=pl["staged"], rowbias=a2vec, chunks=pl["chunks"], **kw)
         fusion, chunks, flow, alpha, v_fixed = pl["fusion"], pl["chunks"], pl["flow"], pl["alpha"], pl["v_fixed"]
         wlin = self._wlin(p, *pl["wlin"]) if pl["wlin"] else None
         qk_map = self._map("qk_replace", N, N // chunks) if fusion == hip.FUSION_REPLACE else None
@@ -695,7 +709,7 @@ class UNetEngine:
         hw = pl["warp_hw"]
         if hw is not None and self.halo_exchange is not None:
             # every rank of a sharded clip takes part in the boundary exchange, a one-frame shard (no local field) too
-            return self._attn1_sharded(xln, res_kw, p, wlin, a2vec, N, n, heads, flow, hw, alpha, out)
+            return self._attn1_sharded(xln, res_kw, p, wlin, a2vec, N, n, heads, flow, hw, alpha, out, chunks)
         if self.decompose_attn1:
             self._attn1_decomposed(xln, p, wlin, a2vec, N, n, heads, chunks, fusion, v_fixed, flow if hw is not None else None,
                                    hw, alpha, qk_map, v_map, out, res_kw)
@@ -747,11 +761,11 @@ class UNetEngine:
                  bias=p["wo"]["b"], rowbias=a2vec, rows_per_sample=n, split_k=False, **res_kw)
         return o
 
-    def _attn1_sharded(self, xln, res_kw, p, wlin, a2vec, N, n, heads, flow, hw, alpha, out):
+    def _attn1_sharded(self, xln, res_kw, p, wlin, a2vec, N, n, heads, flow, hw, alpha, out, chunks=3):
         """flow_fix with frames sharded across ranks: the same kernels as vface_attn1_forward, sequenced here
         so the one-neighbour boundary exchange sits between the fused projection and the warp."""
         d = p["c"]
-        F_ = N // 3
+        F_ = N // chunks
         Fn = F_ * n
         qkv = self._new(N * n, 3 * d)
         T = self._new(Fn, 2 * d)
@@ -765,7 +779,8 @@ class UNetEngine:
         handle = self.halo_exchange.start_exchange(T[(F_ - 1) * n:])
         hip.gemm(xln, p["wqkv"], qkv, M=Fn, N=3 * d, K=d, lda=xln.stride(0), ldc=3 * d)
         hip.gemm(xln[Fn:], p["wqkv"][2 * d:], qkv[Fn:, 2 * d:], M=N * n - Fn, N=d, K=d, lda=xln.stride(0), ldc=3 * d)
-        fused(2, qkv[2 * Fn:, :2 * d])
+        for ch in range(2, chunks):
+            fused(ch, qkv[ch * Fn:(ch + 1) * Fn, :2 * d])
         ev = self.exchange_events if not isinstance(self.halo_exchange, _GraphSegments) else None
         if ev is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -841,7 +856,7 @@ class UNetEngine:
         if fw is not None and not getattr(fw, "_vface", False):
             raise hip.VFaceHipError("attn1.forward was replaced by a closure this engine does not know; use "
                                     "vface_amd.ldm.models.pnp_utils.register_spa_attn_injection")
-        pl = plan_fusion(cfg, N, n, self.halo_hw if self.halo_exchange is not None else None)
+        pl = plan_fusion(cfg, N, n, self.halo_hw if self.halo_exchange is not None else None, self.live_chunks)
         if pl["staged"]:
             return None      # "temporal" / "adaIn" edit a full q,k,v buffer with their own kernels
         d, heads = c, attn1.heads
@@ -1086,7 +1101,7 @@ class UNetEngine:
                                              None if self.halo_flow is None else tuple(self.halo_flow.shape))
         # (every switch that changes the captured launch sequence is part of the key: toggling one on a live engine must not
         # replay a stale graph)
-        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front,
+        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.live_chunks,
                self.decompose_attn1, self.exchange_events is not None, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)

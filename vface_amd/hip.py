@@ -547,6 +547,8 @@ def nhwc_to_nchw_f32(x: torch.Tensor, out: torch.Tensor, *, N: int, C_: int, hw:
 
 def ddim_step(eps, x, inv, x_prev, *, F, C_, hw, lde, scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, pred_x0=None,
               x_prev_recon=None, noise=None, single_branch=False):
+    """``single_branch``: False / 0 = eps is [uncond ; cond ; recon]; True / 1 = one unguided branch (inversion); 2 = [uncond ;
+    cond] only (the sampler's recon third left out)."""
     rc = load().vface_ddim_step(_p(eps), lde, _p(x), _p(inv), _p(x_prev), _p(pred_x0), _p(x_prev_recon), F, C_, hw,
                                 scale, a_t, a_prev, sigma_t, sqrt_one_minus_at, _p(noise), int(single_branch),
                                 _stream())

@@ -14,6 +14,15 @@ What differs is where the work happens, not what is computed:
   ``fusion="flow_fix"``, split 0.8, alpha 0.8) is the default ``hook_plan`` and can be replaced, e.g. by
   ``HookPlan(fusion="replace")`` for structure injection only.
 
+Exact dead-branch elimination, opt-in (``sampler.drop_dead_branches = True``; results are bit-identical, tests/test_unet_gpu.py):
+
+* sampling: the *recon* third of the batch is a pure sink -- ``e_t_recon`` only feeds ``x_prev_recon`` (:667,703-707), which
+  ``p_sample_ddim_with_inverse`` drops (:738 returns ``x_prev, pred_x0``), and every hook mode writes INTO chunk 2, never reads
+  from it (pnp_utils.py:136-142,195-199,255-256) -- so the UNet runs on ``[uncond ; cond]`` (2F samples) and the per-step
+  recon latents are not even loaded;
+* inversion: the *source* half of the 2F batch is never used -- only ``nosie[:batch_size]`` is saved (:464-486) and the
+  entry point re-loads ``x_noisy`` from the saved latents (VFace_inference_batch.py:531-543) -- so it runs on the target half.
+
 Reference quirks kept on purpose: chunk 0 (the structure source) is the unconditional branch; the
 recon branch guidance is ``e_r + s (e_r - e_u)`` (:667); the RNG is drawn even when ``eta == 0`` (:697,702).
 """
@@ -64,6 +73,8 @@ class DDIMSampler(object):
         # what to do with a flow field at pixel resolution (what the reference's own script produces): None =
         # raise like the reference's warp_image does; "area" = bring it to the latent map with vface_flow_to_latent
         self.flow_resample = None
+        # exact dead-branch elimination (module docstring): sampling without the recon third, inversion without the source half
+        self.drop_dead_branches = False
 
     def register_buffer(self, name, attr):
         # the reference forces .to("cuda") here (:149-153); buffers follow the model's device instead
@@ -204,21 +215,30 @@ class DDIMSampler(object):
             t_host = int(self.ddim_timesteps[index])
         else:
             t_host = int(t[0].item()) if torch.is_tensor(t) else int(t)
-        inv_t = self._inv_latent(t_host, inverse_results_dir, device)
+        drop = bool(getattr(self, "drop_dead_branches", False))
+        nb = 2 if drop else 3
+        # (without the recon third its per-step latent is not needed at all: in the file-backed pipeline that is a disk read less)
+        inv_t = None if drop else self._inv_latent(t_host, inverse_results_dir, device)
         f32 = lambda v: v.to(device=device, dtype=torch.float32).contiguous()
-        x_in = torch.empty(3 * F_ * H * W, 16, dtype=eng.dtype, device=device)
+        x_in = torch.empty(nb * F_ * H * W, 16, dtype=eng.dtype, device=device)
         hip.pack_unet_input(f32(x), inv_t, f32(inpaint), f32(mask), x_in, F=F_, h=H, w=W, cpad=16)
-        t_in = torch.cat([t] * 3)
+        t_in = torch.cat([t] * nb)
         # [uncond ; cond ; recon] (:654-667).  The three parts are the same tensors at every step of a clip: build the
         # concatenation once so the UNet engine sees one context object (and keeps its context-only projections)
-        parts = (unconditional_conditioning, c, target_conditioning)
+        parts = (unconditional_conditioning, c) + (() if drop else (target_conditioning,))
         cc = getattr(self, "_c_in_cache", None)
-        if cc is not None and all(a is b for a, b in zip(cc[0], parts)) and cc[1] == tuple(p._version for p in parts):
+        if cc is not None and len(cc[0]) == len(parts) and all(a is b for a, b in zip(cc[0], parts)) and \
+                cc[1] == tuple(p._version for p in parts):
             c_in = cc[2]
         else:
             c_in = torch.cat(list(parts), dim=0)
             self._c_in_cache = (parts, tuple(p._version for p in parts), c_in)
-        eps = eng.step_forward_nhwc(Act(x_in, 3 * F_, H, W), t_in, c_in)  # fp32 [3F*HW, 4]
+        saved_live = eng.live_chunks
+        eng.live_chunks = 2 if drop else None      # the hooks still say chunks = 3: the batch holds the first two of them
+        try:
+            eps = eng.step_forward_nhwc(Act(x_in, nb * F_, H, W), t_in, c_in)  # fp32 [nb F*HW, 4]
+        finally:
+            eng.live_chunks = saved_live
         a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])
         sigma_t, s1m = float(self.ddim_sigmas[index]), float(self.ddim_sqrt_one_minus_alphas[index])
         noise = noise_like(x.shape, device, repeat_noise) * temperature  # drawn even when sigma_t == 0 (:697)
@@ -229,7 +249,8 @@ class DDIMSampler(object):
         pred_x0 = torch.empty_like(x, dtype=torch.float32)
         hip.ddim_step(eps, f32(x), inv_t, x_prev, F=F_, C_=C, hw=H * W, lde=eps.stride(0),
                       scale=float(unconditional_guidance_scale), a_t=a_t, a_prev=a_prev, sigma_t=sigma_t,
-                      sqrt_one_minus_at=s1m, pred_x0=pred_x0, noise=noise if sigma_t != 0.0 else None)
+                      sqrt_one_minus_at=s1m, pred_x0=pred_x0, noise=noise if sigma_t != 0.0 else None,
+                      single_branch=2 if drop else False)
         return x_prev, pred_x0
 
     # ------------------------------------------------------------------ inversion
@@ -242,6 +263,13 @@ class DDIMSampler(object):
         if unconditional_conditioning is not None and unconditional_guidance_scale != 1.:
             raise NotImplementedError("guided inversion is not used by the VFace entry point (:540)")
         device = x.device
+        if getattr(self, "drop_dead_branches", False) and x.shape[0] > batch_size:
+            # only the first `batch_size` samples (the target half) are ever saved (:464-486) and nothing else of this loop is
+            # used by the entry point: run those alone (hooks are off, the kernels are batch-invariant: the same bits)
+            x, cond = x[:batch_size], cond[:batch_size]
+            kw0 = kwargs.get('test_model_kwargs')
+            if kw0 is not None:
+                kwargs = dict(kwargs, test_model_kwargs={k: (v[:batch_size] if torch.is_tensor(v) else v) for k, v in kw0.items()})
         b = x.shape[0]
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=False)
         timesteps = self.ddim_timesteps

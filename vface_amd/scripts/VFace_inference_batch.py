@@ -85,6 +85,11 @@ def build_parser() -> argparse.ArgumentParser:
                    help="(default since round 3; kept for older command lines) replay each DDIM step's UNet forward from a "
                         "hipGraph: one capture per clip shape and hook plan, bit-equal to kernel-by-kernel launches")
     p.add_argument("--no_hip_graph", action="store_true", help="launch every kernel of a step from the host (VFACE_GRAPH=0)")
+    p.add_argument("--drop_dead_branches", action="store_true",
+                   help="exact dead-branch elimination (results bit-identical): sampling runs the UNet on [uncond ; cond] without "
+                        "the recon third -- its x_prev is dropped by the sampler and no hook mode reads chunk 2 (ddim_w_inv.py:"
+                        "667,703-707,738; pnp_utils.py:136-142,195-199,255-256) -- and the inversion runs on the target half only "
+                        "(only nosie[:batch_size] is saved, ddim_w_inv.py:464-486): -33 %% / -50 %% of the UNet work")
     p.add_argument("--max_steps", type=int, default=None, help="stop after this many DDIM steps (smoke runs)")
     return p
 
@@ -232,6 +237,7 @@ def run_synthetic(opt) -> dict:
     sampler = DDIMSampler(model)
     sampler.hook_plan = HookPlan(fusion=opt.fusion, enabled=opt.fusion != "none")
     sampler.flow_gate = opt.flow_gate
+    sampler.drop_dead_branches = bool(opt.drop_dead_branches)
     if opt.hip_graph:
         sampler.model.model.diffusion_model.engine.use_graph = True
     if opt.no_hip_graph:
