@@ -168,7 +168,9 @@ int vface_attention(const void* Q, const void* K, const void* V, int64_t ldq, in
 /* v_sets > 1 ("shared scores", the "replace" injection pnp_utils.py:133-143 / :259-262 where every chunk takes q,k of
  * chunk 0): B counts the q/k samples; for g < v_sets output sample b + g*set_stride = softmax(q_b k_b^T * scale) v_s,
  * s = v_map[b + g*set_stride] (or b + g*set_stride), the probabilities computed once per (b, head).  Supported for
- * v_sets 2|3 and dh 8|16|32|40 (vface_attention_shared_scores_supported); other shapes: use qk_map. */
+ * v_sets 2|3 and dh 8|16|32|40 (vface_attention_shared_scores_supported); other shapes: use qk_map.  * Bits 8..15 of v_sets: the number of LIVE sets (0 = all; supported: 2 of 3): sets g >= live are neither read nor written --
+ * a batch that came without its last chunk (the sampler's dead-branch elimination) -- while every instruction that touches a live
+ * set is that of the full call, so the live outputs are bit-identical to it. */
 int vface_attention_shared_scores_supported(int dh, int v_sets);
 
 /* y = LayerNorm(x) * gamma + beta, fp32 statistics (attention.py:231-233).  in_f32: x is the fp32 residual-stream

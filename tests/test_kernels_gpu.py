@@ -210,6 +210,36 @@ def test_attention_shared_scores(dt, dh, sets, n):
     assert rel_l2(out3.cpu().float(), ref3) < TOL[dt]
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("dh,n", [(40, 500), (40, 1024), (8, 100), (16, 64), (32, 320)])
+def test_attention_shared_scores_two_live_sets_of_three_bit_identical(dt, dh, n):
+    """The sampler's dead-branch elimination hands the hooked layers [chunk 0 ; chunk 1] of a three-chunk hook: the shared-score
+    kernel then runs its THREE-set instantiation with two live sets (``v_sets_live=2``) -- no read of the third chunk's values
+    (the batch ends after the second), no write of its outputs -- and the two live outputs are the full call's bit for bit."""
+    h = hip()
+    Fr, heads = 2, 8
+    d = heads * dh
+    qkv = rnd((3 * Fr, n, 3 * d), 12, dt)
+    qd = qkv.to(DEV)
+    kw = dict(heads=heads, n=n, nk=n, dh=dh, ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d,
+              bsv=n * 3 * d, ldo=d, bso=n * d, scale=dh ** -0.5)
+    full = torch.zeros(3 * Fr, n, d, dtype=dt, device=DEV)
+    h.attention(qd, qd[:, :, d:], qd[:, :, 2 * d:], full, B=Fr, v_sets=3, set_stride=Fr, **kw)
+    q2 = qd[:2 * Fr].contiguous()                       # a batch that really ends after chunk 1
+    SENT = 3.0
+    live = torch.full((2 * Fr + 1, n, d), SENT, dtype=dt, device=DEV)
+    h.attention(q2, q2[:, :, d:], q2[:, :, 2 * d:], live, B=Fr, v_sets=3, v_sets_live=2, set_stride=Fr, **kw)
+    assert torch.equal(live[:2 * Fr], full[:2 * Fr])
+    assert (live[2 * Fr:] == SENT).all()                # nothing written past the live sets
+    v_map = torch.tensor([1, 0, 3, 2], dtype=torch.int32, device=DEV)
+    a = torch.zeros(3 * Fr, n, d, dtype=dt, device=DEV)
+    h.attention(qd, qd[:, :, d:], qd[:, :, 2 * d:], a, B=Fr, v_sets=3, set_stride=Fr,
+                v_map=torch.tensor([1, 0, 3, 2, 5, 4], dtype=torch.int32, device=DEV), **kw)
+    b = torch.zeros(2 * Fr, n, d, dtype=dt, device=DEV)
+    h.attention(q2, q2[:, :, d:], q2[:, :, 2 * d:], b, B=Fr, v_sets=3, v_sets_live=2, set_stride=Fr, v_map=v_map, **kw)
+    assert torch.equal(b, a[:2 * Fr])
+
+
 @pytest.mark.parametrize("sets,n", [(1, 500), (1, 4096), (3, 320)])
 def test_attention_dh40_32x32_form(sets, n):
     """The A/B form of the dh = 40 kernel on mfma 32x32x16 (variant bit 2; never chosen by the dispatcher: measured slower):

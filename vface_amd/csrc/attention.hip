@@ -64,9 +64,13 @@ constexpr int v_pitch_bytes32(int dvp) {
 // NWV: waves per workgroup, 4 or 8: eight waves share one staged K / V block, so a wave issues half the LDS-DMA pieces per block
 // and the K / V stream through L2 halves, for a barrier across eight waves instead of four.  Measured: nothing for the plain dh = 40
 // kernel (665 vs 665 us; variant bit 3 selects it there), -5 % for the shared-score form, which takes it by default.
-template <class TT, int DH, int QT, int G, bool LAZY, bool W32 = false, int NWV = 4>
+// GL: LIVE value sets of the G (GL < G: the batch came without its last chunk(s) -- the sampler's dead-branch elimination): the sets
+// g >= GL are neither read nor written and their column tiles are skipped; the tile layout, the ones column and every instruction
+// that touches a live set are those of GL == G, so the live outputs are the full call's bit for bit.
+template <class TT, int DH, int QT, int G, bool LAZY, bool W32 = false, int NWV = 4, int GL = G>
 __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
     constexpr int NTH = 64 * NWV;
+    static_assert(GL >= 1 && GL <= G && (GL == G || !W32), "live sets");
     using E = typename TT::elem;
     using V8 = typename TT::v8;
     using V4 = typename TT::v4;
@@ -190,8 +194,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
         const int row = id / SV, sl = id - row * SV;
         const int g = sl / CPR, c = sl - g * CPR;
         vrow[r] = row;
-        vact[r] = row < KVB && sl < CPRV;
-        const int bo = b + (g < G ? g : 0) * gs;
+        vact[r] = row < KVB && sl < CPRV && g < GL;      // (a dead set's columns keep the zeros of the initial fill)
+        const int bo = b + (g < GL ? g : 0) * gs;
         const int bv = p.v_map ? p.v_map[bo] : bo;
         voff[r] = vact[r] ? (unsigned)((((long)bv * p.bsv + h * DH + (long)row * p.ldv + c * 8)) * 2) : OOB;
     }
@@ -525,6 +529,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
+            if (c * 16 >= GL * DH && (c + 1) * 16 <= DV) continue;      // a tile of dead sets only (compile-time after unrolling)
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
                 const E* base = cV + (st * 32 + fg * 4 + (fr >> 2)) * VROW + c * 16 + (fr & 3) * 4;
@@ -571,6 +576,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
             const int d0 = c * 16 + fg * 4;
             if (d0 >= DV) continue;
             const int g = d0 / DH, d = d0 - g * DH;   // DH % 4 == 0: a lane's 4 columns stay inside one set
+            if (g >= GL) continue;
             V4 ov;
 #pragma unroll
             for (int r = 0; r < 4; ++r) ov[r] = from_f32<E>(o[c][qt][r] * inv);
@@ -579,12 +585,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
     }
 }
 
-template <class TT, int DH, int QT, int G = 1, bool LAZY = false, bool W32 = false, int NWV = 4>
+template <class TT, int DH, int QT, int G = 1, bool LAZY = false, bool W32 = false, int NWV = 4, int GL = G>
 int launch(const AttnParams& p, hipStream_t stream) {
     constexpr int DKP = (DH / 32) * 32 + ((DH % 32) ? 16 : 0), DVP = W32 ? round_up(G * DH + 1, 32) : round_up(G * DH, 16);
     constexpr int KROW = k_row_elems(DKP), VROW = (W32 ? v_pitch_bytes32(DVP) : v_pitch_bytes(DVP)) / 2;
     constexpr size_t lds = (size_t)(2 * KVB * KROW + 2 * KVB * VROW) * 2;
-    auto kern = attn_kernel<TT, DH, QT, G, LAZY, W32, NWV>;
+    auto kern = attn_kernel<TT, DH, QT, G, LAZY, W32, NWV, GL>;
     static VfOncePerDevice attr_set;
     if (lds > 64 * 1024 && !attr_set.set_lds(reinterpret_cast<const void*>(kern), (int)lds)) return VF_ERR_LAUNCH;
     dim3 grid(((p.n + 16 * NWV * QT - 1) / (16 * NWV * QT)) * p.heads * p.B);
@@ -600,6 +606,15 @@ int dispatch_l(const AttnParams& p, hipStream_t stream) {
             case 16: return launch<TT, 16, 2, 2, LAZY>(p, stream);
             case 32: return launch<TT, 32, 2, 2, LAZY>(p, stream);
             case 40: return launch<TT, 40, 2, 2, LAZY>(p, stream);
+            default: return VF_ERR_SHAPE;
+        }
+    }
+    if (p.v_sets == 3 && p.v_sets_live == 2) {      // [chunk 0 ; chunk 1] of a three-chunk hook: the G = 3 arithmetic, two sets live
+        switch (p.dh) {
+            case 8: return launch<TT, 8, 2, 3, LAZY, false, 4, 2>(p, stream);
+            case 16: return launch<TT, 16, 2, 3, LAZY, false, 4, 2>(p, stream);
+            case 32: return launch<TT, 32, 2, 3, LAZY, false, 4, 2>(p, stream);
+            case 40: return (p.variant & 8) ? launch<TT, 40, 2, 3, LAZY, false, 4, 2>(p, stream) : launch<TT, 40, 2, 3, LAZY, false, 8, 2>(p, stream);
             default: return VF_ERR_SHAPE;
         }
     }
@@ -647,8 +662,10 @@ bool vf_attention_shared_scores_supported(int dh, int v_sets) {
 
 int vf_launch_attention(const AttnParams& p_in, int dtype, hipStream_t stream) {
     AttnParams p = p_in;
-    if (p.v_sets <= 1) { p.v_sets = 1; p.set_stride = 0; }
+    if (p.v_sets <= 1) { p.v_sets = 1; p.set_stride = 0; p.v_sets_live = 0; }
     else if (p.set_stride <= 0 || !vf_attention_shared_scores_supported(p.dh, p.v_sets)) return VF_ERR_SHAPE;
+    if (p.v_sets_live == p.v_sets) p.v_sets_live = 0;
+    if (p.v_sets_live != 0 && !(p.v_sets == 3 && p.v_sets_live == 2)) return VF_ERR_SHAPE;
     if (!p.Q || !p.K || !p.V || !p.O) return VF_ERR_ARG;
     if (p.B <= 0 || p.heads <= 0 || p.n <= 0 || p.nk <= 0) return VF_ERR_ARG;
     if (((uintptr_t)p.Q | (uintptr_t)p.K | (uintptr_t)p.V) & 15) return VF_ERR_ALIGN;
@@ -657,7 +674,7 @@ int vf_launch_attention(const AttnParams& p_in, int dtype, hipStream_t stream) {
     if ((p.ldo | p.bso) & 3) return VF_ERR_ALIGN;
     // extents of the K / V views for the buffer descriptors (sources are bounds-checked: a map entry past the batch reads zeros)
     {
-        const unsigned long nsamp = p.v_sets > 1 ? (unsigned long)(p.v_sets - 1) * p.set_stride + p.B : (unsigned long)p.B;
+        const unsigned long nsamp = p.v_sets > 1 ? (unsigned long)((p.v_sets_live ? p.v_sets_live : p.v_sets) - 1) * p.set_stride + p.B : (unsigned long)p.B;
         const unsigned long kb = ((nsamp - 1) * p.bsk + (unsigned long)(p.nk - 1) * p.ldk + (unsigned long)p.heads * p.dh) * 2;
         const unsigned long vb = ((nsamp - 1) * p.bsv + (unsigned long)(p.nk - 1) * p.ldv + (unsigned long)p.heads * p.dh) * 2;
         if (kb >= 0xFFFFFFF0ul || vb >= 0xFFFFFFF0ul) return VF_ERR_SHAPE;

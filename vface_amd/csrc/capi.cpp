@@ -144,7 +144,7 @@ int vface_attention(const void* Q, const void* K, const void* V, int64_t ldq, in
                     int64_t bso, int B, int heads, int n, int nk, int dh, float scale, int dtype, int v_sets,
                     int set_stride, void* stream) {
     AttnParams p{};
-    p.v_sets = v_sets; p.set_stride = set_stride;
+    p.v_sets = v_sets & 0xFF; p.v_sets_live = (v_sets >> 8) & 0xFF; p.set_stride = set_stride;      // (bits 8..15: live sets)
     p.Q = Q; p.K = K; p.V = V; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.bsq = bsq; p.bsk = bsk; p.bsv = bsv;
     p.qk_map = qk_map; p.v_map = v_map; p.O = O; p.ldo = ldo; p.bso = bso;
     p.B = B; p.heads = heads; p.n = n; p.nk = nk; p.dh = dh; p.scale = scale;

@@ -132,6 +132,7 @@ struct AttnParams {
     int variant;  // 0 = automatic; queries-per-wave variants for A/B benchmarking
     unsigned k_bytes, v_bytes;    // filled by the launcher: extents of the K / V views (buffer descriptors, < 4 GiB)
     int v_sets, set_stride;  // > 1: B q/k samples; output (and value) sample of set g is b + g*set_stride, scores shared
+    int v_sets_live;         // 0 = all; 2 of v_sets == 3: only sets 0, 1 are read / written, with the arithmetic of the full call
 };
 int vf_launch_attention(const AttnParams& p, int dtype, hipStream_t stream);
 

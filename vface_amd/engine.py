@@ -129,7 +129,7 @@ def plan_fusion(cfg: Optional[HookCfg], N: int, n: int, clip_flow_hw=None, live:
     compute exactly what they compute in the full batch); the plan's ``chunks`` is then ``live``, its fusion still the one the
     hook's own ``chunks`` selects."""
     pl = {"fusion": hip.FUSION_NONE, "chunks": 1, "wlin": None, "flow": None, "alpha": 0.8, "v_fixed": False,
-          "staged": None, "warp_hw": None}
+          "staged": None, "warp_hw": None, "hook_chunks": 1}
     if cfg is None or not cfg.switch_on:
         return pl
     chunks = cfg.chunks
@@ -140,7 +140,7 @@ def plan_fusion(cfg: Optional[HookCfg], N: int, n: int, clip_flow_hw=None, live:
         raise hip.VFaceHipError(f"hooked attn1: {there} live chunks of chunks={chunks}")
     if N % there:
         raise hip.VFaceHipError(f"hooked attn1: batch {N} is not divisible by its {there} chunk(s) (hook chunks={chunks})")
-    pl["chunks"] = there
+    pl["chunks"], pl["hook_chunks"] = there, chunks
     f = cfg.fusion
     if chunks == 2 or f == "replace":
         pl["fusion"] = hip.FUSION_REPLACE
@@ -710,9 +710,11 @@ class UNetEngine:
         if hw is not None and self.halo_exchange is not None:
             # every rank of a sharded clip takes part in the boundary exchange, a one-frame shard (no local field) too
             return self._attn1_sharded(xln, res_kw, p, wlin, a2vec, N, n, heads, flow, hw, alpha, out, chunks)
-        if self.decompose_attn1:
+        if self.decompose_attn1 or pl["hook_chunks"] != chunks:
+            # (a batch without its last chunk: the shared-score attention must run the FULL hook's instantiation with fewer live
+            # sets to keep the bits of the full batch -- vface_attn1_forward only knows the chunks it is handed)
             self._attn1_decomposed(xln, p, wlin, a2vec, N, n, heads, chunks, fusion, v_fixed, flow if hw is not None else None,
-                                   hw, alpha, qk_map, v_map, out, res_kw)
+                                   hw, alpha, qk_map, v_map, out, res_kw, pl["hook_chunks"])
             return out32 if s32 else out
         hip.attn1_forward(xln, p["wqkv"], wlin, p["wo"]["w"], p["wo"]["b"], out, B=N, n=n, d=d, heads=heads,
                           chunks=chunks, fusion=fusion, ldx=xln.stride(0), ldo=d, workspace=ws,
@@ -722,7 +724,7 @@ class UNetEngine:
         return out32 if s32 else out
 
     def _attn1_decomposed(self, xln, p, wlin, a2vec, N, n, heads, chunks, fusion, v_fixed, flow, hw, alpha, qk_map, v_map,
-                          out, res_kw):
+                          out, res_kw, hook_chunks=None):
         """The launch sequence of ``vface_attn1_forward`` (capi.cpp) issued call by call from here -- the same kernels with the
         same parameters in the same order, hence the same bits (tests/test_kernels_gpu.py) -- so that ``bench.py``'s
         instrumented pass can put HIP events around the projections and the attention kernel separately."""
@@ -750,9 +752,10 @@ class UNetEngine:
         kw = dict(heads=heads, n=n, nk=n, dh=d // heads, ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d,
                   bsv=n * 3 * d, ldo=d, bso=n * d,
                   scale=float(np.float32(1.0) / np.sqrt(np.float32(d // heads))))   # fp32 arithmetic, as capi.cpp computes it
-        if fusion == hip.FUSION_REPLACE and hip.load().vface_attention_shared_scores_supported(d // heads, chunks):
-            hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=F_, v_map=v_map if v_fixed else None, v_sets=chunks,
-                          set_stride=F_, **kw)
+        hc = hook_chunks or chunks
+        if fusion == hip.FUSION_REPLACE and chunks > 1 and hip.load().vface_attention_shared_scores_supported(d // heads, hc):
+            hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=F_, v_map=v_map if v_fixed else None, v_sets=hc,
+                          v_sets_live=chunks, set_stride=F_, **kw)
         else:
             hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=N, qk_map=qk_map if fusion == hip.FUSION_REPLACE else None,
                           v_map=v_map if v_fixed else None, **kw)
@@ -907,8 +910,10 @@ class UNetEngine:
                   bsv=n * 3 * d, ldo=d, bso=n * d,
                   scale=float(np.float32(1.0) / np.sqrt(np.float32(d // heads))))   # fp32 arithmetic, as capi.cpp computes it
         v_map = self._map("v_fixed", N, F_) if v_fixed else None
-        if fusion == hip.FUSION_REPLACE and hip.load().vface_attention_shared_scores_supported(d // heads, chunks):
-            hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=F_, v_map=v_map, v_sets=chunks, set_stride=F_, **kw)
+        if fusion == hip.FUSION_REPLACE and chunks > 1 and \
+                hip.load().vface_attention_shared_scores_supported(d // heads, pl["hook_chunks"]):
+            hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=F_, v_map=v_map, v_sets=pl["hook_chunks"], v_sets_live=chunks,
+                          set_stride=F_, **kw)
         else:
             hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=N,
                           qk_map=self._map("qk_replace", N, F_) if fusion == hip.FUSION_REPLACE else None, v_map=v_map, **kw)

@@ -245,13 +245,15 @@ def conv_uses_patch_kernel(H: int, W: int, cin: int, cout: int, window: int = 3,
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, *, B: int, heads: int, n: int,
               nk: int, dh: int, ldq: int, ldk: int, ldv: int, bsq: int, bsk: int, bsv: int, ldo: int, bso: int,
-              scale: float, qk_map=None, v_map=None, variant: int = 0, v_sets: int = 1, set_stride: int = 0):
+              scale: float, qk_map=None, v_map=None, variant: int = 0, v_sets: int = 1, set_stride: int = 0,
+              v_sets_live: int = 0):
     """``v_sets > 1``: B q/k samples, output sample ``b + g*set_stride`` uses v of that sample (through ``v_map``)
-    with the probabilities of q/k sample b, computed once (the "replace" injection)."""
+    with the probabilities of q/k sample b, computed once (the "replace" injection).  ``v_sets_live`` (2 of 3): only the first
+    sets exist in the batch; their outputs are those of the full call bit for bit."""
     lib = load()
     rc = lib.vface_attention(_p(q), _p(k), _p(v), ldq, ldk, ldv, bsq, bsk, bsv, _p(qk_map), _p(v_map), _p(out), ldo,
-                             bso, B, heads, n, nk, dh, scale, dtype_code(out.dtype) | (variant << 8), v_sets,
-                             set_stride, _stream())
+                             bso, B, heads, n, nk, dh, scale, dtype_code(out.dtype) | (variant << 8),
+                             v_sets | ((v_sets_live if v_sets_live != v_sets else 0) << 8), set_stride, _stream())
     _check(rc, "vface_attention")
 
 
