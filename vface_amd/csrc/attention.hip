@@ -194,10 +194,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
         const int row = id / SV, sl = id - row * SV;
         const int g = sl / CPR, c = sl - g * CPR;
         vrow[r] = row;
-        vact[r] = row < KVB && sl < CPRV && g < GL;      // (a dead set's columns keep the zeros of the initial fill)
+        vact[r] = row < KVB && sl < CPRV;
         const int bo = b + (g < GL ? g : 0) * gs;
         const int bv = p.v_map ? p.v_map[bo] : bo;
-        voff[r] = vact[r] ? (unsigned)((((long)bv * p.bsv + h * DH + (long)row * p.ldv + c * 8)) * 2) : OOB;
+        // (a dead set's slots load from an out-of-range offset = zeros: the same instructions under the same lane masks as the
+        // full call -- masking those lanes out instead gave wrong values in the eight-wave form)
+        voff[r] = (vact[r] && g < GL) ? (unsigned)((((long)bv * p.bsv + h * DH + (long)row * p.ldv + c * 8)) * 2) : OOB;
     }
     const unsigned kstep = (unsigned)(KVB * p.ldk * 2), vstep = (unsigned)(KVB * p.ldv * 2);
     auto stage_block = [&](int kb, int buf) {
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < RV; ++r) {
             if (r * NTH + wave * 64 < KVB * SV) {
-                const unsigned off = (r0 + vrow[r] < nk) ? voff[r] + (unsigned)kb * vstep : OOB;
+                const unsigned off = ((GL == G || voff[r] != OOB) && r0 + vrow[r] < nk) ? voff[r] + (unsigned)kb * vstep : OOB;
                 if (vact[r]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, LDS_PTR(dV + (r * NTH + wave * 64) * 8), 16, off, 0, 0, 0);
             }
         }
@@ -614,7 +616,10 @@ int dispatch_l(const AttnParams& p, hipStream_t stream) {
             case 8: return launch<TT, 8, 2, 3, LAZY, false, 4, 2>(p, stream);
             case 16: return launch<TT, 16, 2, 3, LAZY, false, 4, 2>(p, stream);
             case 32: return launch<TT, 32, 2, 3, LAZY, false, 4, 2>(p, stream);
-            case 40: return (p.variant & 8) ? launch<TT, 40, 2, 3, LAZY, false, 4, 2>(p, stream) : launch<TT, 40, 2, 3, LAZY, false, 8, 2>(p, stream);
+            // (four waves per workgroup: bit-identical to the eight-wave form the full call takes by default -- the eight-wave
+            // instantiation with two live sets did NOT reproduce the full call's bits on the GPU (cause not found: open item in
+            // DESIGN.md), so it is not instantiated)
+            case 40: return launch<TT, 40, 2, 3, LAZY, false, 4, 2>(p, stream);
             default: return VF_ERR_SHAPE;
         }
     }
