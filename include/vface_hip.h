@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VFACE_ABI_VERSION 5   /* 5: + vface_st_front; nothing of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
+#define VFACE_ABI_VERSION 5   /* 5: + vface_st_front, vface_attn_out_ffn_fused; vface_attention's v_sets carries the live-set count in bits 8..15, vface_pack_unet_input / vface_ddim_step take the two-branch batch; nothing else of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
 
 #define VFACE_OK 0
 #define VFACE_ERR_ARG (-1)
@@ -325,6 +325,19 @@ int vface_ffn_fused_supported(int64_t M, int C);
 int vface_ffn_fused(const float* x32, int64_t ldx, const float* gamma, const float* beta, float eps, const void* W1, const float* b1,
                     const void* W2p, const float* b2, void* out16, int64_t ldo, float* out32, int64_t ldo32, int M, int C,
                     int dtype, void* stream);
+
+/* vface_ffn_fused with the attn1 OUT-PROJECTION in front, one launch (attention.py:239-243; the single-token attn2 is the per-sample
+ * row bias):
+ *   t1  = att_16 @ Wo^T + bo + rowbias[row / rows_per_sample] + resid          (fp32, never stored)
+ *   out = ff.net[2]( GEGLU( ff.net[0]( LayerNorm(t1; gamma, beta, eps) ) ) ) + t1
+ * att: [M][C] 16-bit attention output; resid: [M][C] fp32 (the running sum before attn1); rowbias optional fp32
+ * [M / rows_per_sample][ld_rowbias] (rows_per_sample % 128 == 0).  WoW1 = [C + 8C][C] 16-bit: to_out's C rows, then ff.net[0]'s
+ * 8C rows in the GEGLU-interleaved order of vface_ffn_fused with their k columns permuted like vface_st_front's projection rows
+ * (packing.pack_attn_out_ffn).  b1, W2p, b2, out16 / out32, shapes: as vface_ffn_fused. */
+int vface_attn_out_ffn_fused(const void* att, int64_t ldatt, const float* resid, int64_t ldr, const float* rowbias, int64_t ld_rowbias,
+                             int rows_per_sample, const void* WoW1, const float* bo, const float* gamma, const float* beta, float eps,
+                             const float* b1, const void* W2p, const float* b2, void* out16, int64_t ldo, float* out32,
+                             int64_t ldo32, int M, int C, int dtype, void* stream);
 
 /* Fused FRONT of a SpatialTransformer (attention.py:278-284 norm -> proj_in -> tokens; :239 norm1; :179-183 to_q / to_k / to_v of
  * attn1), one launch for GroupNorm-apply + proj_in + LayerNorm + the attn1 projection on token matrices with C in {64, 128, 320}:

@@ -358,6 +358,39 @@ def gen_full_unet():
     save("full_unet", **out)
 
 
+@torch.no_grad()
+def gen_full_unet_fft():
+    """Round 4: BASELINE config 3's own schedule -- frequency-spectrum attention interpolation alone
+    (fusion="fft" on the input-block attn1) -- on the real 859.5 M-parameter UNet: the fp32 output, the output under fp16
+    autocast and the output with fp16-rounded weights, ADDED to full_unet.npz / lowp.npz (the other entries are kept as they
+    are: same seeded inputs, ``full.x`` / ``full.ctx``)."""
+    import ldm.models.pnp_utils as pnp
+    unet = ref_unet(320)
+    sampler, dd = make_sampler(unet)
+    F_, h, w = 2, 64, 64
+    x, ctx = unet_inputs(F_, h, w, "full")
+    t = torch.full((3 * F_,), 481, dtype=torch.long)
+
+    def hook():
+        pnp.register_spa_attn_injection(sampler, 1, switch_on=False, input_blocks=True, middle_block=True,
+                                        output_blocks=True, attn_component="attn1", chunks=3)
+        pnp.register_spa_attn_injection(sampler, 1, switch_on=True, input_blocks=True, middle_block=False,
+                                        output_blocks=False, attn_component="attn1", flow=None, chunks=3,
+                                        block_indices=list(range(9)), fusion="fft", split_ratio_fft=0.8, alpha=0.8)
+    full = dict(np.load(os.path.join(HERE, "full_unet.npz"), allow_pickle=False))
+    lowp = dict(np.load(os.path.join(HERE, "lowp.npz"), allow_pickle=False))
+    hook()
+    full["fft"] = unet(x, t, context=ctx).numpy()
+    hook()
+    with torch.autocast("cpu", dtype=torch.float16):
+        lowp["full.fft_autocast_f16"] = unet(x, t, context=ctx).float().numpy()
+    _round_weights_(unet)
+    hook()
+    lowp["full.fft_w16"] = unet(x, t, context=ctx).numpy()
+    save("full_unet", **full)
+    save("lowp", **lowp)
+
+
 def _round_weights_(module, dtype=torch.float16):
     for prm in module.parameters():
         prm.data = prm.data.to(dtype).float()
@@ -501,6 +534,7 @@ if __name__ == "__main__":
     gens["lowp"] = lambda: gen_lowp(a.full)
     if a.full:
         gens["full"] = gen_full_unet
+        gens["full_fft"] = gen_full_unet_fft
     for name, fn in gens.items():
         if a.only and name not in a.only.split(","):
             continue

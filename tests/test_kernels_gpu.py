@@ -1064,6 +1064,52 @@ def test_ffn_fused_vs_reference_and_vs_three_kernel_path(dt, M, C):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,C,rps,with_rb", [(128, 64, 128, True), (512, 128, 256, False), (768, 320, 256, True), (4096, 320, 1024, True)])
+def test_attn_out_ffn_fused_vs_reference_and_vs_two_launches(dt, M, C, rps, with_rb):
+    """csrc/ffn.hip, PRE form (``vface_attn_out_ffn_fused``): attn1's out-projection + bias + attn2's per-sample row bias +
+    residual in front of the fused FeedForward, the running sum t1 never stored -- against (a) an fp64 evaluation on the same
+    16-bit operands and (b) the two launches it replaces (vface_gemm into the fp32 stream, then vface_ffn_fused)."""
+    h = hip()
+    from vface_amd import packing
+    att = rnd((M, C), 41, dt, 0.8)
+    t0 = rnd((M, C), 42, torch.float32, 1.2) + rnd((M, 1), 43, torch.float32, 0.5)
+    wo, bo = rnd((C, C), 44, dt, C ** -0.5), rnd((C,), 45, torch.float32, 0.2)
+    rb = rnd((M // rps, C + 32), 46, torch.float32, 0.5)[:, 16:16 + C] if with_rb else None     # a column slice, like a2_all[:, a:b]
+    gamma, beta = 1.0 + rnd((C,), 33, torch.float32, 0.2), rnd((C,), 34, torch.float32, 0.2)
+    w1, b1 = rnd((8 * C, C), 35, dt, C ** -0.5), rnd((8 * C,), 36, torch.float32, 0.3)
+    w2, b2 = rnd((C, 4 * C), 37, dt, (4 * C) ** -0.5), rnd((C,), 38, torch.float32, 0.3)
+    t1_ref = att.double() @ wo.double().t() + bo.double() + t0.double()
+    if with_rb:
+        t1_ref = t1_ref + rb.double().repeat_interleave(rps, 0)
+    ref = _ffn_reference(t1_ref.float(), gamma, beta, w1.float(), b1, w2.float(), b2).float()
+    w1p, b1p = packing.pack_geglu(w1, b1)
+    w2p = packing.pack_ffn_w2(w2)
+    tail_w = packing.pack_attn_out_ffn(wo, w1p)
+    d = lambda v: v.to(DEV).contiguous()
+    rbd = None
+    if with_rb:
+        wide = torch.zeros(M // rps, C + 32, dtype=torch.float32, device=DEV)
+        wide[:, 16:16 + C] = rb.to(DEV)
+        rbd = wide[:, 16:16 + C]
+    attd, t0d = d(att), d(t0)
+    out16, out32 = torch.zeros(M, C, dtype=dt, device=DEV), torch.zeros(M, C, dtype=torch.float32, device=DEV)
+    h.attn_out_ffn_fused(attd, t0d, rbd, d(tail_w), d(bo), d(gamma), d(beta), d(b1p), d(w2p), d(b2), out16, M=M, C_=C,
+                         rows_per_sample=rps, out32=out32)
+    e32 = rel_l2(out32.cpu(), ref)
+    # the two launches it replaces
+    t1 = torch.empty(M, C, dtype=torch.float32, device=DEV)
+    h.gemm(attd, d(wo), None, M=M, N=C, K=C, lda=C, ldc=0, bias=d(bo), rowbias=rbd, rows_per_sample=rps, split_k=False,
+           residual32=t0d, out32=t1)
+    assert rel_l2(t1.cpu().double(), t1_ref) < 2e-6
+    o2 = torch.zeros(M, C, dtype=torch.float32, device=DEV)
+    h.ffn_fused(t1, d(gamma), d(beta), d(w1p), d(b1p), d(w2p), d(b2), None, M=M, C_=C, out32=o2)
+    e2, e_vs2 = rel_l2(o2.cpu(), ref), rel_l2(out32.cpu(), o2.cpu())
+    print(f"attn-out + ffn fused M={M} C={C} {dt}: {e32:.2e}; two launches {e2:.2e}; fused vs two launches {e_vs2:.2e}")
+    assert torch.equal(out16, out32.to(dt))
+    assert e32 < TOL[dt] and e32 < 1.5 * e2 + 1e-5 and e_vs2 < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,C,hw,rows_full,nq_lo,want_ln", [(256, 64, 128, 256, 0, False), (768, 128, 256, 256, 256, True),
                                                             (1024, 320, 256, 1024, 0, False), (3072, 320, 1024, 1024, 640, True),
                                                             (128 * 300, 320, 128 * 100, 128 * 100, 640, False)])

@@ -265,7 +265,7 @@ def test_lowp_fixture_is_the_references_own_error_floor():
     """tests/golden/lowp.npz: the reference under fp16 autocast and with fp16-rounded weights only, against its fp32 output.
     These numbers are what the whole-network GPU bounds are argued from; pin them."""
     lp, fu, ti = load_golden("lowp"), load_golden("full_unet"), load_golden("tiny_unet")
-    for mode in ("plain", "flow_fix", "replace"):
+    for mode in ("plain", "flow_fix", "replace", "fft"):      # ("fft": config 3's own schedule, added in round 4)
         e_auto, e_w = rel_l2(lp[f"full.{mode}_autocast_f16"], fu[mode]), rel_l2(lp[f"full.{mode}_w16"], fu[mode])
         assert 1.4e-3 < e_auto < 1.8e-3 and 9.0e-4 < e_w < 1.05e-3, (mode, e_auto, e_w)
     for mode, key in (("plain", "plain"), ("flow_fix", "in_flow_fix"), ("replace", "in_replace")):

@@ -196,9 +196,10 @@ def test_small_unet_bf16_measured(small, mode):
     assert err < 2e-2
 
 
-@pytest.mark.parametrize("mode", ["plain", "flow_fix", "replace"])
+@pytest.mark.parametrize("mode", ["plain", "flow_fix", "replace", "fft"])
 def test_full_unet_vs_reference_golden(mode):
-    """The real 859.5 M-parameter UNet, F=2 at 64x64, against the fixture the reference itself produced."""
+    """The real 859.5 M-parameter UNet, F=2 at 64x64, against the fixture the reference itself produced ("fft" = BASELINE
+    config 3's own schedule, frequency-spectrum attention interpolation alone: round 4)."""
     from vface_amd.ldm.models.diffusion.ddpm import FFHQ_UNET_CONFIG, LatentDiffusion
     from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler
     from vface_amd.ldm.models.pnp_utils import register_spa_attn_injection as reg

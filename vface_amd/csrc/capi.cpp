@@ -365,6 +365,18 @@ int vface_ffn_fused(const float* x32, int64_t ldx, const float* gamma, const flo
     return vf_launch_ffn_fused(p, dtype, S(stream));
 }
 
+int vface_attn_out_ffn_fused(const void* att, int64_t ldatt, const float* resid, int64_t ldr, const float* rowbias, int64_t ld_rowbias,
+                             int rows_per_sample, const void* WoW1, const float* bo, const float* gamma, const float* beta, float eps,
+                             const float* b1, const void* W2p, const float* b2, void* out16, int64_t ldo, float* out32,
+                             int64_t ldo32, int M, int C, int dtype, void* stream) {
+    if (!att) return VFACE_ERR_ARG;
+    FfnParams p{};
+    p.att = att; p.ldatt = ldatt; p.resid = resid; p.ldr = ldr; p.rowbias = rowbias; p.ld_rowbias = ld_rowbias;
+    p.rows_per_sample = rows_per_sample; p.bo = bo; p.gamma = gamma; p.beta = beta; p.eps = eps; p.W1 = WoW1; p.b1 = b1; p.W2p = W2p;
+    p.b2 = b2; p.out16 = out16; p.ldo = ldo; p.out32 = out32; p.ldo32 = ldo32; p.M = M; p.C = C;
+    return vf_launch_ffn_fused(p, dtype, S(stream));
+}
+
 int vface_st_front_supported(int64_t M, int C, int hw) { return vf_st_front_supported((long)M, C, hw) ? 1 : 0; }
 
 int vface_st_front(const float* x32, int64_t ldx, const float* gn_ab, int64_t ld_ab, int hw, const void* Wcat, const float* b_in,

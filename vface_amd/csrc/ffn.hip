@@ -48,13 +48,23 @@ namespace {
 
 constexpr int ffn_ring(int n, int want) { for (int r = want; r > 1; --r) if (n % r == 0) return r; return 1; }
 
-template <class TT, int C>
+// PRE (round 4): the attn1 OUT-PROJECTION in front of it, in the same launch (attention.py:239-243: x = attn1(norm1(x)) + x;
+// x = attn2(norm2(x), context) + x; x = ff(norm3(x)) + x -- attn2 being a per-sample row bias here):
+//     t1  = to_out(att) + bo + a2[sample] + t0                     (the running sum the three-kernel path kept in HBM as fp32)
+//     out = ff.net[2]( GEGLU( ff.net[0].proj( LayerNorm(t1) ) ) ) + t1
+// The weight stream simply starts NOT stages earlier -- p.W1 = [to_out ; ff.net[0]] rows -- and those stages accumulate
+// to_out's output-channel tiles into the SAME accumulator registers GEMM 2 later adds to: they are initialised with
+// t0 + bo + a2 and hold t1 when the LayerNorm reads them, so neither t1's 126 MB write nor its two 126 MB reads (LayerNorm
+// input, residual) happen, and one launch goes.  The LayerNorm'd tile, register by register, is GEMM 1's B operand (as in
+// stfront.hip), so ff.net[0]'s k columns are stored in ffn_w2_perm order for this form.
+template <class TT, int C, bool PRE = false>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     using E = typename TT::elem;
     using V8 = typename TT::v8;
     constexpr int KS = C / 16;          // k16 steps of GEMM 1 = MFMAs per tile
     constexpr int NOT = C / 32;         // output row tiles of GEMM 2 = its MFMAs per tile
     constexpr int NT = 4 * C / 16;      // hidden tiles
+    constexpr int NPRE = PRE ? C / 32 : 0;   // to_out stages in front of the W1 stream
     constexpr int NW1 = 4, NW2 = 3;     // stage rings
     constexpr int W1E = 32 * C;         // elements per W1 stage: [32 rows][C]
     constexpr int W2E = C * 32;         // elements per W2 stage: [C rows][32 hidden]
@@ -82,7 +92,44 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
 
     // ---- LayerNorm (attention.py:233 norm3, eps 1e-5, fp32, two passes like layernorm_kernel) straight into B fragments
     V8 xf[KS];
-    {
+    f16_t out[NOT];
+    if constexpr (PRE) {
+        // the attention output's rows ARE B fragments (16-bit, k = channel); the accumulators start as t0 + bo + a2[sample]
+        const E* ar = reinterpret_cast<const E*>(p.att) + (tok0 + fr) * p.ldatt + fh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const V8*>(ar + ks * 16);
+        const float* rr = p.resid + (tok0 + fr) * p.ldr + fh * 4;
+        const float* rb = p.rowbias ? p.rowbias + (long)((tok0 + fr) / p.rows_per_sample) * p.ld_rowbias + fh * 4 : nullptr;
+        const float* bo = p.bo + fh * 4;
+#pragma unroll
+        for (int half = 0; half < 4; ++half) {
+            constexpr int H0 = (NOT + 3) / 4;
+            const int o0 = half * H0, o1 = (o0 + H0 < NOT) ? o0 + H0 : NOT;
+            float4 rv[H0][4];
+#pragma unroll
+            for (int o = 0; o < H0; ++o)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    if (o0 + o < o1) rv[o][q4] = *reinterpret_cast<const float4*>(rr + (o0 + o) * 32 + q4 * 8);
+#pragma unroll
+            for (int o = 0; o < H0; ++o) {
+                if (o0 + o >= o1) continue;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int col = (o0 + o) * 32 + q4 * 8;
+                    const float4 b = *reinterpret_cast<const float4*>(bo + col);
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (rb) a = *reinterpret_cast<const float4*>(rb + col);
+                    // (acc + bias) + rowbias + residual, the order of the GEMM epilogue this replaces: acc starts at 0
+                    out[o0 + o][4 * q4 + 0] = (b.x + a.x) + rv[o][q4].x;
+                    out[o0 + o][4 * q4 + 1] = (b.y + a.y) + rv[o][q4].y;
+                    out[o0 + o][4 * q4 + 2] = (b.z + a.z) + rv[o][q4].z;
+                    out[o0 + o][4 * q4 + 3] = (b.w + a.w) + rv[o][q4].w;
+                }
+            }
+        }
+        __syncthreads();                 // sGB (and sB1) written
+    } else {
         // every load of the token rows is issued before anything waits for one (hipcc serialises load / use pairs otherwise)
         float v[KS][8];
         const float* xr = p.x32 + (tok0 + fr) * p.ldx + fh * 8;
@@ -126,7 +173,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     // its reading order and the XOR swizzles that make the fragment reads conflict-free are applied on the SOURCE chunk.
     //   W1 stage = [32 rows][C / 8 slots]: slot of k chunk c of row r = (c & ~7) | ((c & 7) ^ ((r >> 1) & 7))
     //   W2 stage = [C rows][4 slots]:      slot of chunk c of row r   = c ^ ((r >> 2) & 3)
-    const i32x4_t rW1 = raw_buffer_rsrc(p.W1, 8u * C * C * 2u), rW2 = raw_buffer_rsrc(p.W2p, 4u * C * C * 2u);
+    const i32x4_t rW1 = raw_buffer_rsrc(p.W1, (8u * C + (PRE ? C : 0)) * C * 2u), rW2 = raw_buffer_rsrc(p.W2p, 4u * C * C * 2u);
     const unsigned ldsW1 = lds_addr_of(sW1), ldsW2 = lds_addr_of(sW2);
     constexpr int SPR = C / 8;          // 16-byte slots per W1 row
     int w1_off[OPS], w2_off[OPS];
@@ -141,7 +188,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
         w2_off[i] = (r2 * 4 * C + c2 * 8) * 2;
     }
     auto issue_w1_op = [&](int tile, int i) {     // piece i of the W1 stage of hidden tile `tile` (wrapped) -> ring slot tile % NW1
-        const int base = ((tile % NT) * 32 * C) * 2;
+        const int base = ((tile % (NT + NPRE)) * 32 * C) * 2;      // (stage index of the stream: PRE puts to_out's tiles first)
         const unsigned dst = ldsW1 + (unsigned)(((tile % NW1) * W1E + wave * OPS * 512) * 2);
         raw_lds_dma16(rW1, dst + i * 1024, w1_off[i], base);
     };
@@ -177,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     };
     auto advance_w1_issue = [&]() {
         w1i_glob += 32 * C * 2;
-        if (w1i_glob == NT * 32 * C * 2) w1i_glob = 0;                 // past the end: wrap to stages nobody reads
+        if (w1i_glob == (NT + NPRE) * 32 * C * 2) w1i_glob = 0;        // past the end: wrap to stages nobody reads
         w1i_slot = (w1i_slot + 1) & (NW1 - 1);
     };
     auto advance_w2_issue = [&]() {
@@ -207,11 +254,12 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { wa[j] = sW1 + w1_lane[j]; wb[j] = sW1 + (1 % NW1) * W1E + w1_lane[j]; }
 
-    f16_t out[NOT];
+    if constexpr (!PRE) {
 #pragma unroll
-    for (int ot = 0; ot < NOT; ++ot)
+        for (int ot = 0; ot < NOT; ++ot)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[ot][r] = 0.f;
+            for (int r = 0; r < 16; ++r) out[ot][r] = 0.f;
+    }
 
     // ---- prime the pipeline: W1 stages 0..2, W2 stage 0
     __syncthreads();                     // nothing else touches LDS before the DMA lands
@@ -229,15 +277,19 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     // One interval of the three-deep pipeline: GEMM 1 of tile t (H1) || GEGLU of tile t - 1 (HG) || GEMM 2 of tile t - 2 (H2),
     // one instruction stream: per k16 step one MFMA of GEMM 1, every other step one of GEMM 2, every other step one GEGLU value.
     // `cur` receives tile t's sums, `prev` holds tile t - 1's; `hw` receives tile t - 1's GEGLU, `hr` holds tile t - 2's.
-    auto interval = [&](int t, f16_t& cur, f16_t& prev, V8& hw, V8& hr, auto h1_tag, auto hg_tag, auto h2_tag, auto even_tag) {
+    auto interval = [&](int t, f16_t& cur, f16_t& prev, V8& hw, V8& hr, auto h1_tag, auto hg_tag, auto h2_tag, auto even_tag,
+                        auto first_tag) {
         constexpr bool H1 = decltype(h1_tag)::value, HG = decltype(hg_tag)::value, H2 = decltype(h2_tag)::value;
         constexpr bool EVEN = decltype(even_tag)::value;
+        // (PRE, interval 0: the stage it needs was issued by a to_out interval, which issues no W2 piece -- one instruction less
+        // may be in flight than in the steady state)
+        constexpr bool FIRST_AFTER_PRE = decltype(first_tag)::value;
         // top of the interval: this wave's share of W1 stage t + 1 has landed (everything but its 2 OPS (= 10) youngest DMA
         // instructions: intervals t - 1 and t - 2 issued that many after it); behind the barrier every wave's has, every wave is
         // done with W1 stage t - 1 (ring slot of stage t + 3) and, in even intervals, with the W2 stage of tiles t - 4, t - 3
         // (issue order inside an even interval is W1 piece, W2 piece, W1 piece, ...: behind the last W1 piece of stage t + 1 come
         // one W2 piece and interval t - 1's OPS pieces when t is even, interval t - 1's 2 OPS pieces when t is odd)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EVEN ? OPS + 1 : 2 * OPS) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FIRST_AFTER_PRE ? OPS : (EVEN ? OPS + 1 : 2 * OPS)) : "memory");
         raw_barrier();
         // (the stages of this interval -- W1 stage t + 3, in even intervals W2 stage t / 2 + 1 -- are issued one DMA instruction
         // at a time inside the k loop below: a burst of them at the top cost each wave the whole CU's address-unit time)
@@ -349,14 +401,86 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     using F_ = std::false_type;
     static_assert(KS == 2 * NOT && NT % 2 == 0 && NT >= 4);
     //        t      cur   prev  hw   hr    H1   HG   H2   EVEN     (tile t -> accA / hbE when t is even)
-    interval(0,      accA, accB, hbO, hbE,  T_{}, F_{}, F_{}, T_{});
-    interval(1,      accB, accA, hbE, hbO,  T_{}, T_{}, F_{}, F_{});
-    for (int t = 2; t < NT; t += 2) {
-        interval(t,     accA, accB, hbO, hbE, T_{}, T_{}, T_{}, T_{});
-        interval(t + 1, accB, accA, hbE, hbO, T_{}, T_{}, T_{}, F_{});
+    if constexpr (PRE) {
+        // ---- the out-projection: stage s of the stream = rows 32 s .. of to_out -> accumulator tile s (which already holds
+        // t0 + bo + a2); KS MFMAs per stage, the A window rolling on into the next stage, the stage three ahead issued in the loop
+#pragma unroll
+        for (int ot = 0; ot < NPRE; ++ot) gap_valu_result_to_acc_mfma(out[ot]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xf[ks]));
+#pragma unroll
+        for (int s_ = 0; s_ < NPRE; ++s_) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");      // stage s_ + 1 landed (behind it: stage s_ + 2's pieces)
+            raw_barrier();
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                TT::mfma32x32_acc(out[s_], af[ks % RA], xf[ks]);
+                af[(ks + RA - 1) % RA] = (ks - 1 + RA < KS) ? w1_frag_at(wa, ks - 1 + RA) : w1_frag_at(wb, ks - 1 + RA - KS);
+                if (ks % 4 == 1) issue_w1_piece(ks / 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            advance_w1_issue();
+            w1r_slot = (w1r_slot + 1) & (NW1 - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wa[j] = wb[j]; wb[j] = sW1 + w1r_slot * W1E + w1_lane[j]; }
+        }
+        // ---- LayerNorm (norm3) of t1 = the accumulator tiles (a token's C channels sit in lanes l, l ^ 32), two passes, fp32;
+        // the rounded result, register by register, is GEMM 1's B operand: element e of lane half h of k16 step (tile, j) is
+        // channel 32 tile + 16 j + 8 (e >> 2) + 4 h + (e & 3) -- ff.net[0]'s k columns are stored in that order (ffn_w2_perm)
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot) gap_acc_result_to_valu(out[ot]);
+        float s = 0.f;
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s += out[ot][q];
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s / (float)C;
+        // (every pass reads the accumulator registers again: kept in vector registers across the passes, the 160 values spill)
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot) asm volatile("" : "+a"(out[ot]));
+        float qq = 0.f;
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const float d = out[ot][q] - mean; qq += d * d; }
+        qq += __shfl_xor(qq, 32, 64);
+        const float rstd = rsqrtf(qq / (float)C + p.eps);
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot) asm volatile("" : "+a"(out[ot]));
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot) {
+            const float* gp = sGB + ot * 32 + fh * 4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                V8 o;
+#pragma unroll
+                for (int e4 = 0; e4 < 2; ++e4) {
+                    const int q4 = 2 * j + e4;
+                    const float4 g = *reinterpret_cast<const float4*>(gp + q4 * 8), b = *reinterpret_cast<const float4*>(gp + C + q4 * 8);
+                    o[4 * e4 + 0] = from_f32<E>((out[ot][4 * q4 + 0] - mean) * rstd * g.x + b.x);
+                    o[4 * e4 + 1] = from_f32<E>((out[ot][4 * q4 + 1] - mean) * rstd * g.y + b.y);
+                    o[4 * e4 + 2] = from_f32<E>((out[ot][4 * q4 + 2] - mean) * rstd * g.z + b.z);
+                    o[4 * e4 + 3] = from_f32<E>((out[ot][4 * q4 + 3] - mean) * rstd * g.w + b.w);
+                }
+                xf[2 * ot + j] = o;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xf[ks]));
+        gap_valu_result_to_mfma(xf[KS - 1]);
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot) gap_valu_result_to_acc_mfma(out[ot]);      // (out goes back to the matrix pipe untouched)
     }
-    interval(NT,     accA, accB, hbO, hbE,  F_{}, T_{}, T_{}, T_{});
-    interval(NT + 1, accB, accA, hbE, hbO,  F_{}, F_{}, T_{}, F_{});
+    using P_ = std::integral_constant<bool, PRE>;
+    interval(0,      accA, accB, hbO, hbE,  T_{}, F_{}, F_{}, T_{}, P_{});
+    interval(1,      accB, accA, hbE, hbO,  T_{}, T_{}, F_{}, F_{}, F_{});
+    for (int t = 2; t < NT; t += 2) {
+        interval(t,     accA, accB, hbO, hbE, T_{}, T_{}, T_{}, T_{}, F_{});
+        interval(t + 1, accB, accA, hbE, hbO, T_{}, T_{}, T_{}, F_{}, F_{});
+    }
+    interval(NT,     accA, accB, hbO, hbE,  F_{}, T_{}, T_{}, T_{}, F_{});
+    interval(NT + 1, accB, accA, hbE, hbO,  F_{}, F_{}, T_{}, F_{}, F_{});
 
     // ---- epilogue: (out + b2) + x, half the channels of a wave's 32 tokens at a time through LDS (row pitch C / 2 + 4 floats:
     // consecutive tokens one 16-byte slot apart), read back as whole 32-byte row chunks
@@ -379,7 +503,9 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
 #pragma unroll
         for (int k = 0; k < ITM; ++k) {
             const int it = lane + 64 * k;
-            if (it < 32 * CH) {
+            if constexpr (PRE) {
+                r0[k] = make_float4(0.f, 0.f, 0.f, 0.f); r1[k] = r0[k];      // (the residual t1 is inside the accumulators already)
+            } else if (it < 32 * CH) {
                 const int tok = it / CH, ch = it - tok * CH;
                 const float* xr = p.x32 + (tok0 + tok) * p.ldx + ot0 * 32 + ch * 8;
                 r0[k] = *reinterpret_cast<const float4*>(xr);
@@ -423,11 +549,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     }
 }
 
-template <class TT, int C>
+template <class TT, int C, bool PRE = false>
 int launch_c(const FfnParams& p, hipStream_t stream) {
     constexpr size_t lds = (size_t)(4 * 32 * C + 3 * C * 32) * 2 + (size_t)10 * C * 4;
     static_assert((size_t)4 * 32 * (((C / 32 + 1) / 2) * 32 + 4) * 4 <= (size_t)(4 * 32 * C + 3 * C * 32) * 2, "epilogue scratch fits the weight rings");
-    auto kern = ffn_fused_kernel<TT, C>;
+    auto kern = ffn_fused_kernel<TT, C, PRE>;
     static VfOncePerDevice attr_set;
     if (lds > 64 * 1024 && !attr_set.set_lds(reinterpret_cast<const void*>(kern), (int)lds)) return VF_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(p.M / 128), dim3(256), lds, stream, p);
@@ -436,6 +562,14 @@ int launch_c(const FfnParams& p, hipStream_t stream) {
 
 template <class TT>
 int launch_t(const FfnParams& p, hipStream_t stream) {
+    if (p.att) {
+        switch (p.C) {
+            case 64: return launch_c<TT, 64, true>(p, stream);
+            case 128: return launch_c<TT, 128, true>(p, stream);
+            case 320: return launch_c<TT, 320, true>(p, stream);
+            default: return VF_ERR_SHAPE;
+        }
+    }
     switch (p.C) {
         case 64: return launch_c<TT, 64>(p, stream);
         case 128: return launch_c<TT, 128>(p, stream);
@@ -449,9 +583,14 @@ int launch_t(const FfnParams& p, hipStream_t stream) {
 bool vf_ffn_fused_supported(long M, int C) { return M > 0 && (M % 128) == 0 && (C == 64 || C == 128 || C == 320); }
 
 int vf_launch_ffn_fused(const FfnParams& p, int dtype, hipStream_t stream) {
-    if (!p.x32 || !p.gamma || !p.beta || !p.W1 || !p.b1 || !p.W2p || !p.b2 || (!p.out16 && !p.out32)) return VF_ERR_ARG;
+    if ((!p.x32 && !p.att) || !p.gamma || !p.beta || !p.W1 || !p.b1 || !p.W2p || !p.b2 || (!p.out16 && !p.out32)) return VF_ERR_ARG;
     if (!vf_ffn_fused_supported(p.M, p.C)) return VF_ERR_SHAPE;
-    if ((p.ldx & 3) || (p.out16 && (p.ldo & 7)) || (p.out32 && (p.ldo32 & 3))) return VF_ERR_ALIGN;
+    if (p.att) {      // the out-projection in front: att [M][C] 16-bit, resid [M][C] fp32, bo [C], rowbias [M / rows_per_sample][ld]
+        if (!p.resid || !p.bo || (p.rowbias && (p.rows_per_sample <= 0 || (p.rows_per_sample % 128) || (p.ld_rowbias & 3)))) return VF_ERR_ARG;
+        if ((p.ldatt & 7) || (p.ldr & 3)) return VF_ERR_ALIGN;
+        if (((uintptr_t)p.att | (uintptr_t)p.resid | (uintptr_t)p.bo | (uintptr_t)p.rowbias) & 15) return VF_ERR_ALIGN;
+    }
+    if ((p.x32 && (p.ldx & 3)) || (p.out16 && (p.ldo & 7)) || (p.out32 && (p.ldo32 & 3))) return VF_ERR_ALIGN;
     if (((uintptr_t)p.x32 | (uintptr_t)p.gamma | (uintptr_t)p.beta | (uintptr_t)p.W1 | (uintptr_t)p.b1 | (uintptr_t)p.W2p |
          (uintptr_t)p.b2 | (uintptr_t)p.out16 | (uintptr_t)p.out32) & 15) return VF_ERR_ALIGN;
     if (dtype == VF_DTYPE_F16) return launch_t<F16>(p, stream);

@@ -98,6 +98,13 @@ struct FfnParams {
     void* out16; long ldo;           // [M][C] 16-bit result (or null)
     float* out32; long ldo32;        // optional fp32 result
     int M, C;
+    // att != null: the attn1 out-projection runs in front (ffn.hip "PRE"): x32 is unused, the running sum is formed in-kernel as
+    // t1 = att @ Wo^T + bo + rowbias[row / rows_per_sample] + resid; W1 is then [C + 8C][C]: to_out's rows, then ff.net[0]'s
+    // (GEGLU-interleaved rows, k columns in ffn_w2_perm order)
+    const void* att; long ldatt;     // [M][C] 16-bit attention output
+    const float* resid; long ldr;    // [M][C] fp32: the running sum before attn1 (t0)
+    const float* bo;                 // [C] to_out bias
+    const float* rowbias; long ld_rowbias; int rows_per_sample;   // optional fp32 [M / rows_per_sample][ld]: attn2's contribution
 };
 bool vf_ffn_fused_supported(long M, int C);
 int vf_launch_ffn_fused(const FfnParams& p, int dtype, hipStream_t stream);

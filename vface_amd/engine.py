@@ -395,6 +395,9 @@ class UNetEngine:
         # 128-channel test models) as one activation-stationary kernel (csrc/stfront.hip): four launches and four HBM round trips
         # of the token matrix less per block.  VFACE_FUSE_FRONT=0: the separate launches (A/B switch).
         self.fuse_front = os.environ.get("VFACE_FUSE_FRONT", "1") != "0"
+        # attn1's out-projection (+ attn2's row bias + residual) in front of the fused FeedForward, one launch: the block's running
+        # sum after attention never exists in HBM (csrc/ffn.hip, PRE form).  VFACE_FUSE_TAIL=0: GEMM + fused FeedForward (A/B).
+        self.fuse_tail = os.environ.get("VFACE_FUSE_TAIL", "1") != "0"
         self._front_supported: Dict[tuple, bool] = {}
         self._ffn_supported: Dict[tuple, bool] = {}
         self.decompose_attn1 = False                   # bench.py's instrumented pass: vface_attn1_forward's launches call by call
@@ -527,6 +530,10 @@ class UNetEngine:
                 # packed only for the widths that kernel takes (a C = 1280 block would hold 13 MB of dead copy)
                 "ff2p": (self._w16(packing.pack_ffn_w2(cpu(t + ".ff.net.2.weight")))
                          if self.fuse_ffn and hip.ffn_fused_width_supported(sd[t + ".norm1.weight"].shape[0]) else None),
+                # the same kernel with attn1's out-projection in front (vface_attn_out_ffn_fused): [to_out ; ff.net[0] (k permuted)]
+                "tail_w": (self._w16(packing.pack_attn_out_ffn(cpu(t + ".attn1.to_out.0.weight"), ffw))
+                           if self.fuse_ffn and self.fuse_tail and hip.ffn_fused_width_supported(sd[t + ".norm1.weight"].shape[0])
+                           else None),
                 "a2_out": self.pack_lin(sd, t + ".attn2.to_out.0"), "c": sd[t + ".norm1.weight"].shape[0],
                 "wlin": {}, "attn1_name": t + ".attn1",
                 "qk_src": (sd[t + ".attn1.to_q.weight"], sd[t + ".attn1.to_k.weight"])}
@@ -917,6 +924,12 @@ class UNetEngine:
         else:
             hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=N,
                           qk_map=self._map("qk_replace", N, F_) if fusion == hip.FUSION_REPLACE else None, v_map=v_map, **kw)
+        if self.fuse_tail and p.get("tail_w") is not None and n % 128 == 0 and self._ffn_ok(M, c):
+            # to_out + bias + attn2's row bias + residual -> norm3 -> FeedForward -> + x in ONE launch: t1 never exists in HBM
+            t2 = self._new(M, c)
+            hip.attn_out_ffn_fused(att, t0, a2vec, p["tail_w"], p["wo"]["b"], p["ln3"][0], p["ln3"][1], p["ff1"]["b"], p["ff2p"],
+                                   p["ff2"]["b"], t2, M=M, C_=c, rows_per_sample=n)
+            return t2
         t1 = self._new(M, c, torch.float32)
         hip.gemm(att, p["wo"]["w"], None, M=M, N=d, K=d, lda=d, ldc=0, bias=p["wo"]["b"], rowbias=a2vec, rows_per_sample=n,
                  split_k=False, residual32=t0, out32=t1)
@@ -1106,7 +1119,7 @@ class UNetEngine:
                                              None if self.halo_flow is None else tuple(self.halo_flow.shape))
         # (every switch that changes the captured launch sequence is part of the key: toggling one on a live engine must not
         # replay a stale graph)
-        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.live_chunks,
+        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.live_chunks,
                self.decompose_attn1, self.exchange_events is not None, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)

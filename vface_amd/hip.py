@@ -86,6 +86,8 @@ SIGNATURES = {
                                       _vp, _vp, _sz, _vp, _i32, _vp, _s32p]),
     "vface_ffn_fused_supported": (C.c_int, [_i64, _i32]),
     "vface_ffn_fused": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "vface_attn_out_ffn_fused": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _vp,
+                                           _i64, _i32, _i32, _i32, _vp]),
     "vface_st_front_supported": (C.c_int, [_i64, _i32, _i32]),
     "vface_st_front": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32,
                                  _i32, _i32, _i32, _vp]),
@@ -477,6 +479,20 @@ def attn1_forward(x, wqkv, wlin, wo, bo, out, *, B, n, d, heads, chunks, fusion,
 
 def ffn_fused_supported(M: int, C_: int) -> bool:
     return bool(load().vface_ffn_fused_supported(M, C_))
+
+
+def attn_out_ffn_fused(att: torch.Tensor, resid32: torch.Tensor, rowbias: Optional[torch.Tensor], wo_w1: torch.Tensor, bo: torch.Tensor,
+                       gamma: torch.Tensor, beta: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor,
+                       out16: Optional[torch.Tensor], *, M: int, C_: int, rows_per_sample: int, out32: Optional[torch.Tensor] = None,
+                       eps: float = 1e-5):
+    """attn1's out-projection + attn2's row bias + residual, norm3 and the FeedForward in ONE launch (``vface_attn_out_ffn_fused``):
+    ``out = ff(LayerNorm(t1)) + t1`` with ``t1 = att @ Wo^T + bo + rowbias[sample] + resid32`` never stored."""
+    o = out16 if out16 is not None else out32
+    rc = load().vface_attn_out_ffn_fused(_p(att), att.stride(0), _p(resid32), resid32.stride(0), _p(rowbias),
+                                         rowbias.stride(0) if rowbias is not None else 0, rows_per_sample, _p(wo_w1), _p(bo), _p(gamma),
+                                         _p(beta), eps, _p(b1), _p(w2p), _p(b2), _p(out16), out16.stride(0) if out16 is not None else 0,
+                                         _p(out32), out32.stride(0) if out32 is not None else 0, M, C_, dtype_code(att.dtype), _stream())
+    _check(rc, "vface_attn_out_ffn_fused")
 
 
 def st_front_supported(M: int, C_: int, hw: int) -> bool:
