@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     E* sW2 = sW1 + NW1 * W1E;
     float* sB1 = reinterpret_cast<float*>(sW2 + NW2 * W2E);   // ff.net[0] bias, [8 C] fp32 in packed row order
     float* sGB = sB1 + 8 * C;                                 // gamma [C], beta [C]
+    float* sBS = sGB + 2 * C;                                 // PRE: to_out bias + attn2 row bias of this workgroup's sample [C]
 
     const int t_ = threadIdx.x, lane = t_ & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
@@ -98,35 +99,20 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
         const E* ar = reinterpret_cast<const E*>(p.att) + (tok0 + fr) * p.ldatt + fh * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const V8*>(ar + ks * 16);
+        // the accumulators start as t0 itself, loaded STRAIGHT into the accumulator registers (every load of the tile in flight at
+        // once, no vector-register staging); bo + a2[sample] -- one vector per workgroup: rows_per_sample % 128 == 0 -- is staged in
+        // LDS (sBS) and added where the values are read: by the LayerNorm below and by the epilogue
         const float* rr = p.resid + (tok0 + fr) * p.ldr + fh * 4;
-        const float* rb = p.rowbias ? p.rowbias + (long)((tok0 + fr) / p.rows_per_sample) * p.ld_rowbias + fh * 4 : nullptr;
-        const float* bo = p.bo + fh * 4;
 #pragma unroll
-        for (int half = 0; half < 4; ++half) {
-            constexpr int H0 = (NOT + 3) / 4;
-            const int o0 = half * H0, o1 = (o0 + H0 < NOT) ? o0 + H0 : NOT;
-            float4 rv[H0][4];
+        for (int ot = 0; ot < NOT; ++ot)
 #pragma unroll
-            for (int o = 0; o < H0; ++o)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
-                    if (o0 + o < o1) rv[o][q4] = *reinterpret_cast<const float4*>(rr + (o0 + o) * 32 + q4 * 8);
-#pragma unroll
-            for (int o = 0; o < H0; ++o) {
-                if (o0 + o >= o1) continue;
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int col = (o0 + o) * 32 + q4 * 8;
-                    const float4 b = *reinterpret_cast<const float4*>(bo + col);
-                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (rb) a = *reinterpret_cast<const float4*>(rb + col);
-                    // (acc + bias) + rowbias + residual, the order of the GEMM epilogue this replaces: acc starts at 0
-                    out[o0 + o][4 * q4 + 0] = (b.x + a.x) + rv[o][q4].x;
-                    out[o0 + o][4 * q4 + 1] = (b.y + a.y) + rv[o][q4].y;
-                    out[o0 + o][4 * q4 + 2] = (b.z + a.z) + rv[o][q4].z;
-                    out[o0 + o][4 * q4 + 3] = (b.w + a.w) + rv[o][q4].w;
-                }
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 v = *reinterpret_cast<const float4*>(rr + ot * 32 + q4 * 8);
+                out[ot][4 * q4] = v.x; out[ot][4 * q4 + 1] = v.y; out[ot][4 * q4 + 2] = v.z; out[ot][4 * q4 + 3] = v.w;
             }
+        {
+            const float* rb = p.rowbias ? p.rowbias + (long)(tok0 / p.rows_per_sample) * p.ld_rowbias : nullptr;
+            for (int i = t_; i < C; i += 256) sBS[i] = p.bo[i] + (rb ? rb[i] : 0.f);
         }
         __syncthreads();                 // sGB (and sB1) written
     } else {
@@ -429,11 +415,16 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
         // channel 32 tile + 16 j + 8 (e >> 2) + 4 h + (e & 3) -- ff.net[0]'s k columns are stored in that order (ffn_w2_perm)
 #pragma unroll
         for (int ot = 0; ot < NOT; ++ot) gap_acc_result_to_valu(out[ot]);
+        // t1 = accumulator + (bo + a2): register q of tile ot is channel 32 ot + 8 (q >> 2) + 4 fh + (q & 3)
+        auto bsum4 = [&](int ot, int q4) -> float4 { return *reinterpret_cast<const float4*>(sBS + ot * 32 + q4 * 8 + fh * 4); };
         float s = 0.f;
 #pragma unroll
         for (int ot = 0; ot < NOT; ++ot)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) s += out[ot][q];
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 bb = bsum4(ot, q4);
+                s += (out[ot][4 * q4] + bb.x) + (out[ot][4 * q4 + 1] + bb.y) + (out[ot][4 * q4 + 2] + bb.z) + (out[ot][4 * q4 + 3] + bb.w);
+            }
         s += __shfl_xor(s, 32, 64);
         const float mean = s / (float)C;
         // (every pass reads the accumulator registers again: kept in vector registers across the passes, the 160 values spill)
@@ -443,7 +434,12 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
 #pragma unroll
         for (int ot = 0; ot < NOT; ++ot)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) { const float d = out[ot][q] - mean; qq += d * d; }
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 bb = bsum4(ot, q4);
+                const float d0 = out[ot][4 * q4] + bb.x - mean, d1 = out[ot][4 * q4 + 1] + bb.y - mean;
+                const float d2 = out[ot][4 * q4 + 2] + bb.z - mean, d3 = out[ot][4 * q4 + 3] + bb.w - mean;
+                qq += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+            }
         qq += __shfl_xor(qq, 32, 64);
         const float rstd = rsqrtf(qq / (float)C + p.eps);
 #pragma unroll
@@ -458,10 +454,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
                 for (int e4 = 0; e4 < 2; ++e4) {
                     const int q4 = 2 * j + e4;
                     const float4 g = *reinterpret_cast<const float4*>(gp + q4 * 8), b = *reinterpret_cast<const float4*>(gp + C + q4 * 8);
-                    o[4 * e4 + 0] = from_f32<E>((out[ot][4 * q4 + 0] - mean) * rstd * g.x + b.x);
-                    o[4 * e4 + 1] = from_f32<E>((out[ot][4 * q4 + 1] - mean) * rstd * g.y + b.y);
-                    o[4 * e4 + 2] = from_f32<E>((out[ot][4 * q4 + 2] - mean) * rstd * g.z + b.z);
-                    o[4 * e4 + 3] = from_f32<E>((out[ot][4 * q4 + 3] - mean) * rstd * g.w + b.w);
+                    const float4 bb = bsum4(ot, q4);
+                    o[4 * e4 + 0] = from_f32<E>((out[ot][4 * q4 + 0] + bb.x - mean) * rstd * g.x + b.x);
+                    o[4 * e4 + 1] = from_f32<E>((out[ot][4 * q4 + 1] + bb.y - mean) * rstd * g.y + b.y);
+                    o[4 * e4 + 2] = from_f32<E>((out[ot][4 * q4 + 2] + bb.z - mean) * rstd * g.z + b.z);
+                    o[4 * e4 + 3] = from_f32<E>((out[ot][4 * q4 + 3] + bb.w - mean) * rstd * g.w + b.w);
                 }
                 xf[2 * ot + j] = o;
             }
@@ -529,7 +526,12 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
                 const float* sp = scr + tok * SP + ch * 8;
                 const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
                 const int col = ot0 * 32 + ch * 8;
-                const float4 c0 = *reinterpret_cast<const float4*>(p.b2 + col), c1 = *reinterpret_cast<const float4*>(p.b2 + col + 4);
+                float4 c0 = *reinterpret_cast<const float4*>(p.b2 + col), c1 = *reinterpret_cast<const float4*>(p.b2 + col + 4);
+                if constexpr (PRE) {      // (the out-projection's bias + attn2's row bias, held back from the accumulators' initial value)
+                    const float4 e0 = *reinterpret_cast<const float4*>(sBS + col), e1 = *reinterpret_cast<const float4*>(sBS + col + 4);
+                    c0 = make_float4(c0.x + e0.x, c0.y + e0.y, c0.z + e0.z, c0.w + e0.w);
+                    c1 = make_float4(c1.x + e1.x, c1.y + e1.y, c1.z + e1.z, c1.w + e1.w);
+                }
                 const long row = tok0 + tok;
                 const float v[8] = {(a0.x + c0.x) + r0[k].x, (a0.y + c0.y) + r0[k].y, (a0.z + c0.z) + r0[k].z, (a0.w + c0.w) + r0[k].w,
                                     (a1.x + c1.x) + r1[k].x, (a1.y + c1.y) + r1[k].y, (a1.z + c1.z) + r1[k].z, (a1.w + c1.w) + r1[k].w};
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
 
 template <class TT, int C, bool PRE = false>
 int launch_c(const FfnParams& p, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(4 * 32 * C + 3 * C * 32) * 2 + (size_t)10 * C * 4;
+    constexpr size_t lds = (size_t)(4 * 32 * C + 3 * C * 32) * 2 + (size_t)11 * C * 4;
     static_assert((size_t)4 * 32 * (((C / 32 + 1) / 2) * 32 + 4) * 4 <= (size_t)(4 * 32 * C + 3 * C * 32) * 2, "epilogue scratch fits the weight rings");
     auto kern = ffn_fused_kernel<TT, C, PRE>;
     static VfOncePerDevice attr_set;

@@ -45,6 +45,13 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontParams p) {
     constexpr int SPF = 36;             // fp32 scratch row pitch (floats): 32 + 4
     constexpr int SPH = 40;             // 16-bit scratch row pitch (elements): 32 + 8
     static_assert(C % 64 == 0 && C <= 320, "C: a multiple of 64, at most 320");
+    // Output tiles leave UNDER the next stage's MFMAs: a finished tile's values go through the per-wave LDS transpose at k step
+    // PA of the following stage and to global memory at k step PB.  The counted waits at a stage top need to know how many of
+    // this wave's memory instructions are YOUNGER than the last DMA piece of the stage that must have landed: the stores of a
+    // stage are younger than that stage's own last piece (issued at k step LASTP) iff PB >= LASTP.
+    constexpr int LASTP = 4 * (OPS - 1) + 1;
+    constexpr int PA = 2 < KS ? 2 : KS - 1, PB = 6 < KS ? 6 : KS - 1;
+    constexpr bool ST_AFTER = PB >= LASTP;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     E* sW = reinterpret_cast<E*>(smem_raw);
     float* sBin = reinterpret_cast<float*>(sW + NW * WE);   // proj_in bias [C]
@@ -188,10 +195,30 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontParams p) {
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xf[ks]));
             gap_valu_result_to_mfma(xf[KS - 1]);
         }
-        // ---- IN: proj_in, one output-channel tile per stage; the bias is the accumulator's initial value
+        // ---- IN: proj_in, one output-channel tile per stage; the bias is the accumulator's initial value.  Tile ot - 1 (final
+        // since the previous stage) goes out under this stage's MFMAs: fp32, through the per-wave transpose, rows of 128 bytes
+        auto t0_to_scratch = [&](int ot) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4)
+                *reinterpret_cast<float4*>(scr + fr * SPF + q4 * 8 + fh * 4) =
+                    make_float4(out[ot][4 * q4], out[ot][4 * q4 + 1], out[ot][4 * q4 + 2], out[ot][4 * q4 + 3]);
+        };
+        auto t0_scratch_to_global = [&](int ot) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int it = lane + 64 * k, tok = it >> 3, ch = it & 7;
+                const float4 vv = *reinterpret_cast<const float4*>(scr + tok * SPF + ch * 4);
+                *reinterpret_cast<float4*>(p.t0 + (tok0 + tok) * p.ldt0 + ot * 32 + ch * 4) = vv;
+            }
+        };
 #pragma unroll
         for (int ot = 0; ot < TIN; ++ot) {
-            SF_STAGE_TOP(OPS)
+            // younger than the stage that must have landed: the previous stage's OPS pieces and its 4 stores (of tile ot - 2), and
+            // -- if a stage's stores come after its last piece -- the 4 stores of the stage before (tile ot - 3)
+            if (ot == 0) { SF_STAGE_TOP(OPS) }
+            else if (ot == 1) { SF_STAGE_TOP(OPS) }
+            else if (ot == 2) { SF_STAGE_TOP(OPS + 4) }
+            else { SF_STAGE_TOP(OPS + 4 + (ST_AFTER ? 4 : 0)) }
             {
                 const float* bp = sBin + ot * 32 + fh * 4;
 #pragma unroll
@@ -201,7 +228,15 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontParams p) {
                 }
                 gap_valu_result_to_acc_mfma(out[ot]);
             }
-            SF_KLOOP(TT::mfma32x32_acc(out[ot], af[ks % RA], xf[ks]))
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                TT::mfma32x32_acc(out[ot], af[ks % RA], xf[ks]);
+                af[(ks + RA - 1) % RA] = (ks - 1 + RA < KS) ? frag_at(wa, ks - 1 + RA) : frag_at(wb, ks - 1 + RA - KS);
+                if (ks % 4 == 1) issue_piece(ks / 4);
+                if (ot > 0 && ks == PA) t0_to_scratch(ot - 1);
+                if (ot > 0 && ks == PB) t0_scratch_to_global(ot - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             stage_tail();
         }
         // ---- MID: t0 out (fp32, 128-byte row segments through the per-wave transpose), LayerNorm -> B fragments of the projection
@@ -222,19 +257,11 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontParams p) {
                 for (int q = 0; q < 16; ++q) { const float d = out[ot][q] - mean; qq += d * d; }
             qq += __shfl_xor(qq, 32, 64);
             const float rstd = rsqrtf(qq / (float)C + p.eps);
+            t0_to_scratch(TIN - 1);              // (the last tile of t0: the others left under the IN stages)
+            t0_scratch_to_global(TIN - 1);
+            asm volatile("" ::: "memory");       // (the scratch changes its element type below: no reordering across this point)
 #pragma unroll
             for (int ot = 0; ot < TIN; ++ot) {
-                // t0 tile: [32 tokens][32 channels] fp32 through the scratch -> rows of 128 bytes
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
-                    *reinterpret_cast<float4*>(scr + fr * SPF + q4 * 8 + fh * 4) =
-                        make_float4(out[ot][4 * q4], out[ot][4 * q4 + 1], out[ot][4 * q4 + 2], out[ot][4 * q4 + 3]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int it = lane + 64 * k, tok = it >> 3, ch = it & 7;
-                    const float4 vv = *reinterpret_cast<const float4*>(scr + tok * SPF + ch * 4);
-                    *reinterpret_cast<float4*>(p.t0 + (tok0 + tok) * p.ldt0 + ot * 32 + ch * 4) = vv;
-                }
                 // LayerNorm of this tile's 16 values -> two k16 B fragments
                 const float* gp = sGam + ot * 32 + fh * 4;
                 const float* bp = sBet + ot * 32 + fh * 4;
@@ -275,12 +302,29 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontParams p) {
             for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xf[ks]));
             gap_valu_result_to_mfma(xf[KS - 1]);
         }
-        // ---- Q: the projection, one 32-column tile per stage
+        // ---- Q: the projection, one 32-column tile per stage.  A finished tile is rounded to 16 bits at once (8 registers) and
+        // leaves under the NEXT stage's MFMAs: through the per-wave transpose at k step PA, as 16-byte row pieces at k step PB
+        asm volatile("" ::: "memory");
         E* qp = reinterpret_cast<E*>(p.qkv);
+        V4 hprev[4];
+        auto q_to_scratch = [&]() {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<V4*>(scrh + fr * SPH + q4 * 8 + fh * 4) = hprev[q4];
+        };
+        auto q_scratch_to_global = [&](int qt_) {
+            const int col0 = (qf + qt_) * 32;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int it = lane + 64 * k, tok = it >> 2, ch = it & 3;
+                const V8 vv = *reinterpret_cast<const V8*>(scrh + tok * SPH + ch * 8);
+                *reinterpret_cast<V8*>(qp + (tok0 + tok) * p.ldq + col0 + ch * 8) = vv;
+            }
+        };
         for (int qt = 0; qt < TQ; ++qt) {
-            // (the MID phase's stores are younger than the stage this interval needs: a full drain at the first two stages of
-            // the phase, the steady count -- this stage's successor landed, OPS + 2 x 2 younger instructions -- afterwards)
-            if (qt < 2) { SF_STAGE_TOP(0) } else { SF_STAGE_TOP(OPS + 4) }
+            // memory instructions younger than the stage that must have landed (see ST_AFTER): the MID phase's stores force a
+            // drain at the first stage, a stricter count than needed at the second and third
+            if (qt == 0) { SF_STAGE_TOP(0) } else if (qt == 1) { SF_STAGE_TOP(OPS) } else if (qt == 2) { SF_STAGE_TOP(OPS + 2) }
+            else { SF_STAGE_TOP(OPS + 2 + (ST_AFTER ? 2 : 0)) }
             f16_t acc;
             TT::mfma32x32_vzero(acc, af[0], xf[0]);
             af[(RA - 1) % RA] = (RA - 1 < KS) ? frag_at(wa, RA - 1) : frag_at(wb, RA - 1 - KS);
@@ -290,25 +334,20 @@ __global__ __launch_bounds__(256, 1) void st_front_kernel(StFrontParams p) {
                 TT::mfma32x32_vacc(acc, af[ks % RA], xf[ks]);
                 af[(ks + RA - 1) % RA] = (ks - 1 + RA < KS) ? frag_at(wa, ks - 1 + RA) : frag_at(wb, ks - 1 + RA - KS);
                 if (ks % 4 == 1) issue_piece(ks / 4);
+                if (qt > 0 && ks == PA) q_to_scratch();
+                if (qt > 0 && ks == PB) q_scratch_to_global(qt - 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             stage_tail();
             gap_mfma_result_to_valu(acc);
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                V4 h4;
+            for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h4[e] = from_f32<E>(acc[4 * q4 + e]);
-                *reinterpret_cast<V4*>(scrh + fr * SPH + q4 * 8 + fh * 4) = h4;
-            }
-            const int col0 = (qf + qt) * 32;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int it = lane + 64 * k, tok = it >> 2, ch = it & 3;
-                const V8 vv = *reinterpret_cast<const V8*>(scrh + tok * SPH + ch * 8);
-                *reinterpret_cast<V8*>(qp + (tok0 + tok) * p.ldq + col0 + ch * 8) = vv;
-            }
+                for (int e = 0; e < 4; ++e) hprev[q4][e] = from_f32<E>(acc[4 * q4 + e]);
         }
+        q_to_scratch();
+        q_scratch_to_global(TQ - 1);
+        asm volatile("" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no LDS-DMA of this workgroup may land after it has left the CU
 #undef SF_STAGE_TOP
