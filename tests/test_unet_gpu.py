@@ -190,10 +190,19 @@ def test_small_unet_bf16_measured(small, mode):
     flow = [synth.synth_flow(F_ - 1, h, w)[i][None] for i in range(F_ - 1)]
     _register(sampler, mode, flow)
     got = ldm.apply_model(x.to(DEV), t.to(DEV), ctx.to(DEV)).float().cpu()
-    ref = ounet.unet_forward(sd, SMALL, x, t, ctx, _oracle_registry(mode, flow))
+    reg = _oracle_registry(mode, flow)
+    ref = ounet.unet_forward(sd, SMALL, x, t, ctx, reg)
     err = rel_l2(got, ref)
-    print(f"bf16 {mode}: rel-L2 {err:.3e}")
-    assert err < 2e-2
+    # the bound is what the emulation of this build's rounding points PREDICTS for bf16 (tests/precision_budget.py: bf16 weights,
+    # one bf16 rounding per matrix-core operand, fp32 residual stream) on the same inputs, + 25 % -- not a round number
+    # (the same emulation reproduces the fp16 measurement of the full UNet to 4 %: test_precision_budget.py)
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import precision_budget as pb
+    with torch.no_grad():
+        emu = pb.rel(pb.forward(pb.Emu(sd, w16=True, act16=True, stream16=False, half=torch.bfloat16), SMALL, x, t, ctx, reg), ref)
+    print(f"bf16 {mode}: rel-L2 {err:.3e} (emulated rounding points: {emu:.3e})")
+    assert err < 1.25 * emu and err < 2e-2, (err, emu)
 
 
 @pytest.mark.parametrize("mode", ["plain", "flow_fix", "replace", "fft"])
