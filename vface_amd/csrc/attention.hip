@@ -374,21 +374,39 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
         return;
     }
     f4_t o[NC][QT];
-#pragma unroll
-    for (int c = 0; c < NC; ++c)
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) o[c][qt] = f4_t{0.f, 0.f, 0.f, 0.f};
     float m_run[QT], l_run[QT];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -1e30f; l_run[qt] = 0.f; }
     f4_t cneg[QT];   // LAZY: -m_ref of this lane's query, the C operand of the score MFMAs
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) cneg[qt] = f4_t{0.f, 0.f, 0.f, 0.f};
+    float lsum[QT];  // softmax denominators of this lane's queries (after the key loop)
 
     const float cexp = p.scale * 1.44269504088896340736f;
     const int nblocks = (nk + KVB - 1) / KVB;
 
-    __syncthreads();  // zero fill (and the ones column) done before the first DMA lands
+    // SPECULATIVE reference (round 4; LAZY form only).  The lazy softmax raises its reference only when a block's maximum
+    // exceeds it by more than 8 -- which, after the first key block has set the reference to that block's maximum, almost never
+    // happens; but DETECTING it costs a lane-local maximum per query tile and key block (8 v_max3 + compare + branch: 140 of the
+    // ~1 830 issue cycles of a block, profiles/r04_attn_issue_budget.txt) in a kernel that is bound by instruction issue.  Pass 0
+    // therefore takes the maximum in the FIRST block only and never looks again: P = exp2(s - m_ref) stays finite in 16 bits as
+    // long as no later score exceeds the first block's maximum by 2^16 -- and if one does, P overflows to inf, the denominator
+    // (sum of P) is inf, and the workgroup (one vote, the K / V staging is shared) runs the tile again with the checked loop.
+    // Exact either way: every P / sum(P) is formed from one reference per query.
+    constexpr int NPASS = LAZY ? 2 : 1;
+#ifdef VFACE_ATTN_STAMPS
+    const int first_pass = 0;
+#else
+    const int first_pass = (p.variant & 16) ? 1 : 0;      // variant bit 4: checked loop only (A/B)
+#endif
+  for (int pass = first_pass; pass < NPASS; ++pass) {
+    const bool spec = LAZY && pass == 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[c][qt] = f4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { m_run[qt] = -1e30f; l_run[qt] = 0.f; }
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) cneg[qt] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();  // zero fill (and the ones column) done before the first DMA lands; a second pass: every wave left the loop
     stage_block(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -455,10 +473,14 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
                         if (kbase + tl * 16 + r >= nk) s[tl][qt][r] = -1e30f;
             }
             float mx = -1e30f;
+            // (speculative pass: the maximum is taken in the first key block only -- a wave-uniform branch around 8 v_max3)
+            const bool look = !spec || kb == 0;
+            if (look) {
 #pragma unroll
-            for (int tl = 0; tl < 4; ++tl)
+                for (int tl = 0; tl < 4; ++tl)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[tl][qt][r]);
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[tl][qt][r]);
+            }
             if constexpr (!LAZY) mx = quad_row_max(mx);
             float ls = 0.f;
             if constexpr (LAZY) {
@@ -467,7 +489,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
                 // query's four lane groups hold 16 of its 64 keys each: the query's max exceeds 8 iff one of theirs does), so
                 // the cross-lane reduction (two lane swaps + the canonicalising maxima hipcc wraps around them: 10 vector
                 // instructions per query tile) runs only inside the rare branch -- the kernel is VALU-issue-bound.
-                if (__any((kb == 0) || (mx > 8.0f))) {
+                if (look && __any((kb == 0) || (mx > 8.0f))) {
                     mx = quad_row_max(mx);
                     const bool shift = (kb == 0) || (mx > 8.0f);
                     const float delta = shift ? mx : 0.f;
@@ -559,17 +581,27 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
         return;
     }
 
+    // ---- denominators; the speculative pass votes: any of them not finite -> the workgroup runs the checked loop
+    bool bad = false;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        if (ONES) {
+            // the denominator is row DV of O^T: held by lane group (DV % 16) / 4 in register 0 of tile DV / 16
+            lsum[qt] = __shfl(o[DV / 16][qt][0], fr + 16 * ((DV % 16) / 4), 64);
+        } else {
+            lsum[qt] = quad_row_sum(l_run[qt]);
+        }
+        bad = bad || !(lsum[qt] < 3.0e38f);      // inf or NaN
+    }
+    if (!spec) break;
+    if (!__syncthreads_or(bad ? 1 : 0)) break;
+  }
+
     // ---- normalise and store: lane holds value columns 16c + 4fg + r of query fr (set = column / DH)
     E* Og = reinterpret_cast<E*>(p.O) + (long)b * p.bso + h * DH;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        float l;
-        if (ONES) {
-            // the denominator is row DV of O^T: held by lane group (DV % 16) / 4 in register 0 of tile DV / 16
-            l = __shfl(o[DV / 16][qt][0], fr + 16 * ((DV % 16) / 4), 64);
-        } else {
-            l = quad_row_sum(l_run[qt]);
-        }
+        const float l = lsum[qt];
         const float inv = 1.0f / l;
         const int q = q0 + qt * 16 + fr;
         if (q >= p.n) continue;
