@@ -97,7 +97,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
     E* sK = reinterpret_cast<E*>(smem_raw);          // [2][KVB][KROW]
     E* sV = sK + 2 * KVB * KROW;                     // [2][KVB][VROW]
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);      // provably wave-uniform: the staging's per-wave tests become scalar branches
     const int fr = lane & 15, fg = lane >> 4;
     // XCD-aware order (guide T1): workgroups are dealt round-robin to the 8 XCDs; give each XCD a CONTIGUOUS run of the
     // (sample, head, query tile) sequence, so the query tiles of one (sample, head) -- which all walk the same K / V --
@@ -383,20 +384,23 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
 
     // SPECULATIVE reference (round 4; LAZY form only).  The lazy softmax raises its reference only when a block's maximum
     // exceeds it by more than 8 -- which, after the first key block has set the reference to that block's maximum, almost never
-    // happens; but DETECTING it costs a lane-local maximum per query tile and key block (8 v_max3 + compare + branch: 140 of the
-    // ~1 830 issue cycles of a block, profiles/r04_attn_issue_budget.txt) in a kernel that is bound by instruction issue.  Pass 0
-    // therefore takes the maximum in the FIRST block only and never looks again: P = exp2(s - m_ref) stays finite in 16 bits as
-    // long as no later score exceeds the first block's maximum by 2^16 -- and if one does, P overflows to inf, the denominator
-    // (sum of P) is inf, and the workgroup (one vote, the K / V staging is shared) runs the tile again with the checked loop.
-    // Exact either way: every P / sum(P) is formed from one reference per query.
-    constexpr int NPASS = LAZY ? 2 : 1;
+    // happens; but DETECTING it costs a lane-local maximum per query tile and key block (8 v_max3 + compare + branch: ~140 of the
+    // ~1 830 issue cycles of a block, profiles/r04_g_attn_issue_budget.txt) in a kernel that is bound by instruction issue.
+    // Pass 0 therefore takes the maximum in the FIRST block only and never looks again: P = exp2(s - m_ref) stays finite in 16
+    // bits as long as no later score exceeds the first block's maximum by 2^16 -- and if one does, P overflows to inf, the
+    // denominator (sum of P) is inf, and the workgroup (one vote, the K / V staging is shared) runs the tile again with the
+    // checked loop.  Exact either way: every P / sum(P) is formed from one reference per query.
+    // Taken where it measured faster: the plain dh = 40 kernel (661 -> 610 us at F = 8, same box, bit-identical outputs on inputs
+    // that never trip it; the shared-score form and dh = 80 / 160 lost 3-4 % to the second loop's control flow and keep one pass).
+    constexpr bool SPEC = LAZY && !W32 && G == 1 && DH == 40;
+    constexpr int NPASS = SPEC ? 2 : 1;
 #ifdef VFACE_ATTN_STAMPS
     const int first_pass = 0;
 #else
-    const int first_pass = (p.variant & 16) ? 1 : 0;      // variant bit 4: checked loop only (A/B)
+    const int first_pass = (SPEC && (p.variant & 16)) ? 1 : 0;      // variant bit 4: checked loop only (A/B)
 #endif
   for (int pass = first_pass; pass < NPASS; ++pass) {
-    const bool spec = LAZY && pass == 0;
+    const bool spec = SPEC && pass == 0;
 #pragma unroll
     for (int c = 0; c < NC; ++c)
 #pragma unroll
@@ -448,11 +452,21 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) s[tl][qt] = TT::mfma32(kf, qf[qt][ks], s[tl][qt]);
             }
-            if (TAIL) {
+        }
+        if (TAIL) {
+            // The k16 tail step of a tile reads, as its C operand, what that tile's k32 steps wrote -- a DIFFERENT MFMA opcode.
+            // Issued straight behind its producer (where hipcc's scheduler put some of them: it inserts no wait states for this
+            // pair on gfx950) the tail returned stale sums: dh = 40 / 80 kernels that were wrong or right depending on unrelated
+            // edits elsewhere in the kernel (profiles/r04_f_attention_mfma_hazard.txt).  All k32 steps of the four key tiles
+            // therefore go first, the tails after a scheduling fence: >= 3 QT other MFMAs between a tile's two steps.
+            if (NKS > 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int tl = 0; tl < 4; ++tl) {
                 const V4 kf = *reinterpret_cast<const V4*>(cK + (tl * 16 + fr) * KROW + k_slot<KROW>(tl * 16 + fr, NKS * 4 + (fg >> 1)) * 8 + (fg & 1) * 4);
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) s[tl][qt] = TT::mfma16(kf, qt4[qt], s[tl][qt]);
             }
+            if (NKS > 0) __builtin_amdgcn_sched_barrier(0);
         }
         stamp(1);
         // ---- online softmax (fp32)
@@ -592,9 +606,17 @@ __global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
             lsum[qt] = quad_row_sum(l_run[qt]);
         }
         bad = bad || !(lsum[qt] < 3.0e38f);      // inf or NaN
+        if (!ONES) {
+            // (without the ones column the denominator is an fp32 sum of the fp32 exponentials: it stays finite when a P overflowed
+            // only in its 16-bit rounding -- look at the sums the matrix pipe formed from the rounded P instead)
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) bad = bad || !(fabsf(o[c][qt][r]) < 3.0e38f);
+        }
     }
     if (!spec) break;
-    if (!__syncthreads_or(bad ? 1 : 0)) break;
+    if constexpr (SPEC) { if (!__syncthreads_or(bad ? 1 : 0)) break; }
   }
 
     // ---- normalise and store: lane holds value columns 16c + 4fg + r of query fr (set = column / DH)
