@@ -66,8 +66,8 @@ extern "C" {
 
 int vface_abi_version(void);
 const char* vface_error_string(int code);
-/* 1 if the library was built with the experimental GEMM schedules (`make VARIANTS=1`): VFACE_TUNE_VARIANT(1..4, 9, 10)
- * are then accepted; the product build returns 0 and refuses them with VFACE_ERR_SHAPE. */
+/* Always 0 since round 4: the experimental GEMM schedules VFACE_TUNE_VARIANT(1..4, 9, 10) of rounds 1-3 (all measured slower,
+ * HISTORY.md) were removed; those variant codes are refused with VFACE_ERR_SHAPE.  Kept so that version-4 callers still link. */
 int vface_gemm_variants_built(void);
 
 /* The fp32 residual stream (optional last argument of the GEMM-family calls; NULL = everything 16-bit).

@@ -28,15 +28,13 @@ def rnd(shape, seed, dt, scale=1.0):
     return (torch.randn(shape, generator=g) * scale).to(dt)
 
 
-EXPERIMENTAL = (1, 2, 3, 4, 9, 10)              # csrc/experiments/: built by `make VARIANTS=1` only, never shipped
-# 0 = automatic schedule; 5..8 forced product schedules (include/vface_hip.h).  The experimental schedules are collected
-# only when asked for (VFACE_EXPERIMENTS=1 with a `make VARIANTS=1` library), so a product run has no permanent skips.
-VARIANTS = [0, 5, 6, 7, 8] + (list(EXPERIMENTAL) if os.environ.get("VFACE_EXPERIMENTS") == "1" else [])
+# 0 = automatic schedule; 5..8 forced product schedules (include/vface_hip.h).  (Codes 1..4, 9, 10 were the experimental schedules
+# of rounds 1-3, removed in round 4: the library refuses them.)
+VARIANTS = [0, 5, 6, 7, 8]
 
 
 def need_variant(h, variant):
-    if variant in EXPERIMENTAL and not h.load().vface_gemm_variants_built():
-        pytest.skip("experimental GEMM schedule: not in the product build (make VARIANTS=1)")
+    assert variant in VARIANTS
 
 
 GEMM_SHAPES = [(256, 128, 64), (200, 72, 136), (1000, 320, 320), (24, 1280, 320), (4096, 960, 320), (700, 160, 1096)]

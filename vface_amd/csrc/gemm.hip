@@ -1003,13 +1003,10 @@ int vf_launch_gemm_bf16(const GemmParams& p, int variant, hipStream_t stream);
 #if defined(VF_GEMM_TU) && VF_GEMM_TU == 1
 int vf_launch_gemm_bf16(const GemmParams& p, int variant, hipStream_t stream) { return launch_gemm<BF16>(p, variant, stream); }
 #else
-bool vf_gemm_variants_built() {
-#ifdef VFACE_GEMM_VARIANTS
-    return true;
-#else
-    return false;
-#endif
-}
+// (rounds 1-3 kept four experimental schedules -- 3-stage / single-stage / BK = 32 pipelines, a 256-row ping-pong kernel -- behind
+// `make VARIANTS=1`; all measured slower than this kernel on every shape of the UNet (HISTORY.md) and were removed in round 4.
+// The entry point stays in the ABI and answers 0.)
+bool vf_gemm_variants_built() { return false; }
 
 long vf_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_sample) {
     int s = split_for(M, N, K, flags, rows_per_sample);
@@ -1112,12 +1109,7 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
     }
     if ((p.flags & GEMM_GEGLU) && (variant == 2 || variant == 4 || variant == 6 || variant == 8 || variant == 10)) return VF_ERR_SHAPE;
     if (p.colstats && (variant < 5 || variant > 8)) return VF_ERR_SHAPE;
-#ifdef VFACE_GEMM_VARIANTS   // experimental schedules, `make VARIANTS=1` builds only
-    if (variant >= 1 && variant <= 4) return vf_launch_gemm_pipe(p, dtype, variant, stream);
-    if (variant == 9 || variant == 10) return vf_launch_gemm_pp(p, dtype, variant, stream);
-#else
-    if ((variant >= 1 && variant <= 4) || variant == 9 || variant == 10) return VF_ERR_SHAPE;
-#endif
+    if ((variant >= 1 && variant <= 4) || variant == 9 || variant == 10) return VF_ERR_SHAPE;      // (removed experimental schedules)
     if (dtype == VF_DTYPE_F16) return launch_gemm<F16>(p, variant, stream);
     if (dtype == VF_DTYPE_BF16) return vf_launch_gemm_bf16(p, variant, stream);
     return VF_ERR_DTYPE;

@@ -84,8 +84,6 @@ int vf_launch_gemm_patch(const GemmParams& p, int dtype, hipStream_t stream);
 int vf_conv_q8_split(const GemmParams& p);                                      // the 8x8 level through the patch kernel: 0 | K split
 int vf_launch_conv_q8(const GemmParams& p, int dtype, hipStream_t stream);     // (main pass only: the caller runs the split-K reduce)
 bool vf_attention_shared_scores_supported(int dh, int v_sets);
-int vf_launch_gemm_pipe(const GemmParams& p, int dtype, int variant, hipStream_t stream);
-int vf_launch_gemm_pp(const GemmParams& p, int dtype, int variant, hipStream_t stream);
 
 // ffn.hip: fused LayerNorm -> ff.net[0] (GEGLU) -> ff.net[2] -> + x over token matrices with C in {64, 128, 320}, M % 128 == 0
 struct FfnParams {
