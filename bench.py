@@ -108,7 +108,8 @@ class FamilyTimer:
     """HIP-event timing (on the launch stream) of every launch of the instrumented pass, by kernel family:
       conv       by kernel: `patch3` = conv_patch_kernel<3x3> (conv.hip), `patch2` = its 2x2 parity-phase form (four launches
                  per call), `patch8x8` = its 8x8 form (four images per workgroup; the time includes the split-K reduce pass),
-                 `im2col` = gemm.hip's implicit GEMM (stride 2, the 9->320 and 320->4 convolutions);
+                 `im2col` = gemm.hip's implicit GEMM (stride 2, the 9->320 convolution); `out_fused` = outconv.hip (GroupNorm + SiLU +
+                 the 320->4 convolution in one launch, vector dot products: priced at its ALGORITHMIC 2 M 4 9 Cin FLOPs);
       gemm       gemm_kernel<T, MODE_PLAIN, ..>: every Linear / 1x1 conv (sub-classes: `ff1` = the GEGLU projection, `n320` = the
                  level-0 projections with N = 320, `other`); FLOPs = 2 M N K as executed (incl. the folded FSAI K = 2d);
                  `ffn_fused` = ffn_fused_kernel (ffn.hip): LayerNorm + both FeedForward GEMMs + residual of a level-0 block;
@@ -166,6 +167,15 @@ class FamilyTimer:
             patch = hip.conv_uses_patch_kernel(H, W, cin, cout, 3, 1, False, kw.get("flags", 0)) if c2 % 64 == 0 else 0
             timer._timed("conv", {1: "patch3", 2: "patch8x8"}.get(patch, "im2col"), 2.0 * nimg * H * W * cout * (9 * cin + c2), 1, call)
         hip.conv3x3_plus_1x1 = conv3x3_plus_1x1
+        orig_out = hip.gn_silu_conv3x3_small
+
+        def gn_silu_conv3x3_small(x, gn_ab, wt, bias, out, *, nimg, H, W, cin, cout):
+            # the UNet's out layer (GroupNorm + SiLU + conv3x3 to 4 channels) in one launch: algorithmic FLOPs 2 M cout 9 cin
+            call = lambda: orig_out(x, gn_ab, wt, bias, out, nimg=nimg, H=H, W=W, cin=cin, cout=cout)
+            if not timer.on:
+                return call()
+            timer._timed("conv", "out_fused", 2.0 * nimg * H * W * cout * 9 * cin, 1, call)
+        hip.gn_silu_conv3x3_small = gn_silu_conv3x3_small
         orig_gemm = hip.gemm
 
         def gemm(a, wt, out, *, M, N, K, **kw):

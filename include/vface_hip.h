@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VFACE_ABI_VERSION 5   /* 5: + vface_st_front, vface_attn_out_ffn_fused; vface_attention's v_sets carries the live-set count in bits 8..15, vface_pack_unet_input / vface_ddim_step take the two-branch batch; nothing else of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
+#define VFACE_ABI_VERSION 5   /* 5: + vface_st_front, vface_attn_out_ffn_fused, vface_gn_silu_conv3x3_small; vface_attention's v_sets carries the live-set count in bits 8..15, vface_pack_unet_input / vface_ddim_step take the two-branch batch; nothing else of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
 
 #define VFACE_OK 0
 #define VFACE_ERR_ARG (-1)
@@ -338,6 +338,13 @@ int vface_attn_out_ffn_fused(const void* att, int64_t ldatt, const float* resid,
                              int rows_per_sample, const void* WoW1, const float* bo, const float* gamma, const float* beta, float eps,
                              const float* b1, const void* W2p, const float* b2, void* out16, int64_t ldo, float* out32,
                              int64_t ldo32, int M, int C, int dtype, void* stream);
+
+/* The UNet's `out` layer in one launch (openaimodel.py:712-716, :905): out = conv3x3( SiLU( x * a[img] + b[img] )_16 ) + bias with Cout
+ * in {3, 4}, Cin % 64 == 0; x: [nimg*H*W][ldx] fp32 residual-stream carrier (in_f32) or 16-bit; (a, b): vface_groupnorm_coeffs_from_cols;
+ * Wt: [Cout][9*Cin] 16-bit in vface_conv3x3's k order; out: fp32 [nimg*H*W][ldo].  Replaces finalize + apply + an implicit-GEMM whose
+ * 128-wide tile is 97 % padding at four output channels. */
+int vface_gn_silu_conv3x3_small(const void* x, int64_t ldx, int in_f32, const float* gn_ab, int64_t ld_ab, const void* Wt, const float* bias,
+                                float* out, int64_t ldo, int nimg, int H, int W, int Cin, int Cout, int dtype, void* stream);
 
 /* Fused FRONT of a SpatialTransformer (attention.py:278-284 norm -> proj_in -> tokens; :239 norm1; :179-183 to_q / to_k / to_v of
  * attn1), one launch for GroupNorm-apply + proj_in + LayerNorm + the attn1 projection on token matrices with C in {64, 128, 320}:

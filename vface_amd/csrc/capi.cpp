@@ -377,6 +377,14 @@ int vface_attn_out_ffn_fused(const void* att, int64_t ldatt, const float* resid,
     return vf_launch_ffn_fused(p, dtype, S(stream));
 }
 
+int vface_gn_silu_conv3x3_small(const void* x, int64_t ldx, int in_f32, const float* gn_ab, int64_t ld_ab, const void* Wt, const float* bias,
+                                float* out, int64_t ldo, int nimg, int H, int W, int Cin, int Cout, int dtype, void* stream) {
+    OutConvParams p{};
+    p.x = x; p.ldx = ldx; p.in_f32 = in_f32; p.ab = gn_ab; p.ld_ab = ld_ab; p.Wt = Wt; p.bias = bias; p.out = out; p.ldo = ldo;
+    p.nimg = nimg; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+    return vf_launch_out_conv(p, dtype, S(stream));
+}
+
 int vface_st_front_supported(int64_t M, int C, int hw) { return vf_st_front_supported((long)M, C, hw) ? 1 : 0; }
 
 int vface_st_front(const float* x32, int64_t ldx, const float* gn_ab, int64_t ld_ab, int hw, const void* Wcat, const float* b_in,

@@ -125,6 +125,18 @@ struct StFrontParams {
 bool vf_st_front_supported(long M, int C, int hw);
 int vf_launch_st_front(const StFrontParams& p, int dtype, hipStream_t stream);
 
+// outconv.hip: GroupNorm-apply + SiLU + 3x3 convolution to 3 / 4 output channels in one launch (the UNet's `out` layer)
+struct OutConvParams {
+    const void* x; long ldx; int in_f32;   // [nimg*H*W][ldx] fp32 carrier (in_f32) or 16-bit
+    const float* ab; long ld_ab;           // GroupNorm (scale, shift) pairs [nimg][ld_ab][2]
+    const void* Wt;                        // [Cout][9*Cin] 16-bit, k order (64-channel chunk, tap, channel) (packing.pack_conv3x3)
+    const float* bias;                     // [Cout] or null
+    float* out; long ldo;                  // [nimg*H*W][ldo] fp32
+    int nimg, H, W, Cin, Cout;
+};
+bool vf_out_conv_supported(int Cin, int Cout);
+int vf_launch_out_conv(const OutConvParams& p, int dtype, hipStream_t stream);
+
 struct AttnParams {
     const void* Q; const void* K; const void* V;  // [B][n][ld*], head h at column h*dh
     long ldq, ldk, ldv;           // row (token) strides in elements

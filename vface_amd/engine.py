@@ -398,6 +398,8 @@ class UNetEngine:
         # attn1's out-projection (+ attn2's row bias + residual) in front of the fused FeedForward, one launch: the block's running
         # sum after attention never exists in HBM (csrc/ffn.hip, PRE form).  VFACE_FUSE_TAIL=0: GEMM + fused FeedForward (A/B).
         self.fuse_tail = os.environ.get("VFACE_FUSE_TAIL", "1") != "0"
+        # the UNet's `out` layer (GroupNorm -> SiLU -> conv3x3 to 4 channels) as one launch (csrc/outconv.hip).  VFACE_FUSE_OUT=0: A/B
+        self.fuse_out = os.environ.get("VFACE_FUSE_OUT", "1") != "0"
         self._front_supported: Dict[tuple, bool] = {}
         self._ffn_supported: Dict[tuple, bool] = {}
         self.decompose_attn1 = False                   # bench.py's instrumented pass: vface_attn1_forward's launches call by call
@@ -1071,6 +1073,13 @@ class UNetEngine:
             inp = Act(cats[j], x.N, sh, sw, cats_cs[j], cats32[j])
             tgt = part(j + 1, 0, h_ch[j + 1]) if j + 1 < nb else None
             h = run(block, inp, tgt)
+        oc = P["out.conv"]
+        if self.fuse_out and h.cs is not None and oc["cinp"] % 64 == 0 and oc["cout"] in (3, 4) and h.C == oc["cinp"]:
+            # out = normalization -> SiLU -> conv3x3 (openaimodel.py:712-716) in ONE launch (csrc/outconv.hip)
+            ab = hip.groupnorm_coeffs_from_cols(h.cs, P["out.gn"][0], P["out.gn"][1], nimg=h.N, hw=h.hw, C_=h.C, eps=1e-5)
+            eps = self._new(h.M, oc["cout"], torch.float32)
+            hip.gn_silu_conv3x3_small(h.src, ab, oc["w"], oc["b"], eps, nimg=h.N, H=h.H, W=h.W, cin=oc["cinp"], cout=oc["cout"])
+            return eps
         h = self._gn(h, P["out.gn"], 1e-5, True)
         return self._conv(h, P["out.conv"], None, out_f32=True).t
 
@@ -1119,7 +1128,7 @@ class UNetEngine:
                                              None if self.halo_flow is None else tuple(self.halo_flow.shape))
         # (every switch that changes the captured launch sequence is part of the key: toggling one on a live engine must not
         # replay a stale graph)
-        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.live_chunks,
+        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.fuse_out, self.live_chunks,
                self.decompose_attn1, self.exchange_events is not None, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)

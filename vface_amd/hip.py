@@ -88,6 +88,7 @@ SIGNATURES = {
     "vface_ffn_fused": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "vface_attn_out_ffn_fused": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _vp,
                                            _i64, _i32, _i32, _i32, _vp]),
+    "vface_gn_silu_conv3x3_small": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vface_st_front_supported": (C.c_int, [_i64, _i32, _i32]),
     "vface_st_front": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32,
                                  _i32, _i32, _i32, _vp]),
@@ -493,6 +494,15 @@ def attn_out_ffn_fused(att: torch.Tensor, resid32: torch.Tensor, rowbias: Option
                                          _p(beta), eps, _p(b1), _p(w2p), _p(b2), _p(out16), out16.stride(0) if out16 is not None else 0,
                                          _p(out32), out32.stride(0) if out32 is not None else 0, M, C_, dtype_code(att.dtype), _stream())
     _check(rc, "vface_attn_out_ffn_fused")
+
+
+def gn_silu_conv3x3_small(x: torch.Tensor, gn_ab: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
+                          nimg: int, H: int, W: int, cin: int, cout: int):
+    """GroupNorm-apply + SiLU + conv3x3 to 3 / 4 channels in one launch (the UNet's ``out`` layer, ``vface_gn_silu_conv3x3_small``);
+    ``x``: the fp32 carrier or the 16-bit copy ``[nimg*H*W, cin]``; ``out``: fp32 ``[nimg*H*W, >= cout]``."""
+    rc = load().vface_gn_silu_conv3x3_small(_p(x), x.stride(0), int(x.dtype == torch.float32), _p(gn_ab), gn_ab.stride(0) // 2, _p(wt),
+                                            _p(bias), _p(out), out.stride(0), nimg, H, W, cin, cout, dtype_code(wt.dtype), _stream())
+    _check(rc, "vface_gn_silu_conv3x3_small")
 
 
 def st_front_supported(M: int, C_: int, hw: int) -> bool:
