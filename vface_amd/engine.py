@@ -1074,7 +1074,7 @@ class UNetEngine:
             tgt = part(j + 1, 0, h_ch[j + 1]) if j + 1 < nb else None
             h = run(block, inp, tgt)
         oc = P["out.conv"]
-        if self.fuse_out and h.cs is not None and oc["cinp"] % 64 == 0 and oc["cout"] in (3, 4) and h.C == oc["cinp"]:
+        if self.fuse_out and h.cs is not None and oc["cinp"] % 64 == 0 and oc["cinp"] <= 640 and oc["cout"] in (3, 4) and h.C == oc["cinp"]:
             # out = normalization -> SiLU -> conv3x3 (openaimodel.py:712-716) in ONE launch (csrc/outconv.hip)
             ab = hip.groupnorm_coeffs_from_cols(h.cs, P["out.gn"][0], P["out.gn"][1], nimg=h.N, hw=h.hw, C_=h.C, eps=1e-5)
             eps = self._new(h.M, oc["cout"], torch.float32)
