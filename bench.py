@@ -114,6 +114,7 @@ class FamilyTimer:
                  level-0 projections with N = 320, `other`); FLOPs = 2 M N K as executed (incl. the folded FSAI K = 2d);
                  `ffn_fused` = ffn_fused_kernel (ffn.hip): LayerNorm + both FeedForward GEMMs + residual of a level-0 block;
                  `attn_out_ffn_fused` = the same kernel with attn1's out-projection, attn2's row bias and the residual in front;
+                 `attn_out_ffn_proj_fused` = ... and the SpatialTransformer's proj_out + input residual + column statistics behind;
                  `st_front` = st_front_kernel (stfront.hip): GroupNorm-apply + proj_in + LayerNorm + attn1 projection of a level-0 block;
       attention  attn_kernel<T, DH, ..> by head dim; FLOPs = the ALGORITHMIC 4 n nk dh per (output sample, head) --
                  the shared-score form executes fewer;
@@ -203,6 +204,17 @@ class FamilyTimer:
                 return call()
             timer._timed("gemm", "attn_out_ffn_fused", 26.0 * M * C_ * C_, 1, call)
         hip.attn_out_ffn_fused = attn_out_ffn_fused
+        orig_tailp = hip.attn_out_ffn_proj_fused
+
+        def attn_out_ffn_proj_fused(att, resid32, rowbias, w_stream, bo, gamma, beta, b1, w2p, b2, b_po, x_in, out16, out32, colstats, *,
+                                    M, C_, **kw):
+            # ... and the SpatialTransformer's proj_out (2 M C C) behind it, still one launch
+            call = lambda: orig_tailp(att, resid32, rowbias, w_stream, bo, gamma, beta, b1, w2p, b2, b_po, x_in, out16, out32, colstats,
+                                      M=M, C_=C_, **kw)
+            if not timer.on:
+                return call()
+            timer._timed("gemm", "attn_out_ffn_proj_fused", 28.0 * M * C_ * C_, 1, call)
+        hip.attn_out_ffn_proj_fused = attn_out_ffn_proj_fused
         orig_front = hip.st_front
 
         def st_front(x32, gn_ab, wcat, b_in, gamma, beta, t0, qkv, *, M, C_, hw, NQ, rows_full, nq_lo=0, **kw):

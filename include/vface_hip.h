@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VFACE_ABI_VERSION 5   /* 5: + vface_st_front, vface_attn_out_ffn_fused, vface_gn_silu_conv3x3_small; vface_attention's v_sets carries the live-set count in bits 8..15, vface_pack_unet_input / vface_ddim_step take the two-branch batch; nothing else of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
+#define VFACE_ABI_VERSION 5   /* 5: + vface_st_front, vface_attn_out_ffn_fused, vface_attn_out_ffn_proj_fused, vface_gn_silu_conv3x3_small; vface_attention's v_sets carries the live-set count in bits 8..15, vface_pack_unet_input / vface_ddim_step take the two-branch batch; nothing else of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
 
 #define VFACE_OK 0
 #define VFACE_ERR_ARG (-1)
@@ -338,6 +338,18 @@ int vface_attn_out_ffn_fused(const void* att, int64_t ldatt, const float* resid,
                              int rows_per_sample, const void* WoW1, const float* bo, const float* gamma, const float* beta, float eps,
                              const float* b1, const void* W2p, const float* b2, void* out16, int64_t ldo, float* out32,
                              int64_t ldo32, int M, int C, int dtype, void* stream);
+
+/* ... and the SpatialTransformer's proj_out + residual behind it (attention.py:286-289 `x = proj_out(x); return x + x_in`), same launch:
+ *   y = (out of vface_attn_out_ffn_fused)_16 @ Wpo^T + b_po + x_in
+ * WoW1Wp = vface_attn_out_ffn_fused's stream + the C rows of proj_out with their k columns permuted the same way
+ * (packing.pack_attn_out_ffn(.., w_proj_out)); x_in: the transformer's fp32 input [M][ld_xin]; y goes to out16 (optional) / out32
+ * (optional, at least one); colstats (optional): [M / 64][ld_colstats][2] fp32 (sum, sum of squares) of y's columns per 64-row
+ * slice -- what vface_gemm's epilogue hands the next GroupNorm (vface_groupnorm_finalize_cols / _coeffs_from_cols). */
+int vface_attn_out_ffn_proj_fused(const void* att, int64_t ldatt, const float* resid, int64_t ldr, const float* rowbias, int64_t ld_rowbias,
+                                  int rows_per_sample, const void* WoW1Wp, const float* bo, const float* gamma, const float* beta, float eps,
+                                  const float* b1, const void* W2p, const float* b2, const float* b_po, const float* x_in, int64_t ld_xin,
+                                  void* out16, int64_t ldo, float* out32, int64_t ldo32, float* colstats, int64_t ld_colstats, int M, int C,
+                                  int dtype, void* stream);
 
 /* The UNet's `out` layer in one launch (openaimodel.py:712-716, :905): out = conv3x3( SiLU( x * a[img] + b[img] )_16 ) + bias with Cout
  * in {3, 4}, Cin % 64 == 0; x: [nimg*H*W][ldx] fp32 residual-stream carrier (in_f32) or 16-bit; (a, b): vface_groupnorm_coeffs_from_cols;

@@ -1110,6 +1110,62 @@ def test_attn_out_ffn_fused_vs_reference_and_vs_two_launches(dt, M, C, rps, with
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,C,rps,want16,wide", [(256, 64, 128, True, False), (512, 128, 256, False, True), (1024, 320, 512, True, True),
+                                                 (128 * 300, 320, 128 * 100, False, False)])
+def test_attn_out_ffn_proj_fused_vs_reference_and_vs_separate_proj_out(dt, M, C, rps, want16, wide):
+    """csrc/ffn.hip, POST form (``vface_attn_out_ffn_proj_fused``): the SpatialTransformer's proj_out + x_in (attention.py:286-289)
+    and the column statistics of the result behind the fused block tail, one launch -- against (a) fp64 on the same 16-bit operands
+    (the tail's own 16-bit output is the operand, as in the separate GEMM) and (b) vface_attn_out_ffn_fused + vface_gemm with
+    colstats / out32 / residual32; outputs into column slices of wider buffers (the skip-concatenation targets) too."""
+    h = hip()
+    from vface_amd import packing
+    att = rnd((M, C), 41, dt, 0.8)
+    t0 = rnd((M, C), 42, torch.float32, 1.2) + rnd((M, 1), 43, torch.float32, 0.5)
+    wo, bo = rnd((C, C), 44, dt, C ** -0.5), rnd((C,), 45, torch.float32, 0.2)
+    rb = rnd((M // rps, C), 46, torch.float32, 0.5)
+    gamma, beta = 1.0 + rnd((C,), 33, torch.float32, 0.2), rnd((C,), 34, torch.float32, 0.2)
+    w1, b1 = rnd((8 * C, C), 35, dt, C ** -0.5), rnd((8 * C,), 36, torch.float32, 0.3)
+    w2, b2 = rnd((C, 4 * C), 37, dt, (4 * C) ** -0.5), rnd((C,), 38, torch.float32, 0.3)
+    wpo, bpo = rnd((C, C), 47, dt, C ** -0.5), rnd((C,), 48, torch.float32, 0.2)
+    x_in = rnd((M, C), 49, torch.float32, 1.5)
+    w1p, b1p = packing.pack_geglu(w1, b1)
+    w2p = packing.pack_ffn_w2(w2)
+    d = lambda v: v.to(DEV).contiguous()
+    attd, t0d, rbd, xd = d(att), d(t0), d(rb), d(x_in)
+    # (b) first: the block tail alone, then proj_out as a GEMM
+    t3 = torch.zeros(M, C, dtype=dt, device=DEV)
+    h.attn_out_ffn_fused(attd, t0d, rbd, d(packing.pack_attn_out_ffn(wo, w1p)), d(bo), d(gamma), d(beta), d(b1p), d(w2p), d(b2), t3, M=M, C_=C,
+                         rows_per_sample=rps)
+    y2 = torch.zeros(M, C, dtype=torch.float32, device=DEV)
+    y2_16 = torch.zeros(M, C, dtype=dt, device=DEV)
+    cs2 = torch.zeros(M // 64, C, 2, dtype=torch.float32, device=DEV)
+    h.gemm(t3, d(wpo), y2_16, M=M, N=C, K=C, lda=C, ldc=C, bias=d(bpo), colstats=cs2, residual32=xd, out32=y2, rows_per_sample=rps)
+    ref = (t3.cpu().double() @ wpo.double().t() + bpo.double() + x_in.double())
+    assert rel_l2(y2.cpu().double(), ref) < 2e-6
+    # the one launch
+    W = C + 32 if wide else C
+    y32 = torch.full((M, W), 7.0, dtype=torch.float32, device=DEV)[:, W - C:]
+    y16 = torch.full((M, W), 7.0, dtype=dt, device=DEV)[:, W - C:] if want16 else None
+    cs = torch.full((M // 64, W, 2), 7.0, dtype=torch.float32, device=DEV)[:, W - C:]
+    h.attn_out_ffn_proj_fused(attd, t0d, rbd, d(packing.pack_attn_out_ffn(wo, w1p, wpo)), d(bo), d(gamma), d(beta), d(b1p), d(w2p), d(b2),
+                              d(bpo), xd, y16, y32, cs, M=M, C_=C, rows_per_sample=rps)
+    e, e_vs = rel_l2(y32.cpu().double(), ref), rel_l2(y32.cpu(), y2.cpu())
+    print(f"tail + proj_out fused M={M} C={C} {dt}: vs fp64 on the tail's 16-bit output {e:.2e}; vs the separate GEMM {e_vs:.2e}")
+    # (t3 = accumulator + (b2 + bo + a2) is formed and rounded exactly as the separate tail does: the operands are the same bits,
+    # what differs is fp32 summation order -- x_in is the accumulator's initial value here, the epilogue's last addend there)
+    assert e < 1e-5 and e_vs < 1e-5
+    if want16:
+        assert torch.equal(y16, y32.to(dt))
+    sl = y32.reshape(M // 64, 64, C).double()
+    want = torch.stack([sl.sum(1), (sl * sl).sum(1)], -1)
+    assert rel_l2(cs.double().cpu(), want.cpu()) < 1e-6
+    if wide:      # nothing outside the column slice was touched
+        for buf in (y32, cs) + ((y16,) if want16 else ()):
+            base = buf._base
+            assert bool((base[:, :W - C] == 7.0).all())
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,C,hw,rows_full,nq_lo,want_ln", [(256, 64, 128, 256, 0, False), (768, 128, 256, 256, 256, True),
                                                             (1024, 320, 256, 1024, 0, False), (3072, 320, 1024, 1024, 640, True),
                                                             (128 * 300, 320, 128 * 100, 128 * 100, 640, False)])

@@ -58,7 +58,7 @@ def main():
         return img
 
     names = ["gemm", "conv3x3", "conv3x3_plus_1x1", "upsample2x_conv3x3", "attention", "layernorm", "groupnorm_apply",
-             "groupnorm_stats_from_cols", "groupnorm_stats", "ffn_fused", "attn_out_ffn_fused", "st_front", "gn_silu_conv3x3_small", "flow_warp", "silu", "cast_f32", "timestep_embedding",
+             "groupnorm_stats_from_cols", "groupnorm_stats", "ffn_fused", "attn_out_ffn_fused", "attn_out_ffn_proj_fused", "st_front", "gn_silu_conv3x3_small", "flow_warp", "silu", "cast_f32", "timestep_embedding",
              "pack_unet_input", "ddim_step", "groupnorm_coeffs_from_cols", "nchw_to_nhwc", "nhwc_to_nchw_f32", "copy2d"]
     rec, on = [], [False]
 
@@ -117,6 +117,8 @@ def main():
         if name == "st_front":
             M, C, NQ, rf, lo = g("M"), g("C_"), g("NQ"), g("rows_full"), g("nq_lo", 0)
             return 2.0 * M * C * C + 2.0 * C * (rf * NQ + (M - rf) * (NQ - lo)), M * C * 8 + (rf * NQ + (M - rf) * (NQ - lo)) * 2
+        if name == "attn_out_ffn_proj_fused":
+            return 28.0 * g("M") * g("C_") ** 2, g("M") * g("C_") * 14
         if name == "attn_out_ffn_fused":
             return 26.0 * g("M") * g("C_") ** 2, g("M") * g("C_") * 8
         if name == "ffn_fused":

@@ -377,6 +377,20 @@ int vface_attn_out_ffn_fused(const void* att, int64_t ldatt, const float* resid,
     return vf_launch_ffn_fused(p, dtype, S(stream));
 }
 
+int vface_attn_out_ffn_proj_fused(const void* att, int64_t ldatt, const float* resid, int64_t ldr, const float* rowbias, int64_t ld_rowbias,
+                                  int rows_per_sample, const void* WoW1Wp, const float* bo, const float* gamma, const float* beta, float eps,
+                                  const float* b1, const void* W2p, const float* b2, const float* b_po, const float* x_in, int64_t ld_xin,
+                                  void* out16, int64_t ldo, float* out32, int64_t ldo32, float* colstats, int64_t ld_colstats, int M, int C,
+                                  int dtype, void* stream) {
+    if (!att || !x_in || !b_po) return VFACE_ERR_ARG;
+    FfnParams p{};
+    p.att = att; p.ldatt = ldatt; p.resid = resid; p.ldr = ldr; p.rowbias = rowbias; p.ld_rowbias = ld_rowbias;
+    p.rows_per_sample = rows_per_sample; p.bo = bo; p.gamma = gamma; p.beta = beta; p.eps = eps; p.W1 = WoW1Wp; p.b1 = b1; p.W2p = W2p;
+    p.b2 = b2; p.out16 = out16; p.ldo = ldo; p.out32 = out32; p.ldo32 = ldo32; p.M = M; p.C = C;
+    p.Wpo_in_stream = 1; p.b_po = b_po; p.x_in = x_in; p.ld_xin = ld_xin; p.colstats = colstats; p.ld_colstats = ld_colstats;
+    return vf_launch_ffn_fused(p, dtype, S(stream));
+}
+
 int vface_gn_silu_conv3x3_small(const void* x, int64_t ldx, int in_f32, const float* gn_ab, int64_t ld_ab, const void* Wt, const float* bias,
                                 float* out, int64_t ldo, int nimg, int H, int W, int Cin, int Cout, int dtype, void* stream) {
     OutConvParams p{};

@@ -57,14 +57,26 @@ constexpr int ffn_ring(int n, int want) { for (int r = want; r > 1; --r) if (n %
 // t0 + bo + a2 and hold t1 when the LayerNorm reads them, so neither t1's 126 MB write nor its two 126 MB reads (LayerNorm
 // input, residual) happen, and one launch goes.  The LayerNorm'd tile, register by register, is GEMM 1's B operand (as in
 // stfront.hip), so ff.net[0]'s k columns are stored in ffn_w2_perm order for this form.
-template <class TT, int C, bool PRE = false>
+//
+// POST (round 4, with PRE): the SpatialTransformer's proj_out BEHIND it (attention.py:286-289: x = proj_out(x); return x + x_in),
+// same launch:
+//     t3  = out (above), rounded to 16 bits -- the operand the separate GEMM read from HBM
+//     y   = proj_out(t3) + b_po + x_in                  (+ the per-64-row column statistics the next GroupNorm reads)
+// C / 32 more stages at the END of the W1 stream ([to_out ; ff.net[0] ; proj_out] rows, proj_out's k columns in ffn_w2_perm
+// order: the rounded accumulator tiles are the B operand, register by register, as after the LayerNorm).  The accumulators are
+// re-initialised with x_in (loaded straight into the accumulator registers) once t3 has left them, so t3's 63 + 126 MB of
+// writes, proj_out's 63 MB operand read and a 91-us launch go.
+template <class TT, int C, bool PRE = false, bool POST = false>
 __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
+    static_assert(!POST || PRE, "the proj_out stage exists in the block-tail form only");
     using E = typename TT::elem;
     using V8 = typename TT::v8;
     constexpr int KS = C / 16;          // k16 steps of GEMM 1 = MFMAs per tile
     constexpr int NOT = C / 32;         // output row tiles of GEMM 2 = its MFMAs per tile
     constexpr int NT = 4 * C / 16;      // hidden tiles
     constexpr int NPRE = PRE ? C / 32 : 0;   // to_out stages in front of the W1 stream
+    constexpr int NPOST = POST ? C / 32 : 0; // proj_out stages behind it
+    constexpr int NSTREAM = NT + NPRE + NPOST;
     constexpr int NW1 = 4, NW2 = 3;     // stage rings
     constexpr int W1E = 32 * C;         // elements per W1 stage: [32 rows][C]
     constexpr int W2E = C * 32;         // elements per W2 stage: [C rows][32 hidden]
@@ -78,6 +90,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     float* sB1 = reinterpret_cast<float*>(sW2 + NW2 * W2E);   // ff.net[0] bias, [8 C] fp32 in packed row order
     float* sGB = sB1 + 8 * C;                                 // gamma [C], beta [C]
     float* sBS = sGB + 2 * C;                                 // PRE: to_out bias + attn2 row bias of this workgroup's sample [C]
+    float* sBP = sBS + C;                                     // POST: ff.net[2]'s bias + sBS [C]
 
     const int t_ = threadIdx.x, lane = t_ & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t_ >> 6);
@@ -112,7 +125,11 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
             }
         {
             const float* rb = p.rowbias ? p.rowbias + (long)(tok0 / p.rows_per_sample) * p.ld_rowbias : nullptr;
-            for (int i = t_; i < C; i += 256) sBS[i] = p.bo[i] + (rb ? rb[i] : 0.f);
+            for (int i = t_; i < C; i += 256) {
+                const float e = p.bo[i] + (rb ? rb[i] : 0.f);
+                sBS[i] = e;
+                if constexpr (POST) sBP[i] = p.b2[i] + e;
+            }
         }
         __syncthreads();                 // sGB (and sB1) written
     } else {
@@ -159,7 +176,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     // its reading order and the XOR swizzles that make the fragment reads conflict-free are applied on the SOURCE chunk.
     //   W1 stage = [32 rows][C / 8 slots]: slot of k chunk c of row r = (c & ~7) | ((c & 7) ^ ((r >> 1) & 7))
     //   W2 stage = [C rows][4 slots]:      slot of chunk c of row r   = c ^ ((r >> 2) & 3)
-    const i32x4_t rW1 = raw_buffer_rsrc(p.W1, (8u * C + (PRE ? C : 0)) * C * 2u), rW2 = raw_buffer_rsrc(p.W2p, 4u * C * C * 2u);
+    const i32x4_t rW1 = raw_buffer_rsrc(p.W1, (8u * C + (PRE ? C : 0) + (POST ? C : 0)) * C * 2u), rW2 = raw_buffer_rsrc(p.W2p, 4u * C * C * 2u);
     const unsigned ldsW1 = lds_addr_of(sW1), ldsW2 = lds_addr_of(sW2);
     constexpr int SPR = C / 8;          // 16-byte slots per W1 row
     int w1_off[OPS], w2_off[OPS];
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
         w2_off[i] = (r2 * 4 * C + c2 * 8) * 2;
     }
     auto issue_w1_op = [&](int tile, int i) {     // piece i of the W1 stage of hidden tile `tile` (wrapped) -> ring slot tile % NW1
-        const int base = ((tile % (NT + NPRE)) * 32 * C) * 2;      // (stage index of the stream: PRE puts to_out's tiles first)
+        const int base = ((tile % NSTREAM) * 32 * C) * 2;          // (stage index of the stream: PRE puts to_out's tiles first)
         const unsigned dst = ldsW1 + (unsigned)(((tile % NW1) * W1E + wave * OPS * 512) * 2);
         raw_lds_dma16(rW1, dst + i * 1024, w1_off[i], base);
     };
@@ -210,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     };
     auto advance_w1_issue = [&]() {
         w1i_glob += 32 * C * 2;
-        if (w1i_glob == (NT + NPRE) * 32 * C * 2) w1i_glob = 0;        // past the end: wrap to stages nobody reads
+        if (w1i_glob == NSTREAM * 32 * C * 2) w1i_glob = 0;            // past the end: wrap to stages nobody reads
         w1i_slot = (w1i_slot + 1) & (NW1 - 1);
     };
     auto advance_w2_issue = [&]() {
@@ -264,7 +281,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     // one instruction stream: per k16 step one MFMA of GEMM 1, every other step one of GEMM 2, every other step one GEGLU value.
     // `cur` receives tile t's sums, `prev` holds tile t - 1's; `hw` receives tile t - 1's GEGLU, `hr` holds tile t - 2's.
     auto interval = [&](int t, f16_t& cur, f16_t& prev, V8& hw, V8& hr, auto h1_tag, auto hg_tag, auto h2_tag, auto even_tag,
-                        auto first_tag) {
+                        auto first_tag, auto last_tag) {
+        // (POST, the last interval: the stage it would issue -- proj_out's stage 4 -- belongs in the ring slot of proj_out's stage 0,
+        // which nobody has read yet: it issues nothing, and the proj_out loop below counts its own instructions)
+        constexpr bool NO_W1_ISSUE = POST && decltype(last_tag)::value;
         constexpr bool H1 = decltype(h1_tag)::value, HG = decltype(hg_tag)::value, H2 = decltype(h2_tag)::value;
         constexpr bool EVEN = decltype(even_tag)::value;
         // (PRE, interval 0: the stage it needs was issued by a to_out interval, which issues no W2 piece -- one instruction less
@@ -343,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
                 // ks - 1 + RA of this tile, or of the next (its stage has landed)
                 af[(ks + RA - 1) % RA] = (ks - 1 + RA < KS) ? w1_frag_at(wa, ks - 1 + RA) : w1_frag_at(wb, ks - 1 + RA - KS);
             }
-            if (ks % 4 == 1) issue_w1_piece(ks / 4);                        // (KS = 4 OPS)
+            if constexpr (!NO_W1_ISSUE) { if (ks % 4 == 1) issue_w1_piece(ks / 4); }      // (KS = 4 OPS)
             if constexpr (EVEN) { if (ks % 4 == 3) issue_w2_piece(ks / 4); }
             if constexpr (HG) {
                 if constexpr (KS >= 16) { gelu_piece(gap); ++gap; }
@@ -376,7 +396,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
             gap_valu_result_to_mfma(hw);
         }
         // the streams' state for interval t + 1
-        advance_w1_issue();
+        if constexpr (!NO_W1_ISSUE) advance_w1_issue();
         if constexpr (EVEN) advance_w2_issue();
         w1r_slot = (w1r_slot + 1) & (NW1 - 1);                          // ring slot of tile t + 2
 #pragma unroll
@@ -470,14 +490,82 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
         for (int ot = 0; ot < NOT; ++ot) gap_valu_result_to_acc_mfma(out[ot]);      // (out goes back to the matrix pipe untouched)
     }
     using P_ = std::integral_constant<bool, PRE>;
-    interval(0,      accA, accB, hbO, hbE,  T_{}, F_{}, F_{}, T_{}, P_{});
-    interval(1,      accB, accA, hbE, hbO,  T_{}, T_{}, F_{}, F_{}, F_{});
+    interval(0,      accA, accB, hbO, hbE,  T_{}, F_{}, F_{}, T_{}, P_{}, F_{});
+    interval(1,      accB, accA, hbE, hbO,  T_{}, T_{}, F_{}, F_{}, F_{}, F_{});
     for (int t = 2; t < NT; t += 2) {
-        interval(t,     accA, accB, hbO, hbE, T_{}, T_{}, T_{}, T_{}, F_{});
-        interval(t + 1, accB, accA, hbE, hbO, T_{}, T_{}, T_{}, F_{}, F_{});
+        interval(t,     accA, accB, hbO, hbE, T_{}, T_{}, T_{}, T_{}, F_{}, F_{});
+        interval(t + 1, accB, accA, hbE, hbO, T_{}, T_{}, T_{}, F_{}, F_{}, F_{});
     }
-    interval(NT,     accA, accB, hbO, hbE,  F_{}, T_{}, T_{}, T_{}, F_{});
-    interval(NT + 1, accB, accA, hbE, hbO,  F_{}, F_{}, T_{}, F_{}, F_{});
+    interval(NT,     accA, accB, hbO, hbE,  F_{}, T_{}, T_{}, T_{}, F_{}, F_{});
+    interval(NT + 1, accB, accA, hbE, hbO,  F_{}, F_{}, T_{}, F_{}, F_{}, T_{});
+
+    if constexpr (POST) {
+        // ---- proj_out.  Its stages 0..3 (stream stages NPRE + NT ..) were issued by the intervals above; behind this wait and
+        // barrier they have landed and every wave is done with the FeedForward's stages.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        raw_barrier();
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot) gap_acc_result_to_valu(out[ot]);
+        // t3 = accumulator + (b2 + bo + a2), rounded: register by register the B operand (the k order of the LayerNorm'd tile above)
+        const float* xin = p.x_in + (tok0 + fr) * p.ld_xin + fh * 4;
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                V8 o;
+#pragma unroll
+                for (int e4 = 0; e4 < 2; ++e4) {
+                    const int q4 = 2 * j + e4;
+                    const float4 bb = *reinterpret_cast<const float4*>(sBP + ot * 32 + q4 * 8 + fh * 4);
+                    o[4 * e4 + 0] = from_f32<E>(out[ot][4 * q4 + 0] + bb.x);
+                    o[4 * e4 + 1] = from_f32<E>(out[ot][4 * q4 + 1] + bb.y);
+                    o[4 * e4 + 2] = from_f32<E>(out[ot][4 * q4 + 2] + bb.z);
+                    o[4 * e4 + 3] = from_f32<E>(out[ot][4 * q4 + 3] + bb.w);
+                }
+                xf[2 * ot + j] = o;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(xf[ks]));
+        // the accumulators start again as x_in (the SpatialTransformer's input, fp32 carrier), straight into the accumulator registers
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 v = *reinterpret_cast<const float4*>(xin + ot * 32 + q4 * 8);
+                out[ot][4 * q4] = v.x; out[ot][4 * q4 + 1] = v.y; out[ot][4 * q4 + 2] = v.z; out[ot][4 * q4 + 3] = v.w;
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // x_in is in (one exposed HBM latency per workgroup: ~0.5 % of the kernel)
+        gap_valu_result_to_mfma(xf[KS - 1]);
+#pragma unroll
+        for (int ot = 0; ot < NOT; ++ot) gap_valu_result_to_acc_mfma(out[ot]);
+        constexpr int S0 = (NPRE + NT) % NW1;        // ring slot of proj_out's stage 0
+        w1r_slot = (S0 + 1) % NW1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wa[j] = sW1 + S0 * W1E + w1_lane[j]; wb[j] = sW1 + ((S0 + 1) % NW1) * W1E + w1_lane[j]; }
+#pragma unroll
+        for (int i = 0; i < RA; ++i) af[i] = w1_frag_at(wa, i);
+#pragma unroll
+        for (int s_ = 0; s_ < NPOST; ++s_) {
+            if (s_ > 0) {
+                // stage s_ + 1 has landed (issued two stages ago; behind it only stage s_ - 1's OPS pieces) and, behind the barrier,
+                // every wave is done with stage s_ - 1 -- the ring slot this stage's pieces (stage s_ + 3) go to
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+                raw_barrier();
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                TT::mfma32x32_acc(out[s_], af[ks % RA], xf[ks]);
+                af[(ks + RA - 1) % RA] = (ks - 1 + RA < KS) ? w1_frag_at(wa, ks - 1 + RA) : w1_frag_at(wb, ks - 1 + RA - KS);
+                if (s_ > 0 && ks % 4 == 1) issue_w1_piece(ks / 4);       // (past proj_out's last stage: wrapped, nobody reads it)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (s_ > 0) advance_w1_issue();
+            w1r_slot = (w1r_slot + 1) & (NW1 - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wa[j] = wb[j]; wb[j] = sW1 + w1r_slot * W1E + w1_lane[j]; }
+        }
+    }
 
     // ---- epilogue: (out + b2) + x, half the channels of a wave's 32 tokens at a time through LDS (row pitch C / 2 + 4 floats:
     // consecutive tokens one 16-byte slot apart), read back as whole 32-byte row chunks
@@ -488,6 +576,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
     constexpr int NH = (NOT + 1) / 2;    // output tiles per half
     constexpr int SP = NH * 32 + 4;
     float* scr = reinterpret_cast<float*>(smem_raw) + wave * (32 * SP);
+    float* sCS = reinterpret_cast<float*>(smem_raw) + 4 * (32 * SP);      // POST: column (sum, sum of squares) per wave, [4][C][2]
+    const float* bias_out = POST ? p.b_po : p.b2;
     E* out16 = reinterpret_cast<E*>(p.out16);
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
@@ -526,8 +616,8 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
                 const float* sp = scr + tok * SP + ch * 8;
                 const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
                 const int col = ot0 * 32 + ch * 8;
-                float4 c0 = *reinterpret_cast<const float4*>(p.b2 + col), c1 = *reinterpret_cast<const float4*>(p.b2 + col + 4);
-                if constexpr (PRE) {      // (the out-projection's bias + attn2's row bias, held back from the accumulators' initial value)
+                float4 c0 = *reinterpret_cast<const float4*>(bias_out + col), c1 = *reinterpret_cast<const float4*>(bias_out + col + 4);
+                if constexpr (PRE && !POST) {      // (the out-projection's bias + attn2's row bias, held back from the accumulators' initial value)
                     const float4 e0 = *reinterpret_cast<const float4*>(sBS + col), e1 = *reinterpret_cast<const float4*>(sBS + col + 4);
                     c0 = make_float4(c0.x + e0.x, c0.y + e0.y, c0.z + e0.z, c0.w + e0.w);
                     c1 = make_float4(c1.x + e1.x, c1.y + e1.y, c1.z + e1.z, c1.w + e1.w);
@@ -546,16 +636,52 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(FfnParams p) {
                     *reinterpret_cast<float4*>(d) = make_float4(v[0], v[1], v[2], v[3]);
                     *reinterpret_cast<float4*>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 }
+                if constexpr (POST) {
+                    if (p.colstats) {      // the finished values go back to the scratch for the column sums below
+                        float* sw = scr + tok * SP + ch * 8;
+                        *reinterpret_cast<float4*>(sw) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(sw + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                }
+            }
+        }
+        if constexpr (POST) {
+            // per-wave column sums of the half (32 tokens, fixed order): lane l owns channels 4 l .. 4 l + 3 of it
+            if (p.colstats && lane < nt * 8) {
+                float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+                for (int tok = 0; tok < 32; ++tok) {
+                    const float4 a = *reinterpret_cast<const float4*>(scr + tok * SP + lane * 4);
+                    s4[0] += a.x; s4[1] += a.y; s4[2] += a.z; s4[3] += a.w;
+                    q4s[0] = fmaf(a.x, a.x, q4s[0]); q4s[1] = fmaf(a.y, a.y, q4s[1]);
+                    q4s[2] = fmaf(a.z, a.z, q4s[2]); q4s[3] = fmaf(a.w, a.w, q4s[3]);
+                }
+                float* cw = sCS + ((long)wave * C + ot0 * 32 + lane * 4) * 2;
+                *reinterpret_cast<float4*>(cw) = make_float4(s4[0], q4s[0], s4[1], q4s[1]);
+                *reinterpret_cast<float4*>(cw + 4) = make_float4(s4[2], q4s[2], s4[3], q4s[3]);
+            }
+        }
+    }
+    if constexpr (POST) {
+        if (p.colstats) {
+            // a 64-row slice = two waves' tokens: first wave + second wave, written once
+            __syncthreads();
+            for (int i = t_; i < 2 * C; i += 256) {
+                const int sl = i / C, ch = i - sl * C;
+                const float2 a = *reinterpret_cast<const float2*>(sCS + ((2 * sl) * C + ch) * 2);
+                const float2 b = *reinterpret_cast<const float2*>(sCS + ((2 * sl + 1) * C + ch) * 2);
+                *reinterpret_cast<float2*>(p.colstats + (((long)blockIdx.x * 2 + sl) * p.ld_colstats + ch) * 2) = make_float2(a.x + b.x, a.y + b.y);
             }
         }
     }
 }
 
-template <class TT, int C, bool PRE = false>
+template <class TT, int C, bool PRE = false, bool POST = false>
 int launch_c(const FfnParams& p, hipStream_t stream) {
-    constexpr size_t lds = (size_t)(4 * 32 * C + 3 * C * 32) * 2 + (size_t)11 * C * 4;
-    static_assert((size_t)4 * 32 * (((C / 32 + 1) / 2) * 32 + 4) * 4 <= (size_t)(4 * 32 * C + 3 * C * 32) * 2, "epilogue scratch fits the weight rings");
-    auto kern = ffn_fused_kernel<TT, C, PRE>;
+    constexpr size_t lds = (size_t)(4 * 32 * C + 3 * C * 32) * 2 + (size_t)12 * C * 4;
+    static_assert((size_t)4 * 32 * (((C / 32 + 1) / 2) * 32 + 4) * 4 + (size_t)4 * C * 8 <= (size_t)(4 * 32 * C + 3 * C * 32) * 2,
+                  "epilogue scratch (+ the column sums) fits the weight rings");
+    auto kern = ffn_fused_kernel<TT, C, PRE, POST>;
     static VfOncePerDevice attr_set;
     if (lds > 64 * 1024 && !attr_set.set_lds(reinterpret_cast<const void*>(kern), (int)lds)) return VF_ERR_LAUNCH;
     hipLaunchKernelGGL(kern, dim3(p.M / 128), dim3(256), lds, stream, p);
@@ -564,6 +690,14 @@ int launch_c(const FfnParams& p, hipStream_t stream) {
 
 template <class TT>
 int launch_t(const FfnParams& p, hipStream_t stream) {
+    if (p.att && p.Wpo_in_stream) {
+        switch (p.C) {
+            case 64: return launch_c<TT, 64, true, true>(p, stream);
+            case 128: return launch_c<TT, 128, true, true>(p, stream);
+            case 320: return launch_c<TT, 320, true, true>(p, stream);
+            default: return VF_ERR_SHAPE;
+        }
+    }
     if (p.att) {
         switch (p.C) {
             case 64: return launch_c<TT, 64, true>(p, stream);
@@ -591,6 +725,11 @@ int vf_launch_ffn_fused(const FfnParams& p, int dtype, hipStream_t stream) {
         if (!p.resid || !p.bo || (p.rowbias && (p.rows_per_sample <= 0 || (p.rows_per_sample % 128) || (p.ld_rowbias & 3)))) return VF_ERR_ARG;
         if ((p.ldatt & 7) || (p.ldr & 3)) return VF_ERR_ALIGN;
         if (((uintptr_t)p.att | (uintptr_t)p.resid | (uintptr_t)p.bo | (uintptr_t)p.rowbias) & 15) return VF_ERR_ALIGN;
+    }
+    if (p.Wpo_in_stream) {      // proj_out behind: x_in [M][C] fp32, b_po [C], optional column statistics [M / 64][ld][2]
+        if (!p.att || !p.x_in || !p.b_po) return VF_ERR_ARG;
+        if ((p.ld_xin & 3) || (p.colstats && (p.ld_colstats & 1))) return VF_ERR_ALIGN;
+        if (((uintptr_t)p.x_in | (uintptr_t)p.b_po | (uintptr_t)p.colstats) & 15) return VF_ERR_ALIGN;
     }
     if ((p.x32 && (p.ldx & 3)) || (p.out16 && (p.ldo & 7)) || (p.out32 && (p.ldo32 & 3))) return VF_ERR_ALIGN;
     if (((uintptr_t)p.x32 | (uintptr_t)p.gamma | (uintptr_t)p.beta | (uintptr_t)p.W1 | (uintptr_t)p.b1 | (uintptr_t)p.W2p |

@@ -103,6 +103,12 @@ struct FfnParams {
     const float* resid; long ldr;    // [M][C] fp32: the running sum before attn1 (t0)
     const float* bo;                 // [C] to_out bias
     const float* rowbias; long ld_rowbias; int rows_per_sample;   // optional fp32 [M / rows_per_sample][ld]: attn2's contribution
+    // Wpo_in_stream (with att): the SpatialTransformer's proj_out runs behind (ffn.hip "POST"): W1 is [C + 8C + C][C] -- proj_out's rows
+    // last, k columns in ffn_w2_perm order --, the outputs are y = proj_out(t3) + b_po + x_in and its per-64-row column statistics
+    int Wpo_in_stream;
+    const float* b_po;               // [C]
+    const float* x_in; long ld_xin;  // [M][C] fp32: the SpatialTransformer's input
+    float* colstats; long ld_colstats;   // optional [M / 64][ld][2] (sum, sum of squares) of y
 };
 bool vf_ffn_fused_supported(long M, int C);
 int vf_launch_ffn_fused(const FfnParams& p, int dtype, hipStream_t stream);

@@ -398,6 +398,8 @@ class UNetEngine:
         # attn1's out-projection (+ attn2's row bias + residual) in front of the fused FeedForward, one launch: the block's running
         # sum after attention never exists in HBM (csrc/ffn.hip, PRE form).  VFACE_FUSE_TAIL=0: GEMM + fused FeedForward (A/B).
         self.fuse_tail = os.environ.get("VFACE_FUSE_TAIL", "1") != "0"
+        # ... and the SpatialTransformer's proj_out + x_in + column statistics behind it, still one launch (ffn.hip POST form)
+        self.fuse_post = os.environ.get("VFACE_FUSE_POST", "1") != "0"
         # the UNet's `out` layer (GroupNorm -> SiLU -> conv3x3 to 4 channels) as one launch (csrc/outconv.hip).  VFACE_FUSE_OUT=0: A/B
         self.fuse_out = os.environ.get("VFACE_FUSE_OUT", "1") != "0"
         self._front_supported: Dict[tuple, bool] = {}
@@ -552,6 +554,12 @@ class UNetEngine:
             w_in = sd[prefix + ".proj_in.weight"].detach().float().cpu().reshape(c, c)
             w_p = packing.pack_qkv(sd[t + ".to_q.weight"], sd[t + ".to_k.weight"], sd[t + ".to_v.weight"]).detach().float().cpu()
             d["front_w"] = self._w16(packing.pack_st_front(w_in, w_p))
+        d["tail_post"] = False
+        if d.get("tail_w") is not None and self.fuse_post:
+            # proj_out's rows behind the tail's weight stream (vface_attn_out_ffn_proj_fused), k columns in the stream's order
+            w_po = sd[prefix + ".proj_out.weight"].detach().float().cpu().reshape(c, c)
+            d["tail_w"] = torch.cat([d["tail_w"], self._w16(w_po[:, packing.ffn_w2_perm(c)])], 0).contiguous()
+            d["tail_post"] = True
         return d
 
     def _param_version(self):
@@ -845,11 +853,12 @@ class UNetEngine:
         self._gemm(ff, p["ff2"], t2, hw=n, out32=t2_32, **self._resid(t1))
         return (t2, t2_32) if want32 else t2
 
-    def _st_front(self, x: Act, p: dict, attn1, a2vec: torch.Tensor) -> Optional[torch.Tensor]:
+    def _st_front(self, x: Act, p: dict, attn1, a2vec: torch.Tensor, post=None):
         """The SpatialTransformer up to and including its transformer block, with the FRONT -- GroupNorm-apply, proj_in,
         LayerNorm (norm1) and attn1's projection -- as ONE launch (csrc/stfront.hip) instead of four: needs the fp32 carrier
         and the producer's column statistics of ``x`` and a width the kernel takes.  Returns the block's last running sum
-        (16-bit, proj_out's operand), or None when this layer does not qualify (the caller then runs the separate launches).
+        (16-bit, proj_out's operand), or None when this layer does not qualify (the caller then runs the separate launches), or
+        True when ``post = (out16 | None, colstats | None, out32)`` was given and the tail launch also ran proj_out + ``x`` into it.
         What follows the front is the launch sequence of ``vface_attn1_forward`` (capi.cpp) minus its first two GEMMs: the
         dual-source projections of the hook's linear fusions (they read the LayerNorm output the front also writes then), the flow
         warp -- with the boundary exchange between chunk 1's fused projection and the warp when frames are sharded --, the
@@ -928,6 +937,11 @@ class UNetEngine:
                           qk_map=self._map("qk_replace", N, F_) if fusion == hip.FUSION_REPLACE else None, v_map=v_map, **kw)
         if self.fuse_tail and p.get("tail_w") is not None and n % 128 == 0 and self._ffn_ok(M, c):
             # to_out + bias + attn2's row bias + residual -> norm3 -> FeedForward -> + x in ONE launch: t1 never exists in HBM
+            if self.fuse_post and p.get("tail_post") and post is not None and post[2] is not None:
+                hip.attn_out_ffn_proj_fused(att, t0, a2vec, p["tail_w"], p["wo"]["b"], p["ln3"][0], p["ln3"][1], p["ff1"]["b"], p["ff2p"],
+                                            p["ff2"]["b"], p["proj_out"]["b"], x.t32, post[0], post[2], post[1], M=M, C_=c,
+                                            rows_per_sample=n)
+                return True
             t2 = self._new(M, c)
             hip.attn_out_ffn_fused(att, t0, a2vec, p["tail_w"], p["wo"]["b"], p["ln3"][0], p["ln3"][1], p["ff1"]["b"], p["ff2p"],
                                    p["ff2"]["b"], t2, M=M, C_=c, rows_per_sample=n)
@@ -952,10 +966,14 @@ class UNetEngine:
         N, n, c = x.N, x.hw, p["c"]
         s32 = self.stream32 and c % 8 == 0
         a, b = p["a2_slice"]
-        t2 = self._st_front(x, p, mod.transformer_blocks[0].attn1, a2_all[:, a:b]) if s32 else None
+        t2 = None
+        if s32:
+            tgt = self._new_target(x.M, c, x.hw) if tgt is None else tgt
+            t2 = self._st_front(x, p, mod.transformer_blocks[0].attn1, a2_all[:, a:b], post=tgt)
         if t2 is not None:
-            out, cs, o32 = self._new_target(x.M, c, x.hw) if tgt is None else tgt
-            self._gemm(t2, p["proj_out"], out, colstats=cs, hw=x.H * x.W, out32=o32, **self._resid(x))
+            out, cs, o32 = tgt
+            if t2 is not True:
+                self._gemm(t2, p["proj_out"], out, colstats=cs, hw=x.H * x.W, out32=o32, **self._resid(x))
             return Act(out, x.N, x.H, x.W, cs, o32)
         g = self._gn(x, p["gn"], 1e-6, False)
         t0 = self._new(x.M, c, torch.float32 if s32 else None)
@@ -1128,7 +1146,7 @@ class UNetEngine:
                                              None if self.halo_flow is None else tuple(self.halo_flow.shape))
         # (every switch that changes the captured launch sequence is part of the key: toggling one on a live engine must not
         # replay a stale graph)
-        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.fuse_out, self.live_chunks,
+        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.fuse_post, self.fuse_out, self.live_chunks,
                self.decompose_attn1, self.exchange_events is not None, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)

@@ -88,6 +88,8 @@ SIGNATURES = {
     "vface_ffn_fused": (C.c_int, [_vp, _i64, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "vface_attn_out_ffn_fused": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _i64, _vp,
                                            _i64, _i32, _i32, _i32, _vp]),
+    "vface_attn_out_ffn_proj_fused": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp,
+                                                _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
     "vface_gn_silu_conv3x3_small": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vface_st_front_supported": (C.c_int, [_i64, _i32, _i32]),
     "vface_st_front": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32,
@@ -494,6 +496,20 @@ def attn_out_ffn_fused(att: torch.Tensor, resid32: torch.Tensor, rowbias: Option
                                          _p(beta), eps, _p(b1), _p(w2p), _p(b2), _p(out16), out16.stride(0) if out16 is not None else 0,
                                          _p(out32), out32.stride(0) if out32 is not None else 0, M, C_, dtype_code(att.dtype), _stream())
     _check(rc, "vface_attn_out_ffn_fused")
+
+
+def attn_out_ffn_proj_fused(att: torch.Tensor, resid32: torch.Tensor, rowbias: Optional[torch.Tensor], w_stream: torch.Tensor,
+                            bo: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, b1: torch.Tensor, w2p: torch.Tensor, b2: torch.Tensor,
+                            b_po: torch.Tensor, x_in: torch.Tensor, out16: Optional[torch.Tensor], out32: Optional[torch.Tensor],
+                            colstats: Optional[torch.Tensor], *, M: int, C_: int, rows_per_sample: int, eps: float = 1e-5):
+    """``attn_out_ffn_fused`` + the SpatialTransformer's ``proj_out`` + ``x_in`` (+ column statistics) in ONE launch
+    (``vface_attn_out_ffn_proj_fused``); ``w_stream`` = ``packing.pack_attn_out_ffn(w_o, w1_geglu, w_proj_out)``."""
+    rc = load().vface_attn_out_ffn_proj_fused(
+        _p(att), att.stride(0), _p(resid32), resid32.stride(0), _p(rowbias), rowbias.stride(0) if rowbias is not None else 0,
+        rows_per_sample, _p(w_stream), _p(bo), _p(gamma), _p(beta), eps, _p(b1), _p(w2p), _p(b2), _p(b_po), _p(x_in), x_in.stride(0),
+        _p(out16), out16.stride(0) if out16 is not None else 0, _p(out32), out32.stride(0) if out32 is not None else 0,
+        _p(colstats), colstats.stride(0) // 2 if colstats is not None else 0, M, C_, dtype_code(att.dtype), _stream())
+    _check(rc, "vface_attn_out_ffn_proj_fused")
 
 
 def gn_silu_conv3x3_small(x: torch.Tensor, gn_ab: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,

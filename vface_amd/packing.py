@@ -14,6 +14,8 @@ computed in fp64 and handed to the device in the 16-bit compute type:
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 
 
@@ -101,13 +103,20 @@ def pack_st_front(w_in: torch.Tensor, w_proj: torch.Tensor) -> torch.Tensor:
     return torch.cat([w_in, w_proj[:, ffn_w2_perm(c)]], 0).contiguous()
 
 
-def pack_attn_out_ffn(w_o: torch.Tensor, w1_geglu: torch.Tensor) -> torch.Tensor:
+def pack_attn_out_ffn(w_o: torch.Tensor, w1_geglu: torch.Tensor, w_proj_out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Weight stream of the fused block TAIL (csrc/ffn.hip, PRE form): ``attn1.to_out[0]`` rows ``[C, C]`` (k = channel of the
     attention output), then the GEGLU-interleaved ``ff.net[0]`` rows ``[8C, C]`` (``pack_geglu``) with their k columns in
-    ``ffn_w2_perm`` order -- the order in which the LayerNorm'd accumulator tile of the out-projection is that GEMM's B operand."""
+    ``ffn_w2_perm`` order -- the order in which the LayerNorm'd accumulator tile of the out-projection is that GEMM's B operand --
+    and, for the POST form, the SpatialTransformer's ``proj_out`` rows ``[C, C]`` with the same column order (their operand is the
+    FeedForward's rounded accumulator tile)."""
     c = w_o.shape[0]
     assert w_o.shape == (c, c) and w1_geglu.shape == (8 * c, c)
-    return torch.cat([w_o, w1_geglu[:, ffn_w2_perm(c)]], 0).contiguous()
+    perm = ffn_w2_perm(c)
+    parts = [w_o, w1_geglu[:, perm]]
+    if w_proj_out is not None:
+        assert w_proj_out.shape == (c, c)
+        parts.append(w_proj_out[:, perm])
+    return torch.cat(parts, 0).contiguous()
 
 
 def pack_qkv(wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor) -> torch.Tensor:
