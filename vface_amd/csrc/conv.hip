@@ -733,6 +733,7 @@ int vf_conv_patch_tile(const GemmParams& p) {
     if (p.residual && !p.res_f32 && (((uintptr_t)p.residual & 15) || (p.ldr & 7))) return 0;
     if (((uintptr_t)p.C & 15) || (p.C && (p.ldc & 7))) return 0;
     const bool ok160 = p.N % 160 == 0, ok128 = p.N % 128 == 0;
+    if (p.gn_ab && ok128) return 128;      // the fused-normalisation build: its 128-wide instantiation keeps every value in registers
     if (ok160 && ok128 && !(p.flags & (GEMM_PATCH_BN160 | 0x4000))) {
         // Both widths tile N (640, 1280, 1920 channels): one workgroup per CU, so a launch takes ceil(workgroups / CUs) rounds, and
         // a 128-wide workgroup takes ~0.8 of a 160-wide one (32 instead of 40 MFMAs per wave and K tile, same fixed costs).

@@ -665,7 +665,12 @@ class UNetEngine:
     def _gn_fusable(self, x: Act, w: dict, which: str) -> bool:
         """Can GroupNorm-apply + SiLU of ``x`` ride in the operand path of the 3x3 convolution ``w``?  Needs producer-side
         column statistics, a 16-bit copy of ``x`` and a launch that runs the patch-staged kernel."""
-        if self.fuse_gn == "off" or (which == "in" and self.fuse_gn != "both"):
+        mode = self.fuse_gn
+        if mode.endswith("128"):          # only where the spill-free 128-wide instantiation runs (Cout a multiple of 128)
+            if w["cout"] % 128:
+                return False
+            mode = mode[:-3]
+        if mode == "off" or (which == "in" and mode != "both"):
             return False
         return x.cs is not None and x.t is not None and x.C == w["cinp"] and \
             hip.conv_uses_patch_kernel(x.H, x.W, w["cinp"], w["cout"], 3, 1, False) == 1
