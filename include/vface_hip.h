@@ -266,7 +266,10 @@ int vface_convex_upsample(const float* mask32, int64_t ldm, const float* flow32,
  * them on device buffers, with Pillow's 8-bit arithmetic restated exactly (oracle/paste.py is pinned against Pillow itself).
  *
  * vface_frame_to_u8: `torch.clamp((x + 1) / 2, 0, 1)` (:597), `255. * x` and `.astype(np.uint8)` (:606-608).
- *   x planar [frames][3][H][W] in [-1, 1], in_kind 0 fp16 | 1 bf16 | 2 fp32; out interleaved [frames][H][W][3]. */
+ *   x planar [frames][3][H][W] in [-1, 1], in_kind 0 fp16 | 1 bf16 | 2 fp32: the arithmetic is fp32 (what `--precision full` computes;
+ *   a 16-bit input is widened first); in_kind 3 = fp16 input AND fp16 arithmetic, every operation rounded to float16 as torch and
+ *   numpy do on the float16 tensor `--precision autocast` (the reference's default) hands over -- pixels can differ by one between
+ *   the two.  out interleaved [frames][H][W][3]. */
 int vface_frame_to_u8(const void* x, uint8_t* out, int frames, int H, int W, int in_kind, void* stream);
 
 /* One pass of `Image.resize(size, Image.BILINEAR)` on 8-bit RGB (:608, :623; Pillow Resample.c).  axis 0 resamples along x:

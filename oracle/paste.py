@@ -3,11 +3,18 @@
 Restates ``REFace/scripts/VFace_inference_batch.py:597-636`` in numpy.  The reference does this frame by frame on the host
 with Pillow (``Image.fromarray(..).resize(.., BILINEAR)``, ``Image.transform(.., PERSPECTIVE, coeffs, BILINEAR)``,
 ``alpha_composite``) and torchvision (``ToTensor``, ``Normalize``, ``Resize`` on a tensor = ``F.interpolate(mode="bilinear",
-align_corners=False)``).  Pillow is a third-party dependency of the reference (``environment.yaml``: ``pillow``, no pin) and is
-not under ``/root/reference``: the functions below restate Pillow's published algorithms (``src/libImaging/Resample.c``:
-``precompute_coeffs`` / ``normalize_coeffs_8bpc`` / the two 8-bit passes; ``Geometry.c``: ``perspective_transform`` /
-``bilinear_filter32RGB``; ``AlphaComposite.c``), and parity is PINNED by comparing them with the Pillow installed in this
-image (12.2.0) on the reference's own call sequence -- ``tests/test_oracle_golden.py::test_paste_*``.
+align_corners=False)``).  Pillow is a third-party dependency of the reference (``REFace/environment.yml:175`` pins
+``pillow==9.5.0``; ``requirements.txt:24`` says 9.0.1) and is not under ``/root/reference``: the functions below restate Pillow's
+published algorithms (``src/libImaging/Resample.c``: ``precompute_coeffs`` / ``normalize_coeffs_8bpc`` / the two 8-bit passes;
+``Geometry.c``: ``perspective_transform`` / ``bilinear_filter32RGB``; ``AlphaComposite.c``), and parity is PINNED by comparing
+them with the Pillow installed in this image (12.2.0) on the reference's own call sequence --
+``tests/test_oracle_golden.py::test_paste_*``.  The 8-bit bilinear resampling, the perspective transform and the alpha
+composite are the same algorithms in Pillow 9.x and 12.2 (the fixed-point 8bpc resampler dates from 3.x, the pixel-centre
+convention of ``Image.transform`` from 5.x), so pinning against 12.2.0 pins the reference's 9.5.0 behaviour too.
+
+Arithmetic type of the quantisation (:597-608): ``to_u8`` / ``clamp01`` compute in float32 -- the reference under
+``--precision full``.  Under its default ``--precision autocast`` the decoded tensor is float16 and torch / numpy round every
+operation to float16; ``to_u8_half`` / ``clamp01_half`` restate that (pixels can differ by one between the two).
 
 Nothing here is imported by the product path.
 """
@@ -28,6 +35,17 @@ def to_u8(x01: np.ndarray) -> np.ndarray:
 def clamp01(x: np.ndarray) -> np.ndarray:
     """``torch.clamp((x + 1.0) / 2.0, min=0.0, max=1.0)`` in float32 -- :597."""
     return np.clip((x.astype(np.float32) + np.float32(1.0)) / np.float32(2.0), np.float32(0.0), np.float32(1.0))
+
+
+def clamp01_half(x: np.ndarray) -> np.ndarray:
+    """:597 on a float16 tensor (``--precision autocast``): ``x + 1.0`` and ``/ 2.0`` each rounded to float16."""
+    h = x.astype(np.float16)
+    return np.clip(((h + np.float16(1.0)).astype(np.float16) / np.float16(2.0)).astype(np.float16), np.float16(0.0), np.float16(1.0))
+
+
+def to_u8_half(x01: np.ndarray) -> np.ndarray:
+    """:606-608 on the float16 array: ``255. * x`` stays float16 (a Python scalar does not widen a numpy array), then truncation."""
+    return (np.float16(255.0) * x01.astype(np.float16)).astype(np.float16).astype(np.uint8)
 
 
 def resample_coeffs(in_size: int, out_size: int):

@@ -31,6 +31,28 @@ def test_frame_to_u8_is_the_references_clamp_scale_truncate(dt):
     assert np.array_equal(got, ref)
 
 
+def test_frame_to_u8_half_arithmetic_is_the_autocast_paths_float16_rounding():
+    """under the reference's default ``--precision autocast`` the decoded frames are float16 and :597-608 round every
+    operation to float16; ``half_arithmetic=True`` restates that (against torch + numpy run on the float16 tensor, as the
+    reference runs them, and against the oracle), and does differ from the fp32 arithmetic in some pixels."""
+    from vface_amd import hip
+    from oracle import paste as op
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(2, 3, 64, 96, generator=g) * 0.9).half()
+    x[0, 0, 0, :8] = torch.tensor([-1.0, 1.0, -1.5, 1.5, 0.0, 1 / 255, -0.9999, 0.9999]).half()
+    got = hip.frame_to_u8(x.to(DEV), half_arithmetic=True).cpu().numpy()
+    xs = torch.clamp((x + 1.0) / 2.0, min=0.0, max=1.0).permute(0, 2, 3, 1).numpy()                # float16 all the way
+    assert xs.dtype == np.float16
+    ref = (255. * xs).astype(np.uint8)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(got, op.to_u8_half(op.clamp01_half(x.permute(0, 2, 3, 1).numpy())))
+    full = hip.frame_to_u8(x.to(DEV)).cpu().numpy()
+    d = np.abs(got.astype(int) - full.astype(int))
+    assert d.max() == 1 and 0 < (d > 0).mean() < 0.5
+    with pytest.raises(hip.VFaceHipError):
+        hip.frame_to_u8(x.float().to(DEV), half_arithmetic=True)
+
+
 @pytest.mark.parametrize("h,w,ow,oh", [(64, 64, 128, 128), (50, 70, 33, 91), (37, 41, 100, 17), (128, 96, 96, 128), (512, 512, 1024, 1024)])
 def test_resize_u8_is_pillows_bilinear_resize(h, w, ow, oh):
     from PIL import Image

@@ -31,14 +31,26 @@ template <>
 __device__ inline float ld_f32<float>(const float* p, long i) { return p[i]; }
 
 // x: planar [3][H][W] (one frame per blockIdx.y, frame stride 3 H W) in [-1, 1]; out: [H][W][3] uint8
-template <class T>
+// H16: the arithmetic of the reference's DEFAULT `--precision autocast` run -- decode_first_stage hands back float16, so `x + 1.0`,
+// `/ 2.0` (torch, one rounding to float16 each) and numpy's `255. * x` on the float16 array all round to float16 before the
+// truncation; near 255 the float16 spacing is 0.125, so a pixel can differ by one from the fp32 arithmetic of `--precision full`.
+template <class T, bool H16 = false>
 __global__ __launch_bounds__(256) void frame_to_u8_kernel(const T* __restrict__ x, unsigned char* __restrict__ out, int hw) {
 #pragma clang fp contract(off)
     const long fb = (long)blockIdx.y * 3 * hw;
     for (int p = blockIdx.x * 256 + threadIdx.x; p < hw; p += gridDim.x * 256) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float v = (ld_f32(x, fb + (long)c * hw + p) + 1.0f) / 2.0f;
+            float v;
+            if constexpr (H16) {
+                auto r16 = [](float f) { return (float)(_Float16)f; };
+                v = r16(r16(ld_f32(x, fb + (long)c * hw + p) + 1.0f) / 2.0f);
+                v = fminf(fmaxf(v, 0.0f), 1.0f);
+                v = r16(255.0f * v);
+                out[fb + (long)p * 3 + c] = (unsigned char)(int)v;
+                continue;
+            }
+            v = (ld_f32(x, fb + (long)c * hw + p) + 1.0f) / 2.0f;
             v = fminf(fmaxf(v, 0.0f), 1.0f);                    // (torch.clamp: NaN stays NaN there; a NaN frame is already lost)
             out[fb + (long)p * 3 + c] = (unsigned char)(int)(255.0f * v);
         }
@@ -153,6 +165,7 @@ int vf_launch_frame_to_u8(const void* x, unsigned char* out, int frames, int H, 
     if (in_kind == 2) hipLaunchKernelGGL(frame_to_u8_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, out, H * W);
     else if (in_kind == 0) hipLaunchKernelGGL((frame_to_u8_kernel<F16::elem>), grid, dim3(256), 0, stream, (const F16::elem*)x, out, H * W);
     else if (in_kind == 1) hipLaunchKernelGGL((frame_to_u8_kernel<BF16::elem>), grid, dim3(256), 0, stream, (const BF16::elem*)x, out, H * W);
+    else if (in_kind == 3) hipLaunchKernelGGL((frame_to_u8_kernel<F16::elem, true>), grid, dim3(256), 0, stream, (const F16::elem*)x, out, H * W);
     else return VF_ERR_ARG;
     return ok();
 }

@@ -399,12 +399,17 @@ def convex_upsample(mask32: torch.Tensor, flow32: torch.Tensor, *, B: int, h: in
     return out
 
 
-def frame_to_u8(x: torch.Tensor) -> torch.Tensor:
-    """Decoded frames [F, 3, H, W] in [-1, 1] (fp16 / bf16 / fp32) -> uint8 [F, H, W, 3]: clamp((x + 1) / 2, 0, 1) * 255, truncated."""
+def frame_to_u8(x: torch.Tensor, half_arithmetic: bool = False) -> torch.Tensor:
+    """Decoded frames [F, 3, H, W] in [-1, 1] (fp16 / bf16 / fp32) -> uint8 [F, H, W, 3]: clamp((x + 1) / 2, 0, 1) * 255, truncated.
+    The arithmetic is **fp32** whatever the input type -- the reference's ``--precision full`` run.  ``half_arithmetic=True`` (fp16
+    input only) rounds every operation to float16 instead, which is what the reference's default ``--precision autocast`` run
+    computes on the float16 tensor ``decode_first_stage`` returns (:597-608); the two can differ by one in a pixel."""
     if x.dim() != 4 or x.shape[1] != 3:
         raise VFaceHipError(f"frame_to_u8: frames must be [F, 3, H, W]; got {tuple(x.shape)}")
     x = x.contiguous()
-    kind = 2 if x.dtype == torch.float32 else dtype_code(x.dtype)
+    if half_arithmetic and x.dtype != torch.float16:
+        raise VFaceHipError("frame_to_u8(half_arithmetic=True) takes float16 frames (the autocast path's decode output)")
+    kind = 3 if half_arithmetic else (2 if x.dtype == torch.float32 else dtype_code(x.dtype))
     F_, _, H, W = x.shape
     out = torch.empty(F_, H, W, 3, dtype=torch.uint8, device=x.device)
     _check(load().vface_frame_to_u8(_p(x), _p(out), F_, H, W, kind, _stream()), "vface_frame_to_u8")

@@ -330,7 +330,9 @@ def run_synthetic(opt) -> dict:
                 raise SystemExit("--paste_back pastes decoded pixels: it needs --with_vae")
             from .paste_back import PasteBack
             if paster is None:
-                paster = PasteBack(H=opt.H, W=opt.W, device=dev, encode_decode=PasteBack.vae_round_trip(model))
+                # (--precision autocast, the reference's default: its decoded tensor is float16 and :597-608 quantise in float16)
+                paster = PasteBack(H=opt.H, W=opt.W, device=dev, encode_decode=PasteBack.vae_round_trip(model),
+                                   half_arithmetic=opt.precision == "autocast")
             S_ = opt.frame_size
             gen = torch.Generator().manual_seed(opt.seed + 1000 + batch_id)
             frames = torch.randint(0, 256, (F_, S_, S_, 3), dtype=torch.uint8, generator=gen).to(dev)

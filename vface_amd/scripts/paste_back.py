@@ -64,11 +64,14 @@ def resample_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray
 class PasteBack:
     """Batch paste-back on one device.  ``encode_decode`` is the background round trip of :615-617 -- a callable
     ``[F, 3, H, W] fp32 in [-1, 1] -> decoded [F, 3, H, W]`` (``PasteBack.vae_round_trip(model)`` builds it from a
-    ``LatentDiffusion`` with a first stage); ``None`` pastes over the untouched original frame instead (no VAE built)."""
+    ``LatentDiffusion`` with a first stage); ``None`` pastes over the untouched original frame instead (no VAE built).
+    ``half_arithmetic``: quantise float16 decoder outputs with float16 arithmetic, as the reference's default
+    ``--precision autocast`` run does (``hip.frame_to_u8``); the default is the fp32 arithmetic of ``--precision full``."""
 
     def __init__(self, H: int = 512, W: int = 512, canvas: int = 1024, device="cuda:0",
-                 encode_decode: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+                 encode_decode: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, half_arithmetic: bool = False):
         self.H, self.W, self.canvas = H, W, canvas
+        self.half_arithmetic = half_arithmetic
         self.device = torch.device(device)
         self.encode_decode = encode_decode
         self._tables: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -99,7 +102,10 @@ class PasteBack:
 
     def swapped_canvas(self, x_samples: torch.Tensor) -> torch.Tensor:
         """Decoded crops [F, 3, H, W] in [-1, 1] -> the 1024 x 1024 uint8 images the reference saves and projects (:597-608)."""
-        return self.resize_u8(hip.frame_to_u8(x_samples), self.canvas, self.canvas)
+        return self.resize_u8(self._to_u8(x_samples), self.canvas, self.canvas)
+
+    def _to_u8(self, x: torch.Tensor) -> torch.Tensor:
+        return hip.frame_to_u8(x, half_arithmetic=self.half_arithmetic and x.dtype == torch.float16)
 
     def background(self, frames_u8: torch.Tensor) -> torch.Tensor:
         """The frame the crop is pasted over: the original after the encode / decode round trip "to get the consistent output for
@@ -111,7 +117,7 @@ class PasteBack:
             return frames_u8.clone()
         x = hip.frame_normalise_resize(frames_u8, self.H, self.W)
         rec = self.encode_decode(x)
-        out = self.resize_u8(hip.frame_to_u8(rec), Ho, Wo)      # (width, height) := (orig height, orig width), :623
+        out = self.resize_u8(self._to_u8(rec), Ho, Wo)      # (width, height) := (orig height, orig width), :623
         if tuple(out.shape[1:3]) != (Ho, Wo):
             raise ValueError("images do not match")
         return out
