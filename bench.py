@@ -116,6 +116,7 @@ class FamilyTimer:
                  `attn_out_ffn_fused` = the same kernel with attn1's out-projection, attn2's row bias and the residual in front;
                  `attn_out_ffn_proj_fused` = ... and the SpatialTransformer's proj_out + input residual + column statistics behind;
                  `st_front` = st_front_kernel (stfront.hip): GroupNorm-apply + proj_in + LayerNorm + attn1 projection of a level-0 block;
+                 `linear_small` = linear_small_kernel: the time-embedding chain on 3F rows;
       attention  attn_kernel<T, DH, ..> by head dim; FLOPs = the ALGORITHMIC 4 n nk dh per (output sample, head) --
                  the shared-score form executes fewer;
       norm       layernorm / groupnorm apply+finalize: HBM-bound, reported in GB/s of algorithmic bytes."""
@@ -204,6 +205,15 @@ class FamilyTimer:
                 return call()
             timer._timed("gemm", "attn_out_ffn_fused", 26.0 * M * C_ * C_, 1, call)
         hip.attn_out_ffn_fused = attn_out_ffn_fused
+        orig_ls = hip.linear_small
+
+        def linear_small(a, wt, bias, out, *, M, N, K, **kw):
+            # the time-embedding chain's few-row Linear layers (linear_small.hip); FLOPs 2 M N K as executed
+            call = lambda: orig_ls(a, wt, bias, out, M=M, N=N, K=K, **kw)
+            if not timer.on:
+                return call()
+            timer._timed("gemm", "linear_small", 2.0 * M * N * K, 1, call)
+        hip.linear_small = linear_small
         orig_tailp = hip.attn_out_ffn_proj_fused
 
         def attn_out_ffn_proj_fused(att, resid32, rowbias, w_stream, bo, gamma, beta, b1, w2p, b2, b_po, x_in, out16, out32, colstats, *,

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VFACE_ABI_VERSION 5   /* 5: + vface_st_front, vface_attn_out_ffn_fused, vface_attn_out_ffn_proj_fused, vface_gn_silu_conv3x3_small; vface_attention's v_sets carries the live-set count in bits 8..15, vface_pack_unet_input / vface_ddim_step take the two-branch batch; nothing else of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
+#define VFACE_ABI_VERSION 5   /* 5: + vface_st_front, vface_attn_out_ffn_fused, vface_attn_out_ffn_proj_fused, vface_gn_silu_conv3x3_small, vface_linear_small; vface_attention's v_sets carries the live-set count in bits 8..15, vface_pack_unet_input / vface_ddim_step take the two-branch batch; nothing else of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
 
 #define VFACE_OK 0
 #define VFACE_ERR_ARG (-1)
@@ -360,6 +360,16 @@ int vface_attn_out_ffn_proj_fused(const void* att, int64_t ldatt, const float* r
  * 128-wide tile is 97 % padding at four output channels. */
 int vface_gn_silu_conv3x3_small(const void* x, int64_t ldx, int in_f32, const float* gn_ab, int64_t ld_ab, const void* Wt, const float* bias,
                                 float* out, int64_t ldo, int nimg, int H, int W, int Cin, int Cout, int dtype, void* stream);
+
+/* Linear layers on a handful of rows -- the time-embedding chain (openaimodel.py:874-875 `emb = self.time_embed(timestep_embedding(t))`,
+ * :264-271 `emb_layers(emb)` = Linear(SiLU(emb)) of every ResBlock as one matrix; util.py:151-171):
+ *   out[m][n] = act( sum_k a[m][k] W[n][k] + bias[n] ),  M <= 96, N % 32 == 0, K in {320, 640, 1280}
+ * a: [M][lda] 16-bit; act = SiLU when `silu`; out 16-bit, or fp32 when `out_f32`.  Replaces three vface_gemm + two vface_silu
+ * launches of a forward (a 128-row GEMM tile is 81 % padding at M = 24) by three; the SiLU now acts on the fp32 sum (one rounding
+ * instead of two). */
+int vface_linear_small_supported(int M, int N, int K);
+int vface_linear_small(const void* a, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out,
+                       int64_t ldo, int out_f32, int silu, int M, int N, int K, int dtype, void* stream);
 
 /* Fused FRONT of a SpatialTransformer (attention.py:278-284 norm -> proj_in -> tokens; :239 norm1; :179-183 to_q / to_k / to_v of
  * attn1), one launch for GroupNorm-apply + proj_in + LayerNorm + the attn1 projection on token matrices with C in {64, 128, 320}:

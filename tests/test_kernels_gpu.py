@@ -362,6 +362,35 @@ def test_flow_warp_align_matches_oracle_with_halo():
     assert (got - tok(ref[1:]).float()).abs().max() <= 2e-3
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,silu,f32", [(24, 1280, 1280, True, False), (24, 20160, 1280, False, True), (48, 1280, 640, True, False),
+                                            (96, 640, 320, False, True), (5, 64, 320, True, True), (33, 96, 1280, False, False)])
+def test_linear_small_vs_torch_and_vs_gemm(dt, M, N, K, silu, f32):
+    """csrc/linear_small.hip (``vface_linear_small``): Linear (+ SiLU) on a handful of rows -- the time-embedding chain
+    (openaimodel.py:874-875, 264-271) -- against fp64 torch on the same 16-bit operands and against vface_gemm (+ vface_silu);
+    ragged row counts, up to three row tiles, outputs into a column slice of a wider buffer."""
+    h = hip()
+    a, w, b = rnd((M, K), 61, dt, 1.0), rnd((N, K), 62, dt, K ** -0.5), rnd((N,), 63, torch.float32, 0.3)
+    odt = torch.float32 if f32 else dt
+    out = torch.full((M + 3, N + 8), 7.0, dtype=odt, device=DEV)
+    h.linear_small(a.to(DEV), w.to(DEV), b.to(DEV), out[:M, :N], M=M, N=N, K=K, silu=silu)
+    ref = a.double() @ w.double().t() + b.double()
+    if silu:
+        ref = F.silu(ref)
+    got = out[:M, :N].cpu().double()
+    assert rel_l2(got, ref) < (2e-6 if f32 else TOL[dt])
+    assert bool((out[M:] == 7.0).all()) and bool((out[:, N:] == 7.0).all())
+    # the launches it replaces: the tiled GEMM (fp32 out), then SiLU
+    g = torch.zeros(M, N, dtype=torch.float32, device=DEV)
+    h.gemm(a.to(DEV), w.to(DEV), g, M=M, N=N, K=K, lda=K, ldc=N, bias=b.to(DEV), flags=h.EPI_OUT_F32)
+    g = F.silu(g) if silu else g
+    assert rel_l2(got, g.cpu().double()) < (2e-6 if f32 else TOL[dt])
+    assert h.linear_small_supported(M, N, K) and not h.linear_small_supported(97, N, K) and not h.linear_small_supported(M, N + 8, K) \
+        and not h.linear_small_supported(M, N, 512)
+    with pytest.raises(h.VFaceHipError):
+        h.linear_small(a.to(DEV), w.to(DEV), b.to(DEV), out[:M, :N], M=97, N=N, K=K)
+
+
 def test_timestep_embedding_pack_and_ddim():
     h = hip()
     from oracle import ddim as oddim

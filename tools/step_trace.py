@@ -58,7 +58,7 @@ def main():
         return img
 
     names = ["gemm", "conv3x3", "conv3x3_plus_1x1", "upsample2x_conv3x3", "attention", "layernorm", "groupnorm_apply",
-             "groupnorm_stats_from_cols", "groupnorm_stats", "ffn_fused", "attn_out_ffn_fused", "attn_out_ffn_proj_fused", "st_front", "gn_silu_conv3x3_small", "flow_warp", "silu", "cast_f32", "timestep_embedding",
+             "groupnorm_stats_from_cols", "groupnorm_stats", "ffn_fused", "attn_out_ffn_fused", "attn_out_ffn_proj_fused", "st_front", "gn_silu_conv3x3_small", "linear_small", "flow_warp", "silu", "cast_f32", "timestep_embedding",
              "pack_unet_input", "ddim_step", "groupnorm_coeffs_from_cols", "nchw_to_nhwc", "nhwc_to_nchw_f32", "copy2d"]
     rec, on = [], [False]
 

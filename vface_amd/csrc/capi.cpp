@@ -399,6 +399,16 @@ int vface_gn_silu_conv3x3_small(const void* x, int64_t ldx, int in_f32, const fl
     return vf_launch_out_conv(p, dtype, S(stream));
 }
 
+int vface_linear_small_supported(int M, int N, int K) { return vf_linear_small_supported(M, N, K) ? 1 : 0; }
+
+int vface_linear_small(const void* a, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out,
+                       int64_t ldo, int out_f32, int silu, int M, int N, int K, int dtype, void* stream) {
+    LinearSmallParams p{};
+    p.a = a; p.lda = lda; p.W = W; p.ldw = ldw; p.bias = bias; p.out = out;
+    p.ldo = ldo; p.out_f32 = out_f32; p.silu = silu; p.M = M; p.N = N; p.K = K;
+    return vf_launch_linear_small(p, dtype, S(stream));
+}
+
 int vface_st_front_supported(int64_t M, int C, int hw) { return vf_st_front_supported((long)M, C, hw) ? 1 : 0; }
 
 int vface_st_front(const float* x32, int64_t ldx, const float* gn_ab, int64_t ld_ab, int hw, const void* Wcat, const float* b_in,

@@ -113,6 +113,18 @@ struct FfnParams {
 bool vf_ffn_fused_supported(long M, int C);
 int vf_launch_ffn_fused(const FfnParams& p, int dtype, hipStream_t stream);
 
+// linear_small.hip: out[M][N] = act(a[M][K] W[N][K]^T + bias) on M <= 96 rows (the time-embedding chain)
+struct LinearSmallParams {
+    const void* a; long lda;         // [M][K] 16-bit
+    const void* W; long ldw;         // [N][K] 16-bit
+    const float* bias;               // [N] or null
+    void* out; long ldo; int out_f32;
+    int silu;
+    int M, N, K;
+};
+bool vf_linear_small_supported(int M, int N, int K);
+int vf_launch_linear_small(const LinearSmallParams& p, int dtype, hipStream_t stream);
+
 // stfront.hip: GroupNorm-apply -> proj_in -> (t0 out) -> LayerNorm -> attn1 projection, one launch; C in {64, 128, 320}
 struct StFrontParams {
     const float* x32; long ldx;      // [M][C] fp32: the SpatialTransformer's input (residual-stream carrier)

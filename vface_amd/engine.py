@@ -400,6 +400,8 @@ class UNetEngine:
         self.fuse_tail = os.environ.get("VFACE_FUSE_TAIL", "1") != "0"
         # ... and the SpatialTransformer's proj_out + x_in + column statistics behind it, still one launch (ffn.hip POST form)
         self.fuse_post = os.environ.get("VFACE_FUSE_POST", "1") != "0"
+        # the time-embedding chain (timestep embedding, time_embed, every ResBlock's emb_layers) as three few-row launches
+        self.fuse_temb = os.environ.get("VFACE_FUSE_TEMB", "1") != "0"
         # the UNet's `out` layer (GroupNorm -> SiLU -> conv3x3 to 4 channels) as one launch (csrc/outconv.hip).  VFACE_FUSE_OUT=0: A/B
         self.fuse_out = os.environ.get("VFACE_FUSE_OUT", "1") != "0"
         self._front_supported: Dict[tuple, bool] = {}
@@ -998,6 +1000,18 @@ class UNetEngine:
         ``to_out(to_v(ctx))``, as fp32 row-bias matrices."""
         P, N = self._packed, timesteps.shape[0]
         mc = self.unet.model_channels
+        if self.fuse_temb and hip.linear_small_supported(N, 4 * mc, mc) and hip.linear_small_supported(N, P["emb_all"]["n"], 4 * mc):
+            # three launches of the few-row kernel (csrc/linear_small.hip) instead of three GEMMs + two SiLUs; each SiLU acts on its
+            # layer's fp32 sum
+            temb = self._new(N, mc)
+            hip.timestep_embedding(timesteps.to(device=self.device, dtype=torch.int64).contiguous(), temb, mc)
+            e0 = self._new(N, 4 * mc)
+            hip.linear_small(temb, P["time_embed.0"]["w"], P["time_embed.0"]["b"], e0, M=N, N=4 * mc, K=mc, silu=True)
+            emb = self._new(N, 4 * mc)
+            hip.linear_small(e0, P["time_embed.2"]["w"], P["time_embed.2"]["b"], emb, M=N, N=4 * mc, K=4 * mc, silu=True)
+            emb_all = self._new(N, P["emb_all"]["n"], torch.float32)
+            hip.linear_small(emb, P["emb_all"]["w"], P["emb_all"].get("b"), emb_all, M=N, N=P["emb_all"]["n"], K=4 * mc)
+            return emb_all, self.context_projections(context, N)
         temb = self._new(N, mc)
         hip.timestep_embedding(timesteps.to(device=self.device, dtype=torch.int64).contiguous(), temb, mc)
         e0 = self._new(N, 4 * mc)
@@ -1151,7 +1165,7 @@ class UNetEngine:
                                              None if self.halo_flow is None else tuple(self.halo_flow.shape))
         # (every switch that changes the captured launch sequence is part of the key: toggling one on a live engine must not
         # replay a stale graph)
-        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.fuse_post, self.fuse_out, self.live_chunks,
+        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.fuse_post, self.fuse_temb, self.fuse_out, self.live_chunks,
                self.decompose_attn1, self.exchange_events is not None, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)

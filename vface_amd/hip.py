@@ -90,6 +90,8 @@ SIGNATURES = {
                                            _i64, _i32, _i32, _i32, _vp]),
     "vface_attn_out_ffn_proj_fused": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _vp, _vp, _vp, _vp,
                                                 _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "vface_linear_small_supported": (C.c_int, [_i32, _i32, _i32]),
+    "vface_linear_small": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vface_gn_silu_conv3x3_small": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "vface_st_front_supported": (C.c_int, [_i64, _i32, _i32]),
     "vface_st_front": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _f32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32,
@@ -515,6 +517,19 @@ def attn_out_ffn_proj_fused(att: torch.Tensor, resid32: torch.Tensor, rowbias: O
         _p(out16), out16.stride(0) if out16 is not None else 0, _p(out32), out32.stride(0) if out32 is not None else 0,
         _p(colstats), colstats.stride(0) // 2 if colstats is not None else 0, M, C_, dtype_code(att.dtype), _stream())
     _check(rc, "vface_attn_out_ffn_proj_fused")
+
+
+def linear_small_supported(M: int, N: int, K: int) -> bool:
+    return bool(load().vface_linear_small_supported(M, N, K))
+
+
+def linear_small(a: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *, M: int, N: int, K: int,
+                 silu: bool = False):
+    """``out[:M, :N] = act(a[:M, :K] @ wt[:N, :K]^T + bias)`` on a handful of rows (``vface_linear_small``: the time-embedding chain);
+    ``out``: 16-bit or fp32."""
+    rc = load().vface_linear_small(_p(a), a.stride(0), _p(wt), wt.stride(0), _p(bias), _p(out),
+                                   out.stride(0), int(out.dtype == torch.float32), int(silu), M, N, K, dtype_code(wt.dtype), _stream())
+    _check(rc, "vface_linear_small")
 
 
 def gn_silu_conv3x3_small(x: torch.Tensor, gn_ab: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, *,
