@@ -193,15 +193,34 @@ def zeros_page(device) -> torch.Tensor:
 
 
 _splitk_ws = {}
+_ws_domain = 0
+
+
+class workspace_domain:
+    """``with hip.workspace_domain(k):`` -- launches inside take split-K scratch number k.  Launches on ONE stream use a scratch in
+    order; a caller that runs two launch sequences on two streams at once (the engine's two half-batches) gives each its own."""
+
+    def __init__(self, k: int):
+        self.k = int(k)
+
+    def __enter__(self):
+        global _ws_domain
+        self.prev, _ws_domain = _ws_domain, self.k
+        return self
+
+    def __exit__(self, *exc):
+        global _ws_domain
+        _ws_domain = self.prev
+        return False
 
 
 def splitk_workspace(device, M: int, N: int, K: int, flags: int = 0, rows_per_sample: int = 1):
-    """Device scratch for a split-K launch of this shape (grown on demand, one per device; launches on one stream
-    use it in order).  Returns (tensor | None, bytes)."""
+    """Device scratch for a split-K launch of this shape (grown on demand, one per device and workspace domain; launches on
+    one stream use it in order).  Returns (tensor | None, bytes)."""
     need = load().vface_splitk_workspace_bytes(M, N, K, flags, rows_per_sample)
     if need <= 0:
         return None, 0
-    key = str(device)
+    key = str(device) if _ws_domain == 0 else f"{device}#{_ws_domain}"
     ws = _splitk_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=device)
