@@ -450,6 +450,7 @@ def main():
         sampler.hook_plan = HookPlan(fusion=fusion, enabled=fusion != "none")
         sampler.drop_dead_branches = bool(drop)     # (extras only: the headline always runs the full 3F batch)
         eng.use_graph, eng._graphs, eng._graph_failed = bool(graph), {}, set()
+        eng._split_state = {}
         eng.decompose_attn1 = bool(instrument)
         shard = FrameShard(rank, world, F_ * world, dist, mode=a.exchange)
         g0 = shard.first  # global index of this rank's first frame
@@ -529,8 +530,12 @@ def main():
             tt = torch.tensor([el], device="cpu" if rehearse else dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
+        two = graphed and nseg <= 1 and any(k[0] != "plan" and "streams" in v for k, v in eng._split_state.items() if isinstance(v, dict))
         launch = ("kernel by kernel" if not graphed else
-                  ("hipGraph replay of the UNet forward of each step (UNetEngine.step_forward_nhwc)" if nseg <= 1 else
+                  ("hipGraph replay of the UNet forward of each step (UNetEngine.step_forward_nhwc)" +
+                   (": the frames of the batch as two halves (every chunk's frames [0, F/2) and [F/2, F)), each half its own graph, on two "
+                    "HIP streams at once, joined every step (engine._step_forward_split; bit-identical to the single launch sequence)" if two else "")
+                   if nseg <= 1 else
                    f"hipGraph replay in {nseg} segments cut at the halo exchanges, the RCCL send / recv / wait calls issued from the host "
                    "between them (engine._GraphSegments)"))
         eng.exchange_events = None

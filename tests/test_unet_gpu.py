@@ -517,6 +517,66 @@ def test_hipgraph_replay_equals_kernel_by_kernel_launches(small):
         sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
 
 
+@pytest.mark.parametrize("fusion", ["replace", "fft", "mix", "none"])
+def test_two_launch_streams_equal_one(small, fusion):
+    """The graph-replayed forward as two frame halves on two HIP streams (UNetEngine._step_forward_split, the default when no hook
+    mode couples frames) gives the bits of the single launch sequence -- sampling (batch 3F), with the dead branches dropped (2F),
+    inversion (2F, unhooked); the cross-frame modes stay whole."""
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import HookPlan
+    ldm, sampler, sd = small
+    eng = ldm.unet.engine
+    F_, h, w = 4, 32, 32
+    d = lambda v: v.to(DEV)
+    x_T = d(synth.synth_normal("two.xT", (F_, 4, h, w)))
+    c, uc, tc = (d(synth.synth_normal(f"two.{k}", (F_, 1, 768))) for k in ("c", "uc", "tc"))
+    inp = d(synth.synth_normal("two.inpaint", (F_, 4, h, w)) * 0.18215)
+    mask = d(synth.synth_mask(F_, h, w))
+    inv = {int(s): d(synth.synth_normal(f"two.inv.{int(s)}", (F_, 4, h, w))) for s in oddim.ddim_timesteps(50)}
+
+    def run(drop):
+        sampler.drop_dead_branches = drop
+        img, _ = sampler.sample(S=50, batch_size=F_, shape=[4, h, w], conditioning=c, target_conditioning=tc,
+                                inverse_results_dir=inv, verbose=False, unconditional_guidance_scale=3.0,
+                                unconditional_conditioning=uc, eta=0.0, x_T=x_T, flow=None,
+                                test_model_kwargs={"inpaint_image": inp, "inpaint_mask": mask}, max_steps=3)
+        return img.clone()
+
+    def invert():
+        x0 = d(synth.synth_normal("two.z2", (2 * F_, 4, h, w)))
+        xn, _ = sampler.ddim_invert(x=x0, cond=torch.cat([tc, c], 0), S=50, shape=[4, h, w], inverse_dir={}, batch_size=F_,
+                                    test_model_kwargs={"inpaint_image": torch.cat([inp] * 2), "inpaint_mask": torch.cat([mask] * 2)},
+                                    max_steps=2)
+        return xn.clone()
+
+    old = sampler.hook_plan, eng.use_graph, eng._graphs, eng.split_streams, sampler.drop_dead_branches
+    try:
+        sampler.hook_plan = HookPlan(fusion=fusion, enabled=fusion != "none")
+        res = {}
+        for streams in (1, 2):
+            eng.use_graph, eng._graphs, eng._split_state, eng.split_streams = True, {}, {}, streams
+            res[streams] = (run(False), run(True), invert())
+            assert not eng._graph_failed
+            split = [k for k in eng._split_state if k[0] != "plan"]
+            assert (len(split) > 0) == (streams == 2), "the halves must actually have run on their own streams"
+        for a_, b_ in zip(res[1], res[2]):
+            assert torch.equal(a_, b_)
+        # a hook mode that reads the neighbouring frame keeps the batch whole
+        sampler.hook_plan = HookPlan(fusion="flow_fix")
+        sampler._register_step_hooks([synth.synth_flow(F_ - 1, h, w)[i][None].to(DEV) for i in range(F_ - 1)])
+        assert eng._split_plan(3 * F_) is None
+        sampler.hook_plan = HookPlan(fusion="temporal")
+        sampler._register_step_hooks(None)
+        assert eng._split_plan(3 * F_) is None
+        eng.split_streams = 2
+        sampler.hook_plan = HookPlan(fusion="replace")
+        sampler._register_step_hooks(None)
+        assert eng._split_plan(3 * F_) is not None and eng._split_plan(3 * 3) is None and eng._split_plan(6) is None
+    finally:
+        sampler.hook_plan, eng.use_graph, eng._graphs, eng.split_streams, sampler.drop_dead_branches = old
+        eng._split_state = {}
+        sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
+
+
 def test_config1_single_frame_256x256_twenty_steps_vs_oracle(small):
     """BASELINE configs[0] (the reference's own CPU-runnable case): ONE 256 x 256 frame (32 x 32 latent), the whole 20-step DDIM
     loop with the shipped hook schedule -- a clip of one frame has no flow field and no neighbour, every hook degenerates to

@@ -430,8 +430,16 @@ class UNetEngine:
         self.use_graph = os.environ.get("VFACE_GRAPH", "1") != "0"
         self._graphs: "Dict[tuple, dict]" = {}
         self._graph_failed: set = set()       # keys whose capture failed: they run kernel by kernel, other keys still capture
-        self.graph_capacity = 4
+        self.graph_capacity = 8
         self.graph_budget_bytes = int(float(os.environ.get("VFACE_GRAPH_GB", "64")) * (1 << 30))
+        # Two launch streams (VFACE_STREAMS=2, the default; 1 = one stream): a graph-replayed forward whose frames are not coupled
+        # across the split (no hook, or replace / fft / mix: every edit stays inside a frame's own chunks) runs as two half-batches
+        # -- frames [0, F/2) and [F/2, F) of every chunk -- on two HIP streams at once.  The kernels that own a whole CU per
+        # workgroup run their HBM phases in lock-step across the chip; two independent launch sequences put one
+        # half's HBM-bound launches beside the other's matrix-bound ones.  Every kernel is batch-invariant, so the halves' results
+        # are the full batch's bit for bit (tests); measured 1-4.5 % per step depending on the box (profiles/r04_n).
+        self.split_streams = int(os.environ.get("VFACE_STREAMS", "2"))
+        self._split_state: "Dict[tuple, dict]" = {}
         hip.load()
 
     # ------------------------------------------------------------------ weights
@@ -1142,7 +1150,86 @@ class UNetEngine:
                         (fi, tuple(fl.shape)) if fl is not None else None))
         return tuple(sig), flows
 
+    _SPLIT_SAFE = ("replace", "fft", "fft_vfixed", "mix")      # hook modes that never read another FRAME (pnp_utils.py:133-262)
+
+    def _split_plan(self, N: int):
+        """Index tensors of the two frame halves of an N-sample batch (frames [0, F/2) and [F/2, F) of every chunk), or None when
+        this forward has to stay whole: one stream asked for, frames sharded over ranks, a hook mode that couples frames
+        (flow_fix's warp, temporal, adaIn), an odd frame count, or a batch too small to be worth two launch sequences."""
+        if self.split_streams < 2 or self.halo_exchange is not None or N < 8:
+            return None
+        chunks = 1
+        for kind, _, mod in self.unet.layer_table():
+            if kind != "st":
+                continue
+            cfg = getattr(mod.transformer_blocks[0].attn1, "_vface_cfg", None)
+            if cfg is None or not cfg.switch_on or cfg.chunks not in (2, 3):
+                continue
+            if cfg.chunks == 3 and cfg.fusion not in self._SPLIT_SAFE:
+                return None
+            there = cfg.chunks if self.live_chunks is None else self.live_chunks
+            if chunks not in (1, there):
+                return None
+            chunks = there
+        if N % chunks or (N // chunks) % 2:
+            return None
+        key = (N, chunks)
+        plan = self._split_state.get(("plan",) + key)
+        if plan is None:
+            F_ = N // chunks
+            plan = [torch.tensor([c * F_ + f for c in range(chunks) for f in range(lo, hi)], dtype=torch.int64, device=self.device)
+                    for lo, hi in ((0, F_ // 2), (F_ // 2, F_))]
+            self._split_state[("plan",) + key] = plan
+        return plan
+
+    def _step_forward_split(self, x: Act, timesteps: torch.Tensor, context: torch.Tensor, plan) -> torch.Tensor:
+        """The two halves of ``plan`` through ``_step_forward_one`` on two side streams at once (each with its own hipGraph and its
+        own split-K scratch), joined on the calling stream; returns the full batch's eps."""
+        N, hw, C = x.N, x.H * x.W, x.t.shape[1]
+        cur = torch.cuda.current_stream()
+        skey = (N, x.H, x.W, C, x.t.dtype, tuple(context.shape[1:]), cur.cuda_stream, len(plan[0]))
+        st = self._split_state.get(skey)
+        if st is None:
+            st = self._split_state[skey] = {
+                "streams": [torch.cuda.Stream(), torch.cuda.Stream()], "ctx_id": None, "ctx": None, "ctx_keep": None,
+                "x": [torch.empty(len(i) * hw, C, dtype=x.t.dtype, device=self.device) for i in plan],
+                "t": [torch.empty(len(i), dtype=torch.int64, device=self.device) for i in plan], "eps": None}
+        cid = (id(context), context._version)
+        if st["ctx_id"] != cid:
+            # (stable tensor objects per half: the graphs' and the eager path's context caches key on identity)
+            st["ctx"] = [context.index_select(0, i).contiguous() for i in plan]
+            st["ctx_id"], st["ctx_keep"] = cid, context
+        ts = timesteps.to(device=self.device, dtype=torch.int64)
+        xv = x.t.reshape(N, hw * C)
+        for h, idx in enumerate(plan):
+            torch.index_select(xv, 0, idx, out=st["x"][h].view(len(idx), hw * C))
+            torch.index_select(ts, 0, idx, out=st["t"][h])
+        outs = []
+        for h, idx in enumerate(plan):
+            s = st["streams"][h]
+            s.wait_stream(cur)
+            with torch.cuda.stream(s), hip.workspace_domain(h + 1):
+                outs.append(self._step_forward_one(Act(st["x"][h], len(idx), x.H, x.W), st["t"][h], st["ctx"][h]))
+        for s in st["streams"]:
+            cur.wait_stream(s)
+        if st["eps"] is None or st["eps"].shape[1] != outs[0].shape[1]:
+            st["eps"] = torch.empty(N * hw, outs[0].shape[1], dtype=outs[0].dtype, device=self.device)
+        ev = st["eps"].view(N, -1)
+        for idx, o in zip(plan, outs):
+            o.record_stream(cur)
+            ev.index_copy_(0, idx, o.reshape(len(idx), -1))
+        return st["eps"]
+
     def step_forward_nhwc(self, x: Act, timesteps: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
+        """``forward_nhwc`` for the DDIM loop; with two launch streams (``split_streams``) and a batch whose frames are not
+        coupled, the two frame halves through ``_step_forward_one`` at once."""
+        if self.use_graph and x.t32 is None and x.t.is_contiguous():
+            plan = self._split_plan(x.N)
+            if plan is not None:
+                return self._step_forward_split(x, timesteps, context, plan)
+        return self._step_forward_one(x, timesteps, context)
+
+    def _step_forward_one(self, x: Act, timesteps: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
         """``forward_nhwc`` for the DDIM loop: with ``use_graph`` the launch sequence of one forward is captured into a
         hipGraph the first time a (batch, resolution, hook configuration) combination is seen and replayed afterwards -- the
         same kernels on the same buffers, one host call per step instead of ~1200 (ddim_w_inv.py:299-305 calls the UNet once
@@ -1166,7 +1253,7 @@ class UNetEngine:
         # (every switch that changes the captured launch sequence is part of the key: toggling one on a live engine must not
         # replay a stale graph)
         key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.fuse_post, self.fuse_temb, self.fuse_out, self.live_chunks,
-               self.decompose_attn1, self.exchange_events is not None, sig,
+               hip._ws_domain, self.decompose_attn1, self.exchange_events is not None, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)
         if g is None:
