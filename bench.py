@@ -68,6 +68,9 @@ def parse(argv=None):
     ap.add_argument("--no-extras", action="store_true",
                     help="N = 1 only: skip the extra workloads (config 3: 32 frames + fft; shipped schedule: 16 frames + flow_fix)")
     ap.add_argument("--extra-steps", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=None, choices=[1, 2],
+                    help="launch sequences of a graph-replayed forward (default: the engine's, VFACE_STREAMS or 2: two frame halves on "
+                         "two HIP streams where no hook couples frames; 1 = one sequence, what the rocprofv3 summaries under profiles/ run)")
     ap.add_argument("--eager", action="store_true",
                     help="timed region launches kernel by kernel (default: the UNet forward of a step replayed from a hipGraph, "
                          "falling back to kernel-by-kernel launches by itself where a graph cannot be captured)")
@@ -431,6 +434,8 @@ def main():
     sampler.make_schedule(a.ddim_steps, ddim_eta=0.0, verbose=False)
     steps = [int(s) for s in sampler.ddim_timesteps[::-1]]
     eng = ldm.unet.engine
+    if a.streams is not None:
+        eng.split_streams = a.streams
     UNET_GFLOP = {64: 796.94, 96: 2137.52, 32: 176.34}   # BASELINE.md 2 / SURVEY 8d, per sample-forward, by latent size
 
     def fence():
@@ -678,6 +683,7 @@ def main():
                                    f"batch [uncond;cond;recon] = {3 * F_} samples per step",
                        "frames_per_gpu": F_, "latent": [h, h], "fusion": a.fusion,
                        "world_size": world, "backend": backend, "launch": launch_mode,
+                       "launch_streams": 2 if "two halves" in launch_mode else 1,
                        "unet_algorithmic_tflops_per_gpu": unet_tflops,
                        "unet_algorithmic_frac_of_mfma_peak": unet_tflops / MFMA_PEAK_TFLOPS if unet_tflops else None,
                        "host_enqueue_ms_per_step": r["enqueue_ms"],
@@ -701,8 +707,11 @@ def main():
             "extra": extras,
             "dead_branch_elimination": dead,
             "end_to_end": e2e,
-            "instrumented_pass": {"launch": "kernel by kernel, HIP events around every GEMM / convolution / attention / norm launch (what `roofline` "
-                                            "is computed from; vface_attn1_forward's launches issued call by call, bit-identical)",
+            "instrumented_pass": {"launch": "kernel by kernel, ONE launch sequence over the whole batch, HIP events around every GEMM / convolution / "
+                                            "attention / norm launch (what `roofline` is computed from; vface_attn1_forward's launches issued call "
+                                            "by call, bit-identical).  With launch_streams = 2 the timed region runs the same kernels as two "
+                                            "half-batch sequences at once: its step time is below this pass's sum of launch durations by what the "
+                                            "overlap wins (profiles/r04_n)",
                                   "ms_per_step": ri["ms_step"], "host_enqueue_ms_per_step": ri["enqueue_ms"], "steps": a.steps, "warmup": a.warmup,
                                   "event_covered_share": covered / step_ms_i if step_ms_i else None},
             # the kernel family with the largest share of the step's kernel time (by family the plain GEMM, not the
