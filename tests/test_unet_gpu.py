@@ -525,7 +525,7 @@ def test_two_launch_streams_equal_one(small, fusion):
     from vface_amd.ldm.models.diffusion.ddim_w_inv import HookPlan
     ldm, sampler, sd = small
     eng = ldm.unet.engine
-    F_, h, w = 4, 32, 32
+    F_, h, w = 6, 32, 32
     d = lambda v: v.to(DEV)
     x_T = d(synth.synth_normal("two.xT", (F_, 4, h, w)))
     c, uc, tc = (d(synth.synth_normal(f"two.{k}", (F_, 1, 768))) for k in ("c", "uc", "tc"))
@@ -570,7 +570,7 @@ def test_two_launch_streams_equal_one(small, fusion):
         eng.split_streams = 2
         sampler.hook_plan = HookPlan(fusion="replace")
         sampler._register_step_hooks(None)
-        assert eng._split_plan(3 * F_) is not None and eng._split_plan(3 * 3) is None and eng._split_plan(6) is None
+        assert eng._split_plan(3 * F_) is not None and eng._split_plan(3 * 5) is None and eng._split_plan(6) is None
     finally:
         sampler.hook_plan, eng.use_graph, eng._graphs, eng.split_streams, sampler.drop_dead_branches = old
         eng._split_state = {}

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--fusion", default="replace")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--sweep", action="store_true", help="the engine's own two-stream path (split_streams 1 vs 2) over batch sizes, "
+                                                         "unhooked and with the chosen fusion")
     a = ap.parse_args()
     from vface_amd import hip
     from vface_amd.engine import Act
@@ -57,6 +59,35 @@ def main():
                                            unconditional_guidance_scale=3.0, flow=None, unconditional_conditioning=uc, test_model_kwargs=kw)
     eng.step_forward_nhwc = orig
     xt, N, H, W, tsN, ctx = grabbed["args"]
+    if a.sweep:
+        def t_ms(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / a.iters
+        with torch.no_grad():
+            for hooked in (False, True):
+                sampler.hook_plan = HookPlan(fusion=a.fusion, enabled=hooked)
+                sampler._register_step_hooks(None)
+                for n in ((8, 12, 16, 24, 32, 48) if not hooked else (12, 24, 48)):
+                    rep = (n + N - 1) // N
+                    xs = xt.reshape(N, -1).repeat(rep, 1)[:n].reshape(n * H * W, -1).contiguous()
+                    tn, cn = tsN.repeat(rep)[:n].contiguous(), ctx.repeat(rep, 1, 1)[:n].contiguous()
+                    res = {}
+                    for streams in (1, 2):
+                        eng.split_streams, eng._graphs, eng._split_state = streams, {}, {}
+                        out = eng.step_forward_nhwc(Act(xs, n, H, W), tn, cn).clone()
+                        res[streams] = (t_ms(lambda: eng.step_forward_nhwc(Act(xs, n, H, W), tn, cn)), out, bool(eng._graph_failed),
+                                        any(k[0] != "plan" for k in eng._split_state))
+                    print(f"{'hooked ' + a.fusion if hooked else 'unhooked':16s} N={n:3d}: one sequence {res[1][0]:7.3f} ms   two streams {res[2][0]:7.3f} ms "
+                          f"({res[2][0] / res[1][0]:.3f})  split={res[2][3]} equal={torch.equal(res[1][1], res[2][1])} graph_failed={res[1][2] or res[2][2]}", flush=True)
+        return
     chunks = N // F_
     hw, C = H * W, xt.shape[1]
     def parts(k):

@@ -440,6 +440,7 @@ class UNetEngine:
         # are the full batch's bit for bit (tests); measured 1-4.5 % per step depending on the box (profiles/r04_n).
         self.split_streams = int(os.environ.get("VFACE_STREAMS", "2"))
         self._split_state: "Dict[tuple, dict]" = {}
+        self._split_pair = None
         hip.load()
 
     # ------------------------------------------------------------------ weights
@@ -1156,7 +1157,7 @@ class UNetEngine:
         """Index tensors of the two frame halves of an N-sample batch (frames [0, F/2) and [F/2, F) of every chunk), or None when
         this forward has to stay whole: one stream asked for, frames sharded over ranks, a hook mode that couples frames
         (flow_fix's warp, temporal, adaIn), an odd frame count, or a batch too small to be worth two launch sequences."""
-        if self.split_streams < 2 or self.halo_exchange is not None or N < 8:
+        if self.split_streams < 2 or self.halo_exchange is not None or N < 12:      # (8 samples: 11.75 vs 11.46 ms whole, profiles/r04_n)
             return None
         chunks = 1
         for kind, _, mod in self.unet.layer_table():
@@ -1190,8 +1191,13 @@ class UNetEngine:
         skey = (N, x.H, x.W, C, x.t.dtype, tuple(context.shape[1:]), cur.cuda_stream, len(plan[0]))
         st = self._split_state.get(skey)
         if st is None:
+            # ONE pair of side streams per engine, created back to back: HIP maps streams onto a few hardware queues round-robin
+            # in creation order, and two streams that land on the same queue run their launches one after the other (measured: a
+            # pair created later, for another configuration, shared a queue -- 24.2 instead of 16.3 ms per inversion step)
+            if self._split_pair is None:
+                self._split_pair = [torch.cuda.Stream(), torch.cuda.Stream()]
             st = self._split_state[skey] = {
-                "streams": [torch.cuda.Stream(), torch.cuda.Stream()], "ctx_id": None, "ctx": None, "ctx_keep": None,
+                "streams": self._split_pair, "ctx_id": None, "ctx": None, "ctx_keep": None,
                 "x": [torch.empty(len(i) * hw, C, dtype=x.t.dtype, device=self.device) for i in plan],
                 "t": [torch.empty(len(i), dtype=torch.int64, device=self.device) for i in plan], "eps": None}
         cid = (id(context), context._version)
