@@ -1183,6 +1183,34 @@ class UNetEngine:
             self._split_state[("plan",) + key] = plan
         return plan
 
+    def _concurrent_stream_pair(self):
+        """Two side streams whose launches really overlap: a spin kernel on each, timed together and alone -- a pair that shares a
+        hardware queue takes twice as long together and is replaced (three tries; then the pair is kept, and the halves simply run
+        one after the other on it)."""
+        pair = None
+        for _ in range(3):
+            pair = [torch.cuda.Stream(), torch.cuda.Stream()]
+            cur = torch.cuda.current_stream()
+            spin = 2_000_000        # ~1 ms
+
+            def timed(streams):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                for s in streams:
+                    s.wait_stream(cur)
+                    with torch.cuda.stream(s):
+                        torch.cuda._sleep(spin)
+                for s in streams:
+                    cur.wait_stream(s)
+                e1.record(cur)
+                e1.synchronize()
+                return e0.elapsed_time(e1)
+            timed(pair)
+            one, both = timed(pair[:1]), timed(pair)
+            if both < 1.5 * one:
+                break
+        return pair
+
     def _step_forward_split(self, x: Act, timesteps: torch.Tensor, context: torch.Tensor, plan) -> torch.Tensor:
         """The two halves of ``plan`` through ``_step_forward_one`` on two side streams at once (each with its own hipGraph and its
         own split-K scratch), joined on the calling stream; returns the full batch's eps."""
@@ -1195,7 +1223,7 @@ class UNetEngine:
             # in creation order, and two streams that land on the same queue run their launches one after the other (measured: a
             # pair created later, for another configuration, shared a queue -- 24.2 instead of 16.3 ms per inversion step)
             if self._split_pair is None:
-                self._split_pair = [torch.cuda.Stream(), torch.cuda.Stream()]
+                self._split_pair = self._concurrent_stream_pair()
             st = self._split_state[skey] = {
                 "streams": self._split_pair, "ctx_id": None, "ctx": None, "ctx_keep": None,
                 "x": [torch.empty(len(i) * hw, C, dtype=x.t.dtype, device=self.device) for i in plan],
