@@ -1191,7 +1191,7 @@ class UNetEngine:
         for _ in range(3):
             pair = [torch.cuda.Stream(), torch.cuda.Stream()]
             cur = torch.cuda.current_stream()
-            spin = 2_000_000        # ~1 ms
+            spin = 300_000          # 0.15 ms at core clock (3 ms if the counter is the 100 MHz timer): long against a launch, short once per engine
 
             def timed(streams):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
