@@ -684,6 +684,8 @@ def main():
                        "frames_per_gpu": F_, "latent": [h, h], "fusion": a.fusion,
                        "world_size": world, "backend": backend, "launch": launch_mode,
                        "launch_streams": 2 if "two halves" in launch_mode else 1,
+                       # step time / (half A + half B) of the engine's one measured split step: ~0.5 = the halves ran at once
+                       "launch_stream_overlap": eng.split_overlap,
                        "unet_algorithmic_tflops_per_gpu": unet_tflops,
                        "unet_algorithmic_frac_of_mfma_peak": unet_tflops / MFMA_PEAK_TFLOPS if unet_tflops else None,
                        "host_enqueue_ms_per_step": r["enqueue_ms"],

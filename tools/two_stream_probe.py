@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--fusion", default="replace")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--cut", type=int, default=0, help="also time an UNEVEN two-way split: frames [0, cut) and [cut, F)")
     ap.add_argument("--sweep", action="store_true", help="the engine's own two-stream path (split_streams 1 vs 2) over batch sizes, "
                                                          "unhooked and with the chosen fusion")
     a = ap.parse_args()
@@ -98,6 +99,13 @@ def main():
             out.append((Act(xs, len(idx), H, W), tsN.index_select(0, idx).contiguous(), ctx.index_select(0, idx).contiguous(), idx))
         return out
     halves = parts(2)
+    uneven = None
+    if a.cut:
+        uneven = []
+        for lo, hi in ((0, a.cut), (a.cut, F_)):
+            idx = torch.tensor([ch * F_ + f for ch in range(chunks) for f in range(lo, hi)], device=dev)
+            xs = xt.reshape(N, hw * C).index_select(0, idx).reshape(len(idx) * hw, C).contiguous()
+            uneven.append((Act(xs, len(idx), H, W), tsN.index_select(0, idx).contiguous(), ctx.index_select(0, idx).contiguous(), idx))
     quarters = parts(4) if F_ % 4 == 0 else None
     full = (Act(xt, N, H, W), tsN, ctx)
     s0 = torch.cuda.current_stream()
@@ -149,6 +157,22 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / a.iters
+    def spin_overlap(pair):
+        def timed(streams):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s0)
+            for s in streams:
+                s.wait_stream(s0)
+                with torch.cuda.stream(s):
+                    torch.cuda._sleep(300_000)
+            for s in streams:
+                s0.wait_stream(s)
+            e1.record(s0)
+            e1.synchronize()
+            return e0.elapsed_time(e1)
+        timed(pair)
+        return timed(pair) / timed(pair[:1])
+    print(f"spin kernels on the probe's first two streams: together / alone = {spin_overlap(ss[:2]):.2f} (1 = they overlap, 2 = one queue)", flush=True)
     with torch.no_grad():
         ref = run_full().clone()
         t_full = time_ms(run_full)
@@ -165,6 +189,10 @@ def main():
             ok_q = all(torch.equal(o, ref.reshape(N, -1).index_select(0, hv[3]).reshape(o.shape)) for o, hv in zip(qo, quarters))
             t_q = time_ms(lambda: run_par(quarters))
             t_qf = free_running(quarters)
+        if uneven is not None:
+            uo = [o.clone() for o in run_par(uneven)]
+            ok_u = all(torch.equal(o, ref.reshape(N, -1).index_select(0, hv[3]).reshape(o.shape)) for o, hv in zip(uo, uneven))
+            print(f"uneven split {a.cut}/{F_ - a.cut}: {time_ms(lambda: run_par(uneven)):.3f} ms (bit-identical: {ok_u})", flush=True)
         t_full2 = time_ms(run_full)
     print(f"F={F_} fusion={a.fusion}: full {t_full:.3f} / {t_full2:.3f} ms   halves_seq {t_seq:.3f} ms (bit-identical to full: {ok_seq})   "
           f"halves_par {t_par:.3f} ms (bit-identical: {ok_par})   halves free-running {t_free:.3f} ms   "

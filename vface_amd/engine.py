@@ -441,6 +441,8 @@ class UNetEngine:
         self.split_streams = int(os.environ.get("VFACE_STREAMS", "2"))
         self._split_state: "Dict[tuple, dict]" = {}
         self._split_pair = None
+        self._split_verified = False
+        self.split_overlap = None      # step time / (half A + half B) of the measured split step: ~0.5 = the halves ran at once
         hip.load()
 
     # ------------------------------------------------------------------ weights
@@ -1241,14 +1243,38 @@ class UNetEngine:
         for h, idx in enumerate(plan):
             torch.index_select(xv, 0, idx, out=st["x"][h].view(len(idx), hw * C))
             torch.index_select(ts, 0, idx, out=st["t"][h])
+        # Once per engine, on the second split step (graphs captured by the first), the overlap is MEASURED on the real work: events
+        # around each half and around the fork / join.  Halves that run at once each take about as long as the whole step
+        # (total / (t_A + t_B) ~ 0.5); halves that were put on one hardware queue run back to back (~ 1.0, and a half-batch
+        # sequence alone is 30 % less efficient than the full batch): then the engine goes back to one launch sequence for good.
+        st["calls"] = st.get("calls", 0) + 1
+        probe = (not self._split_verified) and st["calls"] == 2
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)] if probe else None
+        if probe:
+            ev[0].record(cur)
         outs = []
         for h, idx in enumerate(plan):
             s = st["streams"][h]
             s.wait_stream(cur)
             with torch.cuda.stream(s), hip.workspace_domain(h + 1):
+                if probe:
+                    ev[1 + 2 * h].record(s)
                 outs.append(self._step_forward_one(Act(st["x"][h], len(idx), x.H, x.W), st["t"][h], st["ctx"][h]))
+                if probe:
+                    ev[2 + 2 * h].record(s)
         for s in st["streams"]:
             cur.wait_stream(s)
+        if probe:
+            ev[5].record(cur)
+            ev[5].synchronize()
+            total, ta, tb = ev[0].elapsed_time(ev[5]), ev[1].elapsed_time(ev[2]), ev[3].elapsed_time(ev[4])
+            self._split_verified = True
+            self.split_overlap = total / max(ta + tb, 1e-6)
+            if self.split_overlap > 0.8:
+                import warnings
+                warnings.warn(f"vface_amd: the two launch streams do not overlap on this device (step {total:.2f} ms, halves {ta:.2f} + "
+                              f"{tb:.2f} ms): back to one launch sequence")
+                self.split_streams = 1
         if st["eps"] is None or st["eps"].shape[1] != outs[0].shape[1]:
             st["eps"] = torch.empty(N * hw, outs[0].shape[1], dtype=outs[0].dtype, device=self.device)
         ev = st["eps"].view(N, -1)
