@@ -560,6 +560,16 @@ def test_two_launch_streams_equal_one(small, fusion):
             assert (len(split) > 0) == (streams == 2), "the halves must actually have run on their own streams"
         for a_, b_ in zip(res[1], res[2]):
             assert torch.equal(a_, b_)
+        if fusion == "replace":
+            # halves that do NOT overlap (here: both on one stream, as two streams sharing a hardware queue would behave) are
+            # detected on the second split step and the engine returns to one launch sequence -- with the right bits throughout
+            one = torch.cuda.Stream()
+            eng.use_graph, eng._graphs, eng._split_state, eng.split_streams = True, {}, {}, 2
+            eng._split_pair, eng._split_verified, eng.split_overlap = [one, one], False, None
+            with pytest.warns(UserWarning, match="do not overlap"):
+                r = run(False)
+            assert eng.split_streams == 1 and eng.split_overlap > 0.8 and torch.equal(r, res[1][0])
+            eng._split_pair, eng._split_verified = None, False
         # a hook mode that reads the neighbouring frame keeps the batch whole
         sampler.hook_plan = HookPlan(fusion="flow_fix")
         sampler._register_step_hooks([synth.synth_flow(F_ - 1, h, w)[i][None].to(DEV) for i in range(F_ - 1)])
