@@ -304,3 +304,22 @@ def test_bench_refuses_a_traffic_summary_from_other_kernel_sources(tmp_path, mon
     t, why = bench.traffic_from_profiles(("gemm_kernel<F16, 0,",), True)
     assert t == (10 * 100.0 + 30 * 300.0) / 40 and "QUOTED" in why
     assert bench.traffic_from_profiles(("gemm_kernel<F16, 0,",), False)[0] is None     # another workload: never quoted
+
+
+def test_workspace_domain_nests_and_restores():
+    """hip.workspace_domain: the split-K scratch key of launches issued inside (two launch sequences on two streams must not share
+    one scratch); nesting restores the outer domain, also on an exception."""
+    from vface_amd import hip
+    assert hip._ws_domain == 0
+    with hip.workspace_domain(1):
+        assert hip._ws_domain == 1
+        with hip.workspace_domain(2):
+            assert hip._ws_domain == 2
+        assert hip._ws_domain == 1
+        try:
+            with hip.workspace_domain(3):
+                raise RuntimeError("x")
+        except RuntimeError:
+            pass
+        assert hip._ws_domain == 1
+    assert hip._ws_domain == 0
