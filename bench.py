@@ -545,7 +545,8 @@ def main():
                    "between them (engine._GraphSegments)"))
         eng.exchange_events = None
         sampler.drop_dead_branches = False
-        return {"ms_step": el / n_steps * 1e3, "enqueue_ms": t_enq / n_steps * 1e3, "inv_ms": inv_ms, "elapsed": el,
+        return {"final_latents": img.detach().clone(),
+                "ms_step": el / n_steps * 1e3, "enqueue_ms": t_enq / n_steps * 1e3, "inv_ms": inv_ms, "elapsed": el,
                 "launch": launch, "exchange": exch, "h": h}
 
     F_ = a.frames
@@ -566,6 +567,10 @@ def main():
     ri = run_workload(F_, a.fusion, a.steps, a.warmup, True, 0, graph=False)
     el = ri["elapsed"]
     log(f"  {ri['ms_step']:.2f} ms/step (host enqueue {ri['enqueue_ms']:.2f} ms/step)")
+    # the timed region (hipGraph replay, two launch streams where they apply) and this pass (kernel by kernel, one launch sequence)
+    # walked the same K steps from the same x_T: their latents must be the same bits
+    same_bits = bool(torch.equal(r["final_latents"], ri["final_latents"]))
+    log(f"  latents after {a.steps} steps: timed region {'==' if same_bits else '!='} kernel-by-kernel pass")
     fps = (F_ * world) / (a.ddim_steps * ms_step / 1e3)
     fam = timer.summary()
     unet_gflop = UNET_GFLOP.get(h)
@@ -686,6 +691,9 @@ def main():
                        "launch_streams": 2 if "two halves" in launch_mode else 1,
                        # step time / (half A + half B) of the engine's one measured split step: ~0.5 = the halves ran at once
                        "launch_stream_overlap": eng.split_overlap,
+                       # torch.equal of the latents after the K timed steps (graph replay, two streams) and after the same K steps
+                       # launched kernel by kernel in one sequence (the instrumented pass)
+                       "timed_region_bits_equal_kernel_by_kernel": same_bits,
                        "unet_algorithmic_tflops_per_gpu": unet_tflops,
                        "unet_algorithmic_frac_of_mfma_peak": unet_tflops / MFMA_PEAK_TFLOPS if unet_tflops else None,
                        "host_enqueue_ms_per_step": r["enqueue_ms"],
