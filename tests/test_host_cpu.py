@@ -323,3 +323,42 @@ def test_workspace_domain_nests_and_restores():
             pass
         assert hip._ws_domain == 1
     assert hip._ws_domain == 0
+
+
+def test_split_plan_halves_frames_across_chunks_and_refuses_coupled_modes():
+    """UNetEngine._split_plan (the two launch streams): frames [0, F/2) and [F/2, F) of EVERY chunk; hook modes that read another
+    frame (flow_fix, temporal, adaIn), odd frame counts, batches under 12 samples and sharded engines keep one launch sequence;
+    a batch without its last chunk (live_chunks) is halved over the chunks it has."""
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler, HookPlan
+    from vface_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    cfg = dict(image_size=32, in_channels=9, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+               channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True, transformer_depth=1, context_dim=768, legacy=False)
+    ldm = LatentDiffusion(cfg)
+    sampler = DDIMSampler(ldm)
+    eng = ldm.unet.engine
+    assert eng.split_streams == 2
+    for fusion in ("replace", "fft", "mix"):
+        sampler.hook_plan = HookPlan(fusion=fusion)
+        sampler._register_step_hooks(None)
+        a, b = (t.tolist() for t in eng._split_plan(24))
+        assert a == [0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19] and b == [4, 5, 6, 7, 12, 13, 14, 15, 20, 21, 22, 23]
+        assert eng._split_plan(9) is None and eng._split_plan(15) is None      # too small / odd frame count
+    for fusion in ("flow_fix", "temporal", "adaIn"):
+        sampler.hook_plan = HookPlan(fusion=fusion)
+        sampler._register_step_hooks(None)
+        assert eng._split_plan(24) is None, fusion
+    sampler.hook_plan = HookPlan(fusion="replace", enabled=False)
+    sampler._register_step_hooks(None)
+    a, b = (t.tolist() for t in eng._split_plan(16))                            # unhooked (inversion): plain halves
+    assert a == list(range(8)) and b == list(range(8, 16))
+    sampler.hook_plan = HookPlan(fusion="fft")
+    sampler._register_step_hooks(None)
+    eng.live_chunks = 2                                                         # [uncond ; cond] of 8 frames
+    a, b = (t.tolist() for t in eng._split_plan(16))
+    assert a == [0, 1, 2, 3, 8, 9, 10, 11] and b == [4, 5, 6, 7, 12, 13, 14, 15]
+    eng.live_chunks = None
+    eng.halo_exchange = object()                                                # frames sharded over ranks
+    assert eng._split_plan(24) is None
+    eng.halo_exchange = None
+    eng.split_streams = 1
+    assert eng._split_plan(24) is None
