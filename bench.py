@@ -5,9 +5,11 @@ A "step" is ONE DDIM step of the hot path over one batch of synthetic input: pac
 (3F samples) -> hooked UNet forward -> guidance + x_{t-1} update, for the F frames this rank owns.
 `value` = swapped frames/s for the whole job at 50 DDIM steps per frame = (F * n_gpus) / (50 * s_per_step).
 
-Default workload (N = 1): BASELINE.json configs[1] -- an 8-frame 512x512 clip (latent 64x64), 50-step DDIM
-schedule, structure attention injection only (fusion "replace" on the input-block attn1 modules), synthetic
-latents / conditioning / weights (name-keyed deterministic fill; there are no checkpoints on the GPU box).
+Default workload (N = 1): BASELINE.json configs[2], the largest configuration of BASELINE's list that one GPU runs -- a
+32-frame 512x512 clip (latent 64x64), 50-step DDIM schedule, frequency-spectrum attention interpolation (fusion "fft" on the
+input-block attn1 modules), 96 samples per step -- on synthetic latents / conditioning / weights (name-keyed deterministic
+fill; there are no checkpoints on the GPU box).  configs[1] (8 frames, "replace": the headline of rounds 1-4) and the
+16-frame flow_fix share are timed in the same process as `extra`.
 Inputs are resident in HBM when the timed region starts.  With --gpus N every rank runs the same per-GPU
 workload on its own frames (weak scaling); `--fusion flow_fix` adds the FSAI + flow path, whose one-neighbour
 boundary exchange runs over RCCL.
@@ -16,8 +18,8 @@ With --gpus N > 1 the defaults change to what north_star asks the multi-GPU run 
 schedule (`--fusion flow_fix`) at BASELINE config 4's per-GPU share (16 frames per GPU), so the one-neighbour halo
 exchange over RCCL is inside the timed region, and the line carries `exchange: {mode, bytes_per_step,
 wait_ms_per_step}`, `ranks_seen` (an all-reduce of 1 over the group) and `scaling_anchor`: the like-for-like
-single-GPU figure of that workload is `python bench.py --gpus 1 --fusion flow_fix --frames 16` (= extra[1] of the
-default N = 1 line), not the default N = 1 `value` (configs[1]: replace, 8 frames).  Every wait on a peer is bounded
+single-GPU figure of that workload is `python bench.py --gpus 1 --fusion flow_fix --frames 16` (= the flow_fix extra of the
+default N = 1 line), not the default N = 1 `value` (configs[2]: fft, 32 frames).  Every wait on a peer is bounded
 (VFACE_EXCHANGE_TIMEOUT_S, default 120 s): a rank whose neighbour never sends exits non-zero naming it.
 
 Also reported on the same JSON line:
@@ -27,8 +29,9 @@ Also reported on the same JSON line:
                   (2.5 PFLOP/s, MI355X_MICROARCH.md), with `by_family` = {gemm, conv, attention, norm} so that the
                   whole-UNet figure can be recomputed from its parts.
   cpu_baseline -- the CPU oracle (torch fp32 restatement of the reference, pinned to reference-generated
-                  golden vectors) timed on this box's host cores on a bounded sample: F=1 (batch 3) UNet
-                  forwards at 64x64 with the same hook mode, extrapolated to 50 steps per frame.
+                  golden vectors) timed on this box's host cores on a bounded sample: 3 timed (+1 warm-up) hooked-UNet
+                  forwards of an F=2 clip (batch 6) at 64x64 under the SAME hook mode as the headline (--fusion),
+                  extrapolated to 50 steps per clip.
 """
 import argparse
 import json
@@ -54,10 +57,10 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (default: 8 at --gpus 1 = BASELINE configs[1]; "
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU (default: 32 at --gpus 1 = BASELINE configs[2]; "
                                                               "16 at --gpus N > 1 = config 4's per-GPU share)")
     ap.add_argument("--res", type=int, default=512)
-    ap.add_argument("--fusion", default=None, help="replace | fft | flow_fix | none (default: replace at --gpus 1; flow_fix -- the "
+    ap.add_argument("--fusion", default=None, help="replace | fft | flow_fix | none (default: fft at --gpus 1; flow_fix -- the "
                                                    "shipped schedule, ddim_w_inv.py:303-305, with its halo exchange -- at --gpus N > 1)")
     ap.add_argument("--exchange", default="p2p", choices=["p2p", "allgather"], help="halo exchange form at --gpus N > 1")
     ap.add_argument("--inv-steps", type=int, default=3, help="DDIM-inversion steps timed after the run (0 = skip)")
@@ -66,7 +69,7 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=3)
     ap.add_argument("--no-extras", action="store_true",
-                    help="N = 1 only: skip the extra workloads (config 3: 32 frames + fft; shipped schedule: 16 frames + flow_fix)")
+                    help="N = 1 only: skip the extra workloads (configs[1]: 8 frames + replace; shipped schedule: 16 frames + flow_fix; 768x768)")
     ap.add_argument("--extra-steps", type=int, default=10)
     ap.add_argument("--streams", type=int, default=None, choices=[1, 2],
                     help="launch sequences of a graph-replayed forward (default: the engine's, VFACE_STREAMS or 2: two frame halves on "
@@ -78,14 +81,14 @@ def parse(argv=None):
 
 
 def resolve_defaults(a):
-    """Workload defaults by GPU count.  One GPU: BASELINE configs[1] -- 8 frames, structure injection
-    ("replace").  N > 1: the shipped schedule, "flow_fix" (REFace/ldm/models/diffusion/ddim_w_inv.py:303-305), 16 frames per
+    """Workload defaults by GPU count.  One GPU: BASELINE configs[2] -- 32 frames, frequency-spectrum attention interpolation
+    ("fft"), the largest single-GPU configuration of BASELINE's list.  N > 1: the shipped schedule, "flow_fix" (REFace/ldm/models/diffusion/ddim_w_inv.py:303-305), 16 frames per
     GPU (config 4's share) -- the only workload whose data path has an exchange step (temporal_flow.py:222-237: frame i+1 reads
     frame i), so a scaling curve from it measures the RCCL halo exchange north_star names."""
     if a.fusion is None:
-        a.fusion = "replace" if a.gpus == 1 else "flow_fix"
+        a.fusion = "fft" if a.gpus == 1 else "flow_fix"
     if a.frames is None:
-        a.frames = 8 if a.gpus == 1 else 16
+        a.frames = 32 if a.gpus == 1 else 16
     return a
 
 
@@ -113,8 +116,9 @@ class FamilyTimer:
                  per call), `patch8x8` = its 8x8 form (four images per workgroup; the time includes the split-K reduce pass),
                  `im2col` = gemm.hip's implicit GEMM (stride 2, the 9->320 convolution); `out_fused` = outconv.hip (GroupNorm + SiLU +
                  the 320->4 convolution in one launch, vector dot products: priced at its ALGORITHMIC 2 M 4 9 Cin FLOPs);
-      gemm       gemm_kernel<T, MODE_PLAIN, ..>: every Linear / 1x1 conv (sub-classes: `ff1` = the GEGLU projection, `n320` = the
-                 level-0 projections with N = 320, `other`); FLOPs = 2 M N K as executed (incl. the folded FSAI K = 2d);
+      gemm       gemm_kernel<T, MODE_PLAIN, ..>: every Linear / 1x1 conv, keyed by shape and epilogue form: `ff1_MxNxK` = the GEGLU projections,
+                 `MxNxK+rb+r32+o32+cs+a2` the rest (row bias, fp32 residual rows in, fp32 carrier out, column statistics, dual-source K);
+                 launches that qualify run gemm_big.hip's 256 x 320 tile; FLOPs = 2 M N K as executed (incl. the folded FSAI K = 2d);
                  `ffn_fused` = ffn_fused_kernel (ffn.hip): LayerNorm + both FeedForward GEMMs + residual of a level-0 block;
                  `attn_out_ffn_fused` = the same kernel with attn1's out-projection, attn2's row bias and the residual in front;
                  `attn_out_ffn_proj_fused` = ... and the SpatialTransformer's proj_out + input residual + column statistics behind;
@@ -187,7 +191,14 @@ class FamilyTimer:
             call = lambda: orig_gemm(a, wt, out, M=M, N=N, K=K, **kw)
             if not timer.on:
                 return call()
-            key = "ff1" if (kw.get("flags", 0) & hip.EPI_GEGLU) else ("n320" if (N == 320 and M >= 4096) else "other")
+            # by shape and epilogue form (what tools/step_trace.py prints per call): `ff1` = the GEGLU projections; the rest as
+            # M x N x K + the operands of its epilogue (r32 = fp32 residual rows in, o32 = fp32 carrier out, cs = column statistics,
+            # a2 = dual-source K: the hook's folded linear fusions)
+            if kw.get("flags", 0) & hip.EPI_GEGLU:
+                key = f"ff1_{M}x{N}x{K}"
+            else:
+                key = f"{M}x{N}x{K}" + "".join(t for t, k in (("+rb", "rowbias"), ("+r32", "residual32"), ("+o32", "out32"), ("+cs", "colstats"),
+                                                            ("+a2", "a2")) if kw.get(k) is not None)
             timer._timed("gemm", key, 2.0 * M * N * K, 1, call)
         hip.gemm = gemm
         orig_ffn = hip.ffn_fused
@@ -320,10 +331,10 @@ def usable_cores():
     return min(n, 16)
 
 
-def cpu_baseline(n_forwards, ddim_steps):
-    """Oracle (kind 'port') timed on the host cores, as BASELINE.md 4 plans it: full-size UNet, 64x64 latent, the shipped
-    hook schedule (flow_fix on the input-block attn1), F = 2 frames (batch 6) so the flow warp really runs, 1 warm-up +
-    `n_forwards` (>= 3) timed forwards on every core of the affinity mask."""
+def cpu_baseline(n_forwards, ddim_steps, fusion):
+    """Oracle (kind 'port') timed on the host cores, as BASELINE.md 4 plans it: full-size UNet, 64x64 latent, the hook mode
+    of the headline beside it (`fusion` on the input-block attn1), F = 2 frames (batch 6: flow_fix then really warps a frame),
+    1 warm-up + `n_forwards` (>= 3) timed forwards on every core of the affinity mask."""
     from oracle import hooks as ohooks
     from oracle import unet as ounet
     from vface_amd.utils import synth
@@ -337,11 +348,12 @@ def cpu_baseline(n_forwards, ddim_steps):
     x = synth.synth_normal("bench.cpu.x", (3 * F_, 9, 64, 64))
     ctx = synth.synth_normal("bench.cpu.ctx", (3 * F_, 1, 768))
     t = torch.full((3 * F_,), 481, dtype=torch.long)
-    flow = [f[None] for f in synth.synth_flow(F_ - 1, 64, 64)]
+    flow = [f[None] for f in synth.synth_flow(F_ - 1, 64, 64)] if fusion == "flow_fix" else None
     reg = {}
-    ohooks.register_spa_attn_injection(reg, ounet.attn1_names(spec), 1, switch_on=True, input_blocks=True,
-                                       middle_block=False, output_blocks=False, chunks=3, flow=flow,
-                                       block_indices=list(range(9)), fusion="flow_fix", split_ratio_fft=0.8, alpha=0.8)
+    if fusion != "none":
+        ohooks.register_spa_attn_injection(reg, ounet.attn1_names(spec), 1, switch_on=True, input_blocks=True,
+                                           middle_block=False, output_blocks=False, chunks=3, flow=flow,
+                                           block_indices=list(range(9)), fusion=fusion, split_ratio_fft=0.8, alpha=0.8)
     with torch.no_grad():
         t0 = time.time()
         ounet.unet_forward(sd, spec, x, t, ctx, reg)  # warm-up
@@ -352,7 +364,7 @@ def cpu_baseline(n_forwards, ddim_steps):
         dt = (time.time() - t0) / n_forwards
     return {"value": F_ / (ddim_steps * dt), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{n_forwards} timed hooked-UNet forwards (+1 warm-up) of the CPU oracle, F={F_} (batch {3 * F_}), "
-                      f"64x64 latent, fp32, fusion=flow_fix on the input-block attn1 (the shipped schedule); {dt:.2f} s per "
+                      f"64x64 latent, fp32, fusion={fusion} on the input-block attn1 (the headline's hook mode); {dt:.2f} s per "
                       f"forward, x{ddim_steps} steps per clip of {F_} frames"}
 
 
@@ -368,7 +380,7 @@ def traffic_from_profiles(prefixes, workload_ok):
     if not cands:
         return None, "no profiles/*_hbm_traffic.json"
     if not workload_ok:
-        return None, "the committed traffic summaries are of the default workload (8 frames, 512x512, replace, fp16) only"
+        return None, "the committed traffic summaries are of the default workload (32 frames, 512x512, fft, fp16) only"
     tj = json.load(open(os.path.join(prof, cands[-1])))
     have, want = (tj.get("_build") or {}).get("source_sha16"), source_sha16()
     if have != want:
@@ -581,6 +593,7 @@ def main():
     extras = []
     if world == 1 and not a.no_extras and a.res == 512:
         for name, f2, fus, res2 in (
+                ("BASELINE configs[1]: 8-frame 512x512 clip, structure attention injection only (the headline of rounds 1-4)", 8, "replace", 512),
                 ("BASELINE configs[2]: 32-frame 512x512 clip + frequency-spectrum attention interpolation", 32, "fft", 512),
                 ("shipped hook schedule (ddim_w_inv.py:303-305), config 4's per-GPU share: 16 frames + flow_fix", 16, "flow_fix", 512),
                 ("BASELINE configs[4]'s per-GPU share: 32 frames at 768x768 (96x96 latents, n = 9216 tokens at level 0), all three "
@@ -679,13 +692,16 @@ def main():
         d = by_family[dom]
         prefixes = {"gemm": ("gemm_kernel<F16, 0,", "gemm_kernel<BF16, 0,", "ffn_fused_kernel", "st_front_kernel"), "conv": ("conv_patch_kernel", "gemm_kernel<F16, 1,", "gemm_kernel<F16, 2,"),
                     "attention": ("attn_kernel",)}[dom]
-        traffic, traffic_src = traffic_from_profiles(prefixes, F_ == 8 and h == 64 and a.fusion == "replace" and a.dtype == "fp16" and world == 1)
+        traffic, traffic_src = traffic_from_profiles(prefixes, F_ == 32 and h == 64 and a.fusion == "fft" and a.dtype == "fp16" and world == 1)
+        baseline_cfg = {(8, "replace", 512): "BASELINE configs[1]: ", (32, "fft", 512): "BASELINE configs[2] (the largest single-GPU configuration): ",
+                        (16, "flow_fix", 512): "BASELINE configs[3]'s per-GPU share (64 frames / 4 GPUs): ",
+                        (32, "flow_fix", 768): "BASELINE configs[4]'s per-GPU share (256 frames / 8 GPUs): "}.get((F_, a.fusion, a.res), "")
         out = {
             "metric": "swapped frames/sec at 512x512, 50-step DDIM", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16" if a.dtype == "fp16" else "bf16",
             "data": "synthetic",
-            "config": {"workload": f"{F_}-frame {a.res}x{a.res} clip per GPU, {a.ddim_steps}-step DDIM, hooked REFace "
+            "config": {"workload": baseline_cfg + f"{F_}-frame {a.res}x{a.res} clip per GPU, {a.ddim_steps}-step DDIM, hooked REFace "
                                    f"UNet (859.5M params), attn1 fusion={a.fusion} on input blocks, CFG scale 3.0, "
                                    f"batch [uncond;cond;recon] = {3 * F_} samples per step",
                        "frames_per_gpu": F_, "latent": [h, h], "fusion": a.fusion,
@@ -705,12 +721,12 @@ def main():
                        "attention_gemm_roofline_frac": (fps / world) * 24.135e12 / (MFMA_PEAK_TFLOPS * 1e12) if h == 64 else None},
             "exchange": r["exchange"],
             "ranks_seen": ranks_seen,
-            # the like-for-like single-GPU figure of an N > 1 line: the N = 1 DEFAULT is BASELINE configs[1] (8 frames, replace),
+            # the like-for-like single-GPU figure of an N > 1 line: the N = 1 DEFAULT is BASELINE configs[2] (32 frames, fft),
             # the N > 1 default the shipped schedule at config 4's share (16 frames per GPU, flow_fix)
             "scaling_anchor": None if world == 1 else (
                 f"N=1 anchor of this workload: `python bench.py --gpus 1 --fusion {a.fusion} --frames {F_}` (also reported by the "
-                f"default N=1 run as extra[1] when fusion=flow_fix, frames=16); the default N=1 `value` is configs[1] "
-                f"(replace, 8 frames) and is NOT the same workload"),
+                f"default N=1 run among `extra` when fusion=flow_fix, frames=16); the default N=1 `value` is configs[2] "
+                f"(fft, 32 frames) and is NOT the same workload"),
             "inversion": None if inv_ms is None else {
                 "ms_per_step": inv_ms, "steps_timed": a.inv_steps,
                 "note": "DDIM inversion step (hooks off, batch 2F, no guidance), outside the timed region; `value` is "
@@ -742,7 +758,7 @@ def main():
                          "by_family": by_family},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_forwards, a.ddim_steps)
+            out["cpu_baseline"] = cpu_baseline(a.cpu_forwards, a.ddim_steps, a.fusion)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

@@ -55,6 +55,8 @@ extern "C" {
 #define VFACE_TUNE_NO_Q8 0x4000000        /* A/B: 3x3 convolutions on 8x8 images stay on the im2col kernel (default: four images per workgroup through the patch-staged kernel + split-K reduce) */
 #define VFACE_TUNE_PATCH_BN160 0x2000000  /* A/B: the patch-staged kernel's 160-channel tile wherever it divides Cout (default: the width whose one-per-CU grid has the cheaper last round) */
 #define VFACE_TUNE_F32_TRANSPOSE 0x1000000 /* A/B: the epilogue's LDS transpose in fp32 even where nothing reads the fp32 sum (default there: 16 bits) */
+#define VFACE_TUNE_BIG_TILE 0x10000000     /* vface_gemm: the 256 x 320 tile (csrc/gemm_big.hip) whenever the launch qualifies (N % 320 == 0, K % 64 == 0, 16-bit output, bias / GEGLU / fp32 residual only), however few tiles; default: from 192 tiles on.  Same bits as the 128-row kernel */
+#define VFACE_TUNE_NO_BIG_TILE 0x20000000  /* A/B: never the 256 x 320 tile */
 /* (VFACE_TUNE_PATCH on vface_gemm: run a plain GEMM with M % 256 == 0, K % 64 == 0, N % 128|160 == 0, no GEGLU / fp32-only output
  *  through the patch-staged kernel's 256-row tile -- same bits as the default kernel, measured 3-18 % SLOWER on the UNet's shapes
  *  (tools/bench_kernels.py "patch256"): an A/B switch, never chosen automatically) */

@@ -272,13 +272,13 @@ def _bench_module():
 def test_bench_multi_gpu_command_line_defaults_to_the_shipped_schedule():
     """VERDICT r2 next #4: the driver's `bench.py --gpus N --steps K --warmup W` with N > 1 must time the workload that HAS
     the halo exchange -- the shipped schedule (flow_fix, ddim_w_inv.py:303-305) at config 4's per-GPU share (16 frames) --
-    while N = 1 stays BASELINE configs[1] (8 frames, replace); explicit flags win."""
+    while N = 1 is BASELINE configs[2] (32 frames, fft: the largest single-GPU configuration, VERDICT r4 next #3); explicit flags win."""
     bench = _bench_module()
     for n in (2, 4, 8):
         a = bench.parse(["--gpus", str(n), "--steps", "20", "--warmup", "5"])
         assert (a.fusion, a.frames, a.exchange) == ("flow_fix", 16, "p2p")
     a = bench.parse(["--gpus", "1", "--steps", "20", "--warmup", "5"])
-    assert (a.fusion, a.frames) == ("replace", 8)
+    assert (a.fusion, a.frames) == ("fft", 32)
     a = bench.parse(["--gpus", "8", "--fusion", "replace", "--frames", "8", "--exchange", "allgather"])
     assert (a.fusion, a.frames, a.exchange) == ("replace", 8, "allgather")
 

@@ -22,7 +22,8 @@ struct VfOncePerDevice {
 };
 
 enum { GEMM_GEGLU = 1, GEMM_OUT_F32 = 2, GEMM_NO_XCD_REMAP = 0x1000, GEMM_NO_SETPRIO = 0x2000, GEMM_NARROW_EPILOGUE = 0x8000, GEMM_NO_PERSIST = 0x10000, GEMM_PERSIST = 0x20000,
-       GEMM_NO_PATCH = 0x80000, GEMM_PATCH = 0x100000, GEMM_GN8 = 0x8000000 /* A/B: fixed column groups of 8 n-tiles in the plain GEMM's tile order */, GEMM_NO_Q8 = 0x4000000 /* A/B: the 8x8 level stays on the im2col kernel */, GEMM_PATCH_BN160 = 0x2000000 /* A/B: the patch kernel's 160-wide tile wherever it divides N */, GEMM_F32_TRANSPOSE = 0x1000000 /* A/B: epilogue transposes in fp32 even where 16 bits would do */ };  // (0x40000 = VFACE_CONV_PAD_TRAILING)  // bits 8..11 of flags: forced schedule variant (0 = automatic)
+       GEMM_NO_PATCH = 0x80000, GEMM_PATCH = 0x100000, GEMM_GN8 = 0x8000000 /* A/B: fixed column groups of 8 n-tiles in the plain GEMM's tile order */, GEMM_NO_Q8 = 0x4000000 /* A/B: the 8x8 level stays on the im2col kernel */, GEMM_PATCH_BN160 = 0x2000000 /* A/B: the patch kernel's 160-wide tile wherever it divides N */, GEMM_F32_TRANSPOSE = 0x1000000 /* A/B: epilogue transposes in fp32 even where 16 bits would do */,
+       GEMM_BIG = 0x10000000 /* take gemm_big.hip's 256 x 320 tile whenever the launch qualifies */, GEMM_NO_BIG = 0x20000000 /* A/B: never */ };  // (0x40000 = VFACE_CONV_PAD_TRAILING)  // bits 8..11 of flags: forced schedule variant (0 = automatic)
 
 struct GemmParams {
     int mode;  // 0: plain A[M][K]; 1: implicit 3x3 conv over NHWC
@@ -71,6 +72,7 @@ struct GemmParams {
     long workspace_bytes;
     int split_k, kt_per_split;  // filled by the launcher
     int tile_group;             // patch-staged kernel: n-tiles per column group of its XCD-aware tile order (launcher; 0 = 8)
+    unsigned res_bytes, c_bytes;  // gemm_big.hip (filled by its launcher): extents of the fp32 residual view and of the 16-bit output view
 };
 long vf_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_sample);
 bool vf_gemm_variants_built();
@@ -81,6 +83,8 @@ int vf_conv_kernel_choice(const GemmParams& p, int* arg);                       
 int vf_launch_conv_patch(const GemmParams& p, int dtype, hipStream_t stream);
 int vf_gemm_patch_tile(const GemmParams& p);                                   // plain GEMM through the patch kernel's 256-row tile: 0 | 160 | 128
 int vf_launch_gemm_patch(const GemmParams& p, int dtype, hipStream_t stream);
+bool vf_gemm_big_ok(const GemmParams& p);                                      // gemm_big.hip: the 256 x 320 tile takes this plain-GEMM launch
+int vf_launch_gemm_big(const GemmParams& p, int dtype, hipStream_t stream);
 int vf_conv_q8_split(const GemmParams& p);                                      // the 8x8 level through the patch kernel: 0 | K split
 int vf_launch_conv_q8(const GemmParams& p, int dtype, hipStream_t stream);     // (main pass only: the caller runs the split-K reduce)
 bool vf_attention_shared_scores_supported(int dh, int v_sets);

@@ -26,6 +26,7 @@ TUNE_NO_Q8 = 0x4000000  # A/B: the 8x8 level stays on the im2col kernel
 TUNE_PATCH_BN160 = 0x2000000  # A/B: patch kernel's 160-wide tile wherever it divides Cout
 TUNE_F32_TRANSPOSE = 0x1000000  # A/B: epilogue transposes through LDS in fp32 even where 16 bits would do
 TUNE_NO_PERSISTENT, TUNE_PERSISTENT = 0x10000, 0x20000  # flags of gemm / conv3x3: force one workgroup per tile / the persistent form
+TUNE_BIG_TILE, TUNE_NO_BIG_TILE = 0x10000000, 0x20000000  # gemm: always (where the launch qualifies) / never the 256 x 320 tile (csrc/gemm_big.hip)
 FUSION_NONE, FUSION_REPLACE, FUSION_LINEAR = 0, 1, 2
 
 _i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
@@ -229,6 +230,25 @@ def splitk_workspace(device, M: int, N: int, K: int, flags: int = 0, rows_per_sa
 
 
 # ---------------------------------------------------------------------------------------------- wrappers
+# EXPERIMENT switch (A/B runs only; unset = the library's own rule): VFACE_BIG_RULE = "off" | "min:<tiles>" | "eff:<max waste>:<min tiles>"
+def _parse_big_rule():
+    r = os.environ.get("VFACE_BIG_RULE")
+    if not r:
+        return None
+    if r == "off":
+        return lambda tiles: False
+    k = r.split(":")
+    if k[0] == "min":
+        return lambda tiles, m=int(k[1]): tiles >= m
+    if k[0] == "eff":
+        w, m = float(k[1]), int(k[2])
+        return lambda tiles: tiles >= m and (-(-tiles // 256)) * 256 / tiles <= w
+    raise ValueError(r)
+
+
+_BIG_RULE = _parse_big_rule()
+
+
 def gemm(a: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldc: int,
          ldw: Optional[int] = None, bias=None, rowbias=None, rows_per_sample: int = 1, residual=None, ldr: int = 0,
          a2=None, lda2: int = 0, k1: int = 0, a2_row_mod: int = 0, flags: int = 0, colstats=None, split_k: bool = True,
@@ -236,6 +256,8 @@ def gemm(a: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     """out[M, :N] = a[M, :K] @ wt[:N, :K]^T (+ epilogue).  Tensors are device buffers; M/N/K/ld* describe the view.
     ``residual32`` / ``out32``: the fp32 residual stream (``vface_stream32``); ``out`` may be None with ``out32``."""
     lib = load()
+    if _BIG_RULE is not None and not (flags & (TUNE_BIG_TILE | TUNE_NO_BIG_TILE)):
+        flags |= TUNE_BIG_TILE if _BIG_RULE(((M + 255) // 256) * (N // 320)) else TUNE_NO_BIG_TILE
     ws, ws_bytes = splitk_workspace(a.device, M, N, K, flags, rows_per_sample) if split_k else (None, 0)
     rc = lib.vface_gemm(_p(a), lda, _p(a2), lda2, k1, a2_row_mod, _p(wt), ldw if ldw is not None else K, M, N, K,
                         _p(bias), _p(rowbias), rows_per_sample, rowbias.stride(0) if rowbias is not None else 0,
