@@ -19,7 +19,9 @@ def pytest_configure(config):
 def load_golden(name):
     path = os.path.join(GOLDEN, name + ".npz")
     if not os.path.exists(path):
-        pytest.skip(f"golden fixture {name}.npz not generated")
+        # a missing fixture is a FAILURE, not a skip: every reference-pinned test would otherwise vanish with exit code 0
+        pytest.fail(f"golden fixture tests/golden/{name}.npz is missing (regenerate with tests/golden/make_golden.py where "
+                    "/root/reference exists; the fixtures are committed and travel with the repo)", pytrace=False)
     z = np.load(path, allow_pickle=False)
     return {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiu" and z[k].ndim > 0 else z[k]) for k in z.files}
 

@@ -1,6 +1,24 @@
 """One small invocation of the hot path on cuda:0, checked against the CPU oracle (driver smoke test)."""
 import torch
 
+# rel-L2 that fp16 weights + one rounding per matrix-core operand (fp32 accumulation, statistics and residual stream) cost on the
+# smoke case, emulated on the CPU oracle (tests/precision_budget.py); the asserted bound is 1.25 x it, as for the bf16 UNet test
+EMULATED_REL_L2 = 1.26e-3
+SMOKE_BOUND = 1.25 * EMULATED_REL_L2
+
+
+def smoke_case():
+    """(spec, F, h, w, x, ctx, t, flow) of the smoke invocation: one definition for run() and for the CPU test that derives its bound."""
+    from oracle import unet as ounet
+    from vface_amd.utils import synth
+    spec = ounet.UNetSpec(model_channels=64)
+    F_, h, w = 2, 16, 16
+    x = synth.synth_normal("smoke.x", (3 * F_, 9, h, w))
+    ctx = synth.synth_normal("smoke.ctx", (3 * F_, 1, 768))
+    t = torch.full((3 * F_,), 481, dtype=torch.long)
+    flow = synth.synth_flow(F_ - 1, h, w)
+    return spec, F_, h, w, x, ctx, t, flow
+
 
 def run(verbose: bool = True) -> float:
     from oracle import hooks as ohooks
@@ -13,7 +31,7 @@ def run(verbose: bool = True) -> float:
 
     hip.load()
     dev = "cuda:0"
-    spec = ounet.UNetSpec(model_channels=64)
+    spec, F_, h, w, x, ctx, t, flow = smoke_case()
     cfg = dict(image_size=32, in_channels=9, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1],
                num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
                transformer_depth=1, context_dim=768, legacy=False)
@@ -22,11 +40,6 @@ def run(verbose: bool = True) -> float:
     ldm = ldm.to(dev)
     sampler = DDIMSampler(ldm)
     sampler.flow_gate = "flow_hw"   # a 16x16 latent: the reference's own gate (n == 4096) would skip the warp
-    F_, h, w = 2, 16, 16
-    x = synth.synth_normal("smoke.x", (3 * F_, 9, h, w))
-    ctx = synth.synth_normal("smoke.ctx", (3 * F_, 1, 768))
-    t = torch.full((3 * F_,), 481, dtype=torch.long)
-    flow = synth.synth_flow(F_ - 1, h, w)
     register_spa_attn_injection(sampler, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True)
     register_spa_attn_injection(sampler, 1, switch_on=True, input_blocks=True, middle_block=False, output_blocks=False,
                                 flow=[flow[i][None] for i in range(F_ - 1)], chunks=3, block_indices=list(range(9)),
@@ -42,5 +55,8 @@ def run(verbose: bool = True) -> float:
     err = float((got - ref).norm() / ref.norm())
     if verbose:
         print(f"smoke: hooked UNet (flow_fix) on {torch.cuda.get_device_name(0)}: rel-L2 vs CPU oracle = {err:.3e}")
-    assert err < 1.5e-3, err   # measured 1.27e-3 (the reference's own fp16 autocast: 2.06e-3 on this size, tests/golden/lowp.npz)
+    # bound = 1.25 x the error an emulation of this build's rounding points predicts for exactly this case (EMULATED_REL_L2,
+    # re-derived on the CPU by tests/test_precision_budget.py::test_smoke_bound_is_the_emulations; measured 1.27e-3; the
+    # reference's own fp16 autocast: 2.06e-3 on this size, tests/golden/lowp.npz)
+    assert err < SMOKE_BOUND, err
     return err
