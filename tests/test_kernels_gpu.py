@@ -1372,18 +1372,54 @@ def test_gemm_big_tile_equals_128_row_kernel_bit_for_bit(dt, M, N, K):
     assert torch.equal(outs[0], outs[1]), "GEGLU: the two tiles' outputs differ"
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K,rps", [(1024, 640, 640, 256), (768, 1280, 1280, 256), (2048, 320, 128, 1024)])
+def test_gemm_big_tile_residual_stream_form(dt, M, N, K, rps):
+    """The 256 x 320 tile's fp32 residual-stream epilogue (proj_in / to_out / proj_out of a 640- / 1280-channel block): bias +
+    per-sample row bias + fp32 residual rows -> fp32 carrier (+ 16-bit copy, + per-64-row column statistics).  Carrier and copy
+    are the 128-row kernel's bits; the statistics are the same sums folded in another order (allclose), and the sums of what was
+    stored (fp64)."""
+    h = hip()
+    a, w = rnd((M, K), 1, dt).to(DEV), rnd((N, K), 2, dt, 1 / math.sqrt(K)).to(DEV)
+    bias, rb = rnd((N,), 3, torch.float32).to(DEV), rnd((M // rps, N), 5, torch.float32).to(DEV)
+    res32 = rnd((M, N), 6, torch.float32).to(DEV)
+    base = a.double() @ w.double().t() + bias.double()
+    cases = [("proj_in", dict(), False, False, base),
+             ("to_out", dict(rowbias=rb, rows_per_sample=rps, residual32=res32), False, False, base + rb.double().repeat_interleave(rps, 0) + res32.double()),
+             ("proj_out", dict(residual32=res32, rows_per_sample=rps), True, True, base + res32.double())]
+    for name, kw, want16, stats, ref in cases:
+        outs = []
+        for fl in (h.TUNE_NO_BIG_TILE, h.TUNE_BIG_TILE):
+            o32 = torch.full((M, N + 8), 3.0, dtype=torch.float32, device=DEV)
+            o16 = torch.full((M, N + 8), 3.0, dtype=dt, device=DEV) if want16 else None
+            cs = torch.zeros(M // 64, N, 2, dtype=torch.float32, device=DEV) if stats else None
+            h.gemm(a, w, o16[:, 8:] if want16 else None, M=M, N=N, K=K, lda=K, ldc=N + 8 if want16 else 0, bias=bias, flags=fl,
+                   colstats=cs, out32=o32[:, :N], split_k=False, **kw)
+            outs.append((o32, o16, cs))
+        assert rel_l2(outs[1][0][:, :N].double().cpu(), ref.cpu()) < 1e-5, name
+        assert torch.equal(outs[0][0], outs[1][0]), f"{name}: fp32 carrier differs (or something outside the view was written)"
+        if want16:
+            assert torch.equal(outs[0][1], outs[1][1]), f"{name}: 16-bit copy differs"
+        if stats:
+            assert torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-3), f"{name}: column statistics differ"
+            v = outs[1][0][:, :N].double().reshape(M // 64, 64, N)
+            want = torch.stack([v.sum(1), (v * v).sum(1)], -1)
+            assert torch.allclose(outs[1][2].double(), want, rtol=1e-5, atol=1e-3)
+
+
 def test_gemm_big_tile_refuses_what_it_cannot_do():
-    """VFACE_TUNE_BIG_TILE is a preference, not a different result: a launch the 256 x 320 tile does not take (column statistics,
-    fp32 carrier, N % 320 != 0) runs the 128-row kernel and gives that kernel's bits."""
+    """VFACE_TUNE_BIG_TILE is a preference, not a different result: a launch the 256 x 320 tile does not take (N % 320 != 0; a row
+    bias whose samples are shorter than the tile; an fp32-only output) runs the 128-row kernel and gives that kernel's bits."""
     h = hip()
     dt = torch.float16
-    M, N, K = 512, 640, 320
-    a, w = rnd((M, K), 1, dt).to(DEV), rnd((N, K), 2, dt, 1 / math.sqrt(K)).to(DEV)
-    outs = []
-    for fl in (h.TUNE_NO_BIG_TILE, h.TUNE_BIG_TILE):
-        o, o32 = torch.empty(M, N, dtype=dt, device=DEV), torch.empty(M, N, dtype=torch.float32, device=DEV)
-        cs = torch.zeros(M // 64, N, 2, dtype=torch.float32, device=DEV)
-        h.gemm(a, w, o, M=M, N=N, K=K, lda=K, ldc=N, flags=fl, colstats=cs, out32=o32, split_k=False)
-        outs.append((o, o32, cs))
-    for x, y in zip(*outs):
-        assert torch.equal(x, y)
+    for M, N, K, rps in ((512, 512, 320, 256), (512, 640, 320, 64)):
+        a, w = rnd((M, K), 1, dt).to(DEV), rnd((N, K), 2, dt, 1 / math.sqrt(K)).to(DEV)
+        rb = rnd((M // rps, N), 5, torch.float32).to(DEV)
+        outs = []
+        for fl in (h.TUNE_NO_BIG_TILE, h.TUNE_BIG_TILE):
+            o, o32 = torch.empty(M, N, dtype=dt, device=DEV), torch.empty(M, N, dtype=torch.float32, device=DEV)
+            cs = torch.zeros(M // 64, N, 2, dtype=torch.float32, device=DEV)
+            h.gemm(a, w, o, M=M, N=N, K=K, lda=K, ldc=N, flags=fl, colstats=cs, out32=o32, rowbias=rb, rows_per_sample=rps, split_k=False)
+            outs.append((o, o32, cs))
+        for x, y in zip(*outs):
+            assert torch.equal(x, y)

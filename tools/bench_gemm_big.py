@@ -31,11 +31,13 @@ def timeit(fn, iters=10):
 def main():
     g = torch.Generator(device=DEV).manual_seed(0)
     print(f"{'launch':10s} {'M':>6s} {'N':>6s} {'K':>5s} {'tiles':>6s} | {'128-row us':>10s} {'TF':>5s} | {'256x320 us':>10s} {'TF':>5s} | {'library us':>10s} {'TF':>5s}  (library: no epilogue)")
+    o32 = cs = rbv = None
     for samples in (24, 48, 96):
         for lvl, (n, c) in (("L1", (1024, 640)), ("L2", (256, 1280)), ("mid", (64, 1280))):
             M = samples * n
             for name, N, K, kind in ((f"qkv {lvl}", 3 * c, c, "plain"), (f"ff1 {lvl}", 8 * c, c, "geglu"), (f"ff2 {lvl}", c, 4 * c, "res32"),
-                                     (f"fsai {lvl}", 2 * c, 2 * c, "a2")):
+                                     (f"fsai {lvl}", 2 * c, 2 * c, "a2"), (f"proj_in {lvl}", c, c, "o32"), (f"to_out {lvl}", c, c, "rb_r32_o32"),
+                                     (f"proj_out {lvl}", c, c, "r32_o32_o16_cs")):
                 Mx = M // 3 if kind == "a2" else M
                 a = torch.randn(Mx, K if kind != "a2" else K // 2, device=DEV, generator=g).half()
                 a2 = torch.randn(Mx, K // 2, device=DEV, generator=g).half() if kind == "a2" else None
@@ -43,12 +45,24 @@ def main():
                 bias = torch.randn(N, device=DEV, generator=g)
                 out = torch.empty(Mx, N // 2 if kind == "geglu" else N, dtype=torch.float16, device=DEV)
                 res = torch.randn(Mx, N, device=DEV, generator=g) if kind == "res32" else None
+                if kind in ("o32", "rb_r32_o32", "r32_o32_o16_cs"):
+                    if n % 256:
+                        continue
+                    o32 = torch.empty(Mx, N, dtype=torch.float32, device=DEV)
+                    res = torch.randn(Mx, N, device=DEV, generator=g) if kind != "o32" else None
+                    rbv = torch.randn(samples, N, device=DEV, generator=g)
+                    cs = torch.empty(Mx // 64, N, 2, dtype=torch.float32, device=DEV)
+                    if kind != "r32_o32_o16_cs":
+                        out = None
                 kw = {"plain": dict(), "geglu": dict(bias=bias, flags=hip.EPI_GEGLU), "res32": dict(bias=bias, residual32=res),
-                      "a2": dict(a2=a2, lda2=K // 2, k1=K // 2)}[kind]
+                      "a2": dict(a2=a2, lda2=K // 2, k1=K // 2),
+                      "o32": dict(bias=bias, out32=o32 if kind == "o32" else None, rows_per_sample=n),
+                      "rb_r32_o32": dict(bias=bias, rowbias=rbv if kind == "rb_r32_o32" else None, rows_per_sample=n, residual32=res, out32=o32 if kind == "rb_r32_o32" else None, split_k=False),
+                      "r32_o32_o16_cs": dict(bias=bias, residual32=res, out32=o32 if kind == "r32_o32_o16_cs" else None, colstats=cs if kind == "r32_o32_o16_cs" else None, rows_per_sample=n)}[kind]
                 fl0 = kw.pop("flags", 0)
                 t = {}
                 for tag, fl in (("old", hip.TUNE_NO_BIG_TILE), ("big", hip.TUNE_BIG_TILE)):
-                    t[tag] = timeit(lambda: hip.gemm(a, w, out, M=Mx, N=N, K=K, lda=a.shape[1], ldc=out.shape[1], flags=fl | fl0, **kw))
+                    t[tag] = timeit(lambda: hip.gemm(a, w, out, M=Mx, N=N, K=K, lda=a.shape[1], ldc=out.shape[1] if out is not None else 0, flags=fl | fl0, **kw))
                 if kind == "a2":
                     acat = torch.cat([a, a2], 1)
                     lo = torch.empty(Mx, N, dtype=torch.float16, device=DEV)
@@ -61,6 +75,7 @@ def main():
                 print(f"{name:10s} {Mx:6d} {N:6d} {K:5d} {tiles:6d} | {t['old']:10.1f} {fl / t['old'] / 1e6:5.0f} | {t['big']:10.1f} {fl / t['big'] / 1e6:5.0f} | "
                       f"{tl:10.1f} {fl / tl / 1e6:5.0f}", flush=True)
                 del a, a2, w, out, res, lo
+                o32 = cs = rbv = None
 
 
 if __name__ == "__main__":

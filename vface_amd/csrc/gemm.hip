@@ -32,7 +32,6 @@
 namespace {
 
 constexpr int BM = 128, BK = 64;
-constexpr long VF_GEMM_BIG_MIN_TILES = 192;      // (measured: tools/bench_gemm_big.py)
 enum { MODE_PLAIN = 0, MODE_CONV_FAST = 1, MODE_CONV_GENERIC = 2 };
 
 // RM: the residual form of the wide epilogue (0 none, 1 16-bit, 2 the fp32 stream) as an instantiation of its own; -1 = chosen
@@ -1094,12 +1093,8 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         }
     }
     if (p.mode == 0 && (p.flags & GEMM_PATCH) && !((p.flags >> 8) & 0xF) && vf_gemm_patch_tile(p)) return vf_launch_gemm_patch(p, dtype, stream);
-    // long token matrices: gemm_big.hip's 256 x 320 tile (bit-identical output, so the rule may look at the batch): from about a
-    // round of the one-workgroup-per-CU grid on
-    if (p.mode == 0 && !(p.flags & GEMM_NO_BIG) && vf_gemm_big_ok(p)) {
-        const long tiles = (long)((p.M + 255) / 256) * (p.N / 320);
-        if ((p.flags & GEMM_BIG) || tiles >= VF_GEMM_BIG_MIN_TILES) return vf_launch_gemm_big(p, dtype, stream);
-    }
+    // long token matrices: gemm_big.hip's 256 x 320 tile (the one statement of the rule: vf_gemm_big_choice)
+    if (p.mode == 0 && vf_gemm_big_choice(p)) return vf_launch_gemm_big(p, dtype, stream);
     if (p.gn_ab) return VF_ERR_SHAPE;   // the fused input normalisation exists in the patch-staged kernel only
     const int variant = pick_variant(p);
     if ((p.res_f32 || p.C32) && variant != 5 && variant != 6) return VF_ERR_SHAPE;

@@ -23,7 +23,9 @@
 //   the results are BIT-IDENTICAL to that kernel's, so which of the two a launch takes may depend on the batch (tests).
 // * Epilogues (template EPI): 0: + bias, round, transposed through LDS as 16-bit rows, 16-byte stores; 1: GEGLU (weight rows
 //   interleaved in 16-row value / gate blocks, packing.pack_geglu) the same way; 2: + bias + fp32 residual-stream rows, one
-//   rounding, transposed in fp32.
+//   rounding, transposed in fp32; 3: the fp32 residual-stream form -- + bias + per-sample row bias + fp32 residual rows -> fp32
+//   carrier (+ optional 16-bit copy, + optional per-64-row column statistics of the carrier), gemm.hip's NT = 5 epilogue on each
+//   80-channel half of the wave's tile.
 #include <type_traits>
 
 #include "common.hpp"
@@ -64,6 +66,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         n0 = (g * GN + (rem - tm * gw)) * BN2;
     }
 
+    const float* rowbias_row = nullptr;      // EPI 3: the per-sample row bias of this tile (every tile lies inside one sample)
+    if constexpr (EPI == 3) {
+        const int rps = max(p.rows_per_sample, 1);
+        const int smp = __builtin_amdgcn_readfirstlane(m0 / rps);      // (uniform: keeps the pointer in scalar registers across the K loop)
+        rowbias_row = p.rowbias ? p.rowbias + (long)smp * p.ld_rowbias : nullptr;
+    }
     const i32x4_t rA = raw_buffer_rsrc(p.A, p.a_bytes);
     const i32x4_t rA2 = raw_buffer_rsrc(p.A2 ? p.A2 : p.A, p.A2 ? p.a2_bytes : 0u);
     const i32x4_t rW = raw_buffer_rsrc(p.Wt, p.w_bytes);
@@ -179,22 +187,42 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
 
     // ---- epilogue.  Lane (fr, fq) holds, per (j, i), channels n0 + wn*160 + j*16 + fq*4 .. +3 of row m0 + wm*64 + i*16 + fr.
     __syncthreads();                    // every wave is done with the last stage: the stages become transpose scratch
+    {   // (lane coordinates re-derived from the thread id behind an opaque asm: hipcc otherwise carries the K loop's copies across
+        //  the loop in spilled registers instead of re-computing two ANDs)
+    int te = threadIdx.x;
+    asm volatile("" : "+v"(te));
+    const int lane = te & 63, fr = lane & 15, fq = lane >> 4;
     const int wrow0 = m0 + wm * 64;
     {
-        // bias summed into the accumulators up front (unconditionally: an absent bias is loaded as zeros), so its 40 registers are
-        // free again before the passes start -- gemm.hip's order of fp32 additions: (acc + bias) + residual
-        float4 bj[10];
+        // bias (and, EPI 3, the per-sample row bias: the launcher only takes tiles that lie inside one sample) summed into the
+        // accumulators up front -- gemm.hip's order of fp32 additions, ((acc + bias) + rowbias) + residual -- five channel tiles at a
+        // time (20 registers beside the 160 accumulators), unconditionally: an absent vector is loaded as zeros
+        // (through a buffer descriptor: an absent vector is a descriptor of zero bytes, every load of it returns zeros -- no branch
+        //  per load, which hipcc turns into a region the accumulators are spilled around)
+        auto add_vec = [&](const float* vec) {
+            const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(vec ? (const void*)vec : p.Wt), 0, vec ? p.N * 4 : 0, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            const int nb = n0 + wn * 160 + j * 16 + fq * 4;
-            bj[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + nb) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+            for (int jh = 0; jh < 2; ++jh) {
+                f4_t bj[5];
 #pragma unroll
-        for (int j = 0; j < 10; ++j)
+                for (int j = 0; j < 5; ++j)
+                    bj[j] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rV, (n0 + wn * 160 + (jh * 5 + j) * 16 + fq * 4) * 4, 0, 0));
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[j][i][0] += bj[j].x; acc[j][i][1] += bj[j].y; acc[j][i][2] += bj[j].z; acc[j][i][3] += bj[j].w;
+                for (int j = 0; j < 5; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[jh * 5 + j][i] += bj[j];
+                        asm volatile("" : "+v"(acc[jh * 5 + j][i]));      // (pinned HERE: hipcc otherwise sinks the sums to their first use and spills the vector meanwhile)
+                    }
+                __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        add_vec(p.bias);
+        if constexpr (EPI == 3) {
+            // (unconditional: a conditional update of the 160 accumulator registers makes hipcc keep two copies of them; the row's
+            //  sample was divided out before the K loop: a branch here and hipcc sinks the bias sums below it, spilling the bias)
+            add_vec(rowbias_row);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);      // (nothing of the passes below is hoisted above the bias sums: its registers are those the bias held)
     E* Cout = reinterpret_cast<E*>(p.C);
@@ -238,6 +266,100 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             for (int it = 0; it < NIT; ++it) {
                 const long m = wrow0 + i * 16 + rr[it];
                 if (rr[it] >= 0 && m < p.M) *reinterpret_cast<V8*>(Cout + m * p.ldc + ncol0 + cc[it] * 8) = o[it];
+            }
+        }
+    } else if constexpr (EPI == 3) {
+        // the fp32 residual-stream form.  Per 80-channel half of the wave's tile: row tile by row tile, five accumulator tiles cross
+        // LDS in fp32 (16 rows x 84 floats per wave), lanes re-read them as (row rrow + 6 it, 8-channel chunk rch) -- 10 chunks x 6
+        // rows per pass, three passes per row tile -- add the residual rows, store the carrier (and the rounded copy), and sum
+        // the stored values per channel; the six row-lanes of a channel are folded through the scratch in a fixed order.
+        constexpr int SP = 84;
+        float* scr = reinterpret_cast<float*>(smem_raw) + wave * (16 * SP);
+        const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual ? p.residual : p.Wt), 0, (int)(p.residual ? p.res_bytes : 0u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C ? p.C : const_cast<void*>(p.Wt), 0, (int)(p.C ? p.c_bytes : 0u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rC32 = __builtin_amdgcn_make_buffer_rsrc(p.C32, 0, (int)p.c32_bytes, 0x00020000);
+        const int rrow = lane / 10, rch = lane - rrow * 10;
+        const bool act = lane < 60;
+        const bool has_res = p.residual != nullptr, has_c16 = p.C != nullptr;
+        // byte offsets of (row wrow0 + rrow, this lane's chunk) in the three views, and their strides per 6 rows (pass) / 16 rows (row
+        // tile): kept as RUNNING values behind an opaque asm -- left to itself hipcc precomputes all 72 (pass, view) offsets of the
+        // unrolled passes up front and spills the accumulators to hold them
+        const unsigned st_r6 = (unsigned)(6 * p.ldr * 4), st_c6 = (unsigned)(6 * p.ldc32 * 4), st_h6 = (unsigned)(6 * p.ldc * 2);
+        const unsigned st_r16 = (unsigned)(16 * p.ldr * 4), st_c16 = (unsigned)(16 * p.ldc32 * 4), st_h16 = (unsigned)(16 * p.ldc * 2);
+#pragma unroll
+        for (int hc = 0; hc < 2; ++hc) {
+            const int ncol = n0 + wn * 160 + hc * 80 + rch * 8;      // first channel of this lane's chunk
+            unsigned o_r = (unsigned)(((long)(wrow0 + rrow) * p.ldr + ncol) * 4), o_c = (unsigned)(((long)(wrow0 + rrow) * p.ldc32 + ncol) * 4);
+            unsigned o_h = (unsigned)(((long)(wrow0 + rrow) * p.ldc + ncol) * 2);
+            unsigned o_rn = o_r;                                     // the residual loads run one row tile ahead
+            int mrow = wrow0 + rrow, mrow_n = mrow;                   // absolute row of pass 0 of the current / the prefetched row tile
+            float s8[8], q8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s8[e] = q8[e] = 0.f;
+            f4_t r32[3][2];
+            auto load_res = [&](int it) {      // pass `it` of the row tile (o_rn, mrow_n) point at
+                const int r = rrow + 6 * it;
+                const unsigned off = (act && r < 16 && mrow_n + 6 * it < p.M && has_res) ? o_rn + it * st_r6 : OOB;
+                r32[it][0] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)off, 0, 0));
+                r32[it][1] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)off, 16, 0));
+            };
+#pragma unroll
+            for (int it = 0; it < 3; ++it) load_res(it);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float* srow = scr + fr * SP + fq * 4;
+#pragma unroll
+                for (int j = 0; j < 5; ++j)
+                    *reinterpret_cast<float4*>(srow + j * 16) = make_float4(acc[hc * 5 + j][i][0], acc[hc * 5 + j][i][1], acc[hc * 5 + j][i][2], acc[hc * 5 + j][i][3]);
+                o_rn += st_r16; mrow_n += 16;
+                asm volatile("" : "+v"(o_rn), "+v"(mrow_n));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int it = 0; it < 3; ++it) {
+                    const int r = rrow + 6 * it;
+                    const float* lrd = scr + min(r, 15) * SP + rch * 8;
+                    const f4_t x0 = *reinterpret_cast<const f4_t*>(lrd), x1 = *reinterpret_cast<const f4_t*>(lrd + 4);
+                    const f4_t a = r32[it][0], b = r32[it][1];
+                    const bool ok = act && r < 16 && mrow + 6 * it < p.M;
+                    float v[8] = {x0[0] + a[0], x0[1] + a[1], x0[2] + a[2], x0[3] + a[3], x1[0] + b[0], x1[1] + b[1], x1[2] + b[2], x1[3] + b[3]};
+                    if (i + 1 < 4) load_res(it);
+                    const unsigned o32 = ok ? o_c + it * st_c6 : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, f4_t{v[0], v[1], v[2], v[3]}), rC32, (int)o32, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, f4_t{v[4], v[5], v[6], v[7]}), rC32, (int)o32, 16, 0);
+                    if (has_c16) {
+                        V8 o;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = from_f32<E>(v[e]);
+                        const unsigned o16 = ok ? o_h + it * st_h6 : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, o), rC, (int)o16, 0, 0);
+                    }
+                    if (ok) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { s8[e] += v[e]; q8[e] = fmaf(v[e], v[e], q8[e]); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                o_c += st_c16; o_h += st_h16; mrow += 16;
+                asm volatile("" : "+v"(o_c), "+v"(o_h), "+v"(mrow));
+            }
+            if (p.colstats) {
+                // fold the six row-lanes of every channel through the scratch (fixed order: reproducible); the wave's 64 rows are
+                // one statistics slice
+                if (act) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        scr[(rrow * 80 + rch * 8 + e) * 2] = s8[e];
+                        scr[(rrow * 80 + rch * 8 + e) * 2 + 1] = q8[e];
+                    }
+                }
+                const long slice = (long)wrow0 >> 6;
+                if (wrow0 < p.M) {
+                    for (int c = lane; c < 80; c += 64) {
+                        float ss = 0.f, qq = 0.f;
+                        for (int l = 0; l < 6; ++l) { ss += scr[(l * 80 + c) * 2]; qq += scr[(l * 80 + c) * 2 + 1]; }
+                        *reinterpret_cast<float2*>(p.colstats + (slice * p.ld_colstats + n0 + wn * 160 + hc * 80 + c) * 2) = make_float2(ss, qq);
+                    }
+                }
             }
         }
     } else {
@@ -293,6 +415,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             }
         }
     }
+    }
 }
 
 template <class TT, int EPI>
@@ -318,6 +441,7 @@ int launch_big(const GemmParams& p, hipStream_t stream) {
 
 template <class TT>
 int launch_big_dtype(const GemmParams& p, hipStream_t stream) {
+    if (p.C32) return launch_big<TT, 3>(p, stream);
     if (p.flags & GEMM_GEGLU) return launch_big<TT, 1>(p, stream);
     if (p.residual) return launch_big<TT, 2>(p, stream);
     return launch_big<TT, 0>(p, stream);
@@ -333,11 +457,36 @@ bool vf_gemm_big_ok(const GemmParams& p) {
     if ((p.N % BN2) || (p.K & 63) || p.K < 128 || (p.Kw < p.K)) return false;
     if (p.A2 && ((p.K1 & 63) || p.K1 <= 0 || p.K1 >= p.K)) return false;
     if (p.flags & (GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE | GEMM_F32_TRANSPOSE | 0x4000 | (0xF << 8))) return false;
-    if (p.colstats || p.rowbias || p.C32 || !p.C) return false;
-    if (((uintptr_t)p.C & 15) || (p.ldc & 7) || (p.lda & 7) || (p.ldw & 7)) return false;
+    if (p.C32) {
+        // the fp32 residual-stream form (EPI 3): carrier required; the per-sample row bias needs every 256-row tile inside one sample
+        if (p.flags & GEMM_GEGLU) return false;
+        if (((uintptr_t)p.C32 & 15) || (p.ldc32 & 3)) return false;
+        if (p.rowbias && (p.rows_per_sample <= 0 || (p.rows_per_sample % BM2) || (p.ld_rowbias & 3) || ((uintptr_t)p.rowbias & 15))) return false;
+        if (p.colstats && ((p.M & 63) || (p.ld_colstats & 1) || ((uintptr_t)p.colstats & 7))) return false;
+    } else if (p.colstats || p.rowbias || !p.C) {
+        return false;
+    }
+    if (p.C && (((uintptr_t)p.C & 15) || (p.ldc & 7))) return false;
+    if ((p.lda & 7) || (p.ldw & 7)) return false;
     if (p.residual && (!p.res_f32 || (p.flags & GEMM_GEGLU) || ((uintptr_t)p.residual & 15) || (p.ldr & 3))) return false;
     if (p.bias && ((uintptr_t)p.bias & 15)) return false;
     return true;
+}
+
+// THE rule for which plain-GEMM kernel a launch runs (vf_launch_gemm dispatches on it).  Outputs and the fp32 carrier are
+// bit-identical between the two kernels (the per-64-row column statistics of the residual-stream form are not: another fold
+// order -- one more reason that form is never chosen automatically: a sample's bits must not depend on which other samples
+// share its launch, what frame sharding and the two launch streams rely on); 16-bit-output launches take the 256 x 320 tile
+// from 192 tiles on -- about a round of the one-workgroup-per-CU grid (measured: profiles/r05_c, r05_d).
+bool vf_gemm_big_choice(const GemmParams& p) {
+    if ((p.flags & GEMM_NO_BIG) || !vf_gemm_big_ok(p)) return false;
+    if (p.flags & GEMM_BIG) return true;
+    // the fp32 residual-stream form (EPI 3: proj_in / to_out / proj_out) is built, bit-identical and MEASURED SLOWER than the 128-row
+    // kernel on 14 of 18 of the UNet's launches (profiles/r05_e: 0.78-1.29x): these launches are bound by their epilogue's HBM
+    // traffic (4 + 4 B per output element around a K = 640 loop), which two 128-row workgroups per CU overlap with each other's
+    // K loops and one 256-row workgroup per CU cannot.  It stays selectable (VFACE_TUNE_BIG_TILE) and is never chosen here.
+    if (p.C32) return false;
+    return (long)((p.M + BM2 - 1) / BM2) * (p.N / BN2) >= 192;
 }
 
 int vf_launch_gemm_big(const GemmParams& p_in, int dtype, hipStream_t stream) {
@@ -346,10 +495,11 @@ int vf_launch_gemm_big(const GemmParams& p_in, int dtype, hipStream_t stream) {
     {
         // extents of the residual and output views for the epilogue's buffer descriptors (bytes; below 4 GiB - 16)
         const unsigned long nout = (p.flags & GEMM_GEGLU) ? (unsigned long)p.N / 2 : (unsigned long)p.N;
-        const unsigned long cb = ((unsigned long)(p.M - 1) * p.ldc + nout) * 2ul;
+        const unsigned long cb = p.C ? ((unsigned long)(p.M - 1) * p.ldc + nout) * 2ul : 0ul;
         const unsigned long rb = p.residual ? ((unsigned long)(p.M - 1) * p.ldr + p.N) * 4ul : 0ul;
-        if (cb >= 0xFFFFFFF0ul || rb >= 0xFFFFFFF0ul) return VF_ERR_SHAPE;
-        p.c_bytes = (unsigned)cb; p.res_bytes = (unsigned)rb;
+        const unsigned long c32b = p.C32 ? ((unsigned long)(p.M - 1) * p.ldc32 + p.N) * 4ul : 0ul;
+        if (cb >= 0xFFFFFFF0ul || rb >= 0xFFFFFFF0ul || c32b >= 0xFFFFFFF0ul) return VF_ERR_SHAPE;
+        p.c_bytes = (unsigned)cb; p.res_bytes = (unsigned)rb; p.c32_bytes = (unsigned)c32b;
     }
     if (dtype == VF_DTYPE_F16) return launch_big_dtype<F16>(p, stream);
     if (dtype == VF_DTYPE_BF16) return launch_big_dtype<BF16>(p, stream);

@@ -72,7 +72,7 @@ struct GemmParams {
     long workspace_bytes;
     int split_k, kt_per_split;  // filled by the launcher
     int tile_group;             // patch-staged kernel: n-tiles per column group of its XCD-aware tile order (launcher; 0 = 8)
-    unsigned res_bytes, c_bytes;  // gemm_big.hip (filled by its launcher): extents of the fp32 residual view and of the 16-bit output view
+    unsigned res_bytes, c_bytes, c32_bytes;  // gemm_big.hip (filled by its launcher): extents of the fp32 residual view, of the 16-bit output view and of the fp32 carrier view
 };
 long vf_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_sample);
 bool vf_gemm_variants_built();
@@ -83,7 +83,8 @@ int vf_conv_kernel_choice(const GemmParams& p, int* arg);                       
 int vf_launch_conv_patch(const GemmParams& p, int dtype, hipStream_t stream);
 int vf_gemm_patch_tile(const GemmParams& p);                                   // plain GEMM through the patch kernel's 256-row tile: 0 | 160 | 128
 int vf_launch_gemm_patch(const GemmParams& p, int dtype, hipStream_t stream);
-bool vf_gemm_big_ok(const GemmParams& p);                                      // gemm_big.hip: the 256 x 320 tile takes this plain-GEMM launch
+bool vf_gemm_big_ok(const GemmParams& p);
+bool vf_gemm_big_choice(const GemmParams& p);                                  // ... and the rule says it should                                      // gemm_big.hip: the 256 x 320 tile takes this plain-GEMM launch
 int vf_launch_gemm_big(const GemmParams& p, int dtype, hipStream_t stream);
 int vf_conv_q8_split(const GemmParams& p);                                      // the 8x8 level through the patch kernel: 0 | K split
 int vf_launch_conv_q8(const GemmParams& p, int dtype, hipStream_t stream);     // (main pass only: the caller runs the split-K reduce)
