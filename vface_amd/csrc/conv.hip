@@ -236,12 +236,19 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
 
     // weight fragment addresses (constant over the K loop): row = wn * BN/2 + j*16 + fr, 16-B slot (kk*4 + fq) ^ swz(row);
     // the kk = 1 half is the same address with byte bit 6 flipped; the ring slot is an immediate offset
-    unsigned wadr[NT];
+    // (ONE register: channel tile j is 16 rows = 2 KiB further and keeps the swizzle term -- ((row + 16 j) >> 1) & 7 = (row >> 1) & 7 --
+    //  so the other NT - 1 addresses are immediates of the ds_read; as NT registers the NT = 5 kernel spilled one)
+    //  -- where slot offset + tile offset still fit the 16-bit immediate: the three-slot ring of the 3x3 windows; the four-slot
+    //  ring of the 2x2 windows keeps one register per tile)
+    constexpr bool WADR1 = (NSLOT - 1) * BSLOT + (NT - 1) * 2048 + 64 < 65536;
+    const int wrow = wn * (BN / 2) + fr;
+    const unsigned wadr0 = (unsigned)(wrow * 128 + ((fq ^ ((wrow >> 1) & 7)) << 4));
+    unsigned wadrs[WADR1 ? 1 : NT];
+    if constexpr (!WADR1) {
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        const int row = wn * (BN / 2) + j * 16 + fr;
-        wadr[j] = (unsigned)(row * 128 + ((fq ^ ((row >> 1) & 7)) << 4));
+        for (int j = 0; j < NT; ++j) wadrs[j] = wadr0 + j * 2048;
     }
+    auto wadr = [&](int j) -> unsigned { if constexpr (WADR1) return wadr0 + j * 2048; else return wadrs[j]; };
     // patch pixel of (pixel row 0 of this wave, tap (0,0)); Q8: rows 8.. and columns 8.. lie in the next quadrant, 2 halo pixels on
     const int lane_pp = Q8 ? (wm * 4 + (wm >= 2 ? 2 : 0)) * PW + fr + (fr >= 8 ? 2 : 0) : wm * 4 * PW + fr;
 
@@ -267,14 +274,14 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) afX[i] = *reinterpret_cast<const V8*>(smem_raw + padr[i]);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bfX[j] = *reinterpret_cast<const V8*>(sB + wbase + wadr[j]);
+        for (int j = 0; j < NT; ++j) bfX[j] = *reinterpret_cast<const V8*>(sB + wbase + wadr(j));
     };
     auto read_h1 = [&](unsigned wbase) {
         if (DIAG && abl_reads) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) afY[i] = *reinterpret_cast<const V8*>(smem_raw + (padr[i] ^ 64u));
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bfY[j] = *reinterpret_cast<const V8*>(sB + wbase + (wadr[j] ^ 64u));
+        for (int j = 0; j < NT; ++j) bfY[j] = *reinterpret_cast<const V8*>(sB + wbase + (wadr(j) ^ 64u));
     };
     auto mfma_X = [&]() {
         __builtin_amdgcn_s_setprio(1);

@@ -907,18 +907,24 @@ int launch_one(const GemmParams& p, hipStream_t stream) {
     // persistent form: only where a workgroup would get more than one tile and the wide epilogue applies
     // (measured on the UNet's shapes: +1..3 % for the implicit convolutions, +-2 % noise for plain GEMMs, which keep the
     // one-tile-per-workgroup launch unless GEMM_PERSIST asks otherwise)
-    const bool persist = DB && p.split_k == 1 && !(p.flags & (GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE | GEMM_NO_PERSIST | 0x4000)) &&
+    // (never for the generic-window form -- Cin % 64 != 0: the UNet's 9 -> 320 input convolution --: its persistent instantiation
+    //  carries all three residual forms of the epilogue and spilled 35 registers; the one-tile-per-workgroup form does not)
+    const bool persist_shape = DB && MODE != MODE_CONV_GENERIC && p.split_k == 1 &&
+                         !(p.flags & (GEMM_OUT_F32 | GEMM_NARROW_EPILOGUE | GEMM_NO_PERSIST | 0x4000)) &&
                          !(p.N & 7) && ntiles > persistent_grid() && (MODE != MODE_PLAIN || (p.flags & GEMM_PERSIST));
     // residual form of the wide epilogue as a kernel of its own for the forms the UNet launches (see gemm_kernel's RM)
     const int rm = p.res_f32 ? 2 : (p.residual ? 1 : 0);
+    const bool persist = persist_shape && rm == 0;
     void (*kern)(GemmParams) = nullptr;
     int which = 0;
     if constexpr (DB && MODE != MODE_CONV_GENERIC) {
-        if (persist) { which = rm == 0 ? 1 : 2; kern = rm == 0 ? gemm_kernel<TT, MODE, NT, DB, DB, 0> : gemm_kernel<TT, MODE, NT, DB, DB>; }
+        // (the persistent form exists without a residual only -- what the UNet launches it with; its run-time-residual instantiation
+        //  spilled 22-41 registers and is gone: a persistent launch with a residual runs one tile per workgroup)
+        if (persist) { which = 1; kern = gemm_kernel<TT, MODE, NT, DB, DB, 0>; }
         else { which = 3 + rm; kern = rm == 2 ? gemm_kernel<TT, MODE, NT, DB, false, 2> : rm == 1 ? gemm_kernel<TT, MODE, NT, DB, false, 1> : gemm_kernel<TT, MODE, NT, DB, false, 0>; }
     } else {
-        which = persist ? 2 : 0;
-        kern = persist ? gemm_kernel<TT, MODE, NT, DB, DB> : gemm_kernel<TT, MODE, NT, DB, false>;
+        which = 0;
+        kern = gemm_kernel<TT, MODE, NT, DB, false>;
     }
     static VfOncePerDevice attr_set[6];
     if (lds > 64 * 1024 && !attr_set[which].set_lds(reinterpret_cast<const void*>(kern), (int)lds)) return VF_ERR_LAUNCH;
