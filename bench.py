@@ -603,7 +603,17 @@ def main():
                 continue
             log(f"extra workload: {f2} frames at {res2}x{res2}, fusion={fus} ...")
             e = run_workload(f2, fus, a.extra_steps if res2 == 512 else max(3, a.extra_steps // 2), 2, False, 0, graph=not a.eager, res=res2)
+            same2 = None
+            if fus == "flow_fix" and res2 == 512 and not a.eager and eng.split_streams == 2 and "two halves" in e["launch"]:
+                # flow_fix on two launch streams runs its halves as coupled in-process shards (parallel.StreamShard): every bench run
+                # re-checks that hand-over against the single launch sequence, bit for bit, on this workload
+                eng.split_streams = 1
+                e1 = run_workload(f2, fus, a.extra_steps, 2, False, 0, graph=True, res=res2)
+                eng.split_streams = 2
+                same2 = bool(torch.equal(e["final_latents"], e1["final_latents"]))
+                log(f"  two launch streams {'==' if same2 else '!='} one launch sequence after {a.extra_steps} steps (one sequence: {e1['ms_step']:.2f} ms/step)")
             extras.append({"workload": name, "frames_per_gpu": f2, "fusion": fus, "res": res2, "latent": [e["h"], e["h"]],
+                           "launch_streams": 2 if "two halves" in e["launch"] else 1, "two_streams_bits_equal_one_sequence": same2,
                            "steps": a.extra_steps if res2 == 512 else max(3, a.extra_steps // 2), "warmup": 2,
                            "launch": "hipGraph replay" if e["launch"] != "kernel by kernel" else "kernel by kernel",
                            "ms_per_step": e["ms_step"], "host_enqueue_ms_per_step": e["enqueue_ms"],

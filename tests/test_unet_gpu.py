@@ -9,6 +9,8 @@ already 9.6e-4 (full UNet) / 1.1e-3 (small configuration) from its fp32 output, 
 arithmetic (fp16 autocast) is 1.59e-3 / 2.06e-3 away.  What is asserted here instead, per case:
   * the HIP path is CLOSER to the fp32 reference than the reference's own fp16-autocast run (fixture, not emulation);
   * an absolute bound a little above the measured value (fp32 residual stream: DESIGN 6), so a regression shows."""
+import os
+
 import pytest
 import torch
 
@@ -517,11 +519,22 @@ def test_hipgraph_replay_equals_kernel_by_kernel_launches(small):
         sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
 
 
-@pytest.mark.parametrize("fusion", ["replace", "fft", "mix", "none"])
+def _diff_pattern(a, b):
+    """Which frames / how many elements / how large: enough to tell a stale or torn boundary slab (frame F/2 first, later frames
+    only after further DDIM steps; rounding-sized) from an ordering bug in a half's own work (any frame of that half) at one look."""
+    d = (a.double() - b.double()).abs()
+    per = [(i, int((d[i] > 0).sum()), float(d[i].max()), float(d[i].max() / b[i].double().abs().max().clamp_min(1e-30)))
+           for i in range(a.shape[0]) if bool((d[i] > 0).any())]
+    return "; ".join(f"frame {i}: {n} elements differ, max abs {m:.3e} (rel {r:.1e})" for i, n, m, r in per) or "equal"
+
+
+@pytest.mark.parametrize("fusion", ["replace", "fft", "mix", "none", "flow_fix"])
 def test_two_launch_streams_equal_one(small, fusion):
-    """The graph-replayed forward as two frame halves on two HIP streams (UNetEngine._step_forward_split, the default when no hook
-    mode couples frames) gives the bits of the single launch sequence -- sampling (batch 3F), with the dead branches dropped (2F),
-    inversion (2F, unhooked); the cross-frame modes stay whole."""
+    """The graph-replayed forward as two frame halves on two HIP streams (UNetEngine._step_forward_split) gives the bits of the
+    single launch sequence -- sampling (batch 3F), with the dead branches dropped (2F), inversion (2F, unhooked).  Hook modes
+    that never read another frame split freely; flow_fix, whose warp reads the previous frame, runs its halves as two in-process
+    frame shards (parallel.StreamShard: half 0 hands its last frame's fused q|k to half 1 at every hooked flow layer); the
+    modes that couple frames more widely stay whole."""
     from vface_amd.ldm.models.diffusion.ddim_w_inv import HookPlan
     ldm, sampler, sd = small
     eng = ldm.unet.engine
@@ -532,12 +545,15 @@ def test_two_launch_streams_equal_one(small, fusion):
     inp = d(synth.synth_normal("two.inpaint", (F_, 4, h, w)) * 0.18215)
     mask = d(synth.synth_mask(F_, h, w))
     inv = {int(s): d(synth.synth_normal(f"two.inv.{int(s)}", (F_, 4, h, w))) for s in oddim.ddim_timesteps(50)}
+    flow = [synth.synth_flow(F_ - 1, h, w)[i][None] for i in range(F_ - 1)] if fusion == "flow_fix" else None
+    old_gate = getattr(sampler, "flow_gate", None)
+    sampler.flow_gate = "flow_hw"        # (32 x 32 latents: the reference's 4096-token gate would never fire)
 
     def run(drop):
         sampler.drop_dead_branches = drop
         img, _ = sampler.sample(S=50, batch_size=F_, shape=[4, h, w], conditioning=c, target_conditioning=tc,
                                 inverse_results_dir=inv, verbose=False, unconditional_guidance_scale=3.0,
-                                unconditional_conditioning=uc, eta=0.0, x_T=x_T, flow=None,
+                                unconditional_conditioning=uc, eta=0.0, x_T=x_T, flow=flow,
                                 test_model_kwargs={"inpaint_image": inp, "inpaint_mask": mask}, max_steps=3)
         return img.clone()
 
@@ -558,8 +574,10 @@ def test_two_launch_streams_equal_one(small, fusion):
             assert not eng._graph_failed
             split = [k for k in eng._split_state if k[0] != "plan"]
             assert (len(split) > 0) == (streams == 2), "the halves must actually have run on their own streams"
-        for a_, b_ in zip(res[1], res[2]):
-            assert torch.equal(a_, b_)
+            if streams == 2 and fusion == "flow_fix":
+                assert any("shard_objs" in v for k, v in eng._split_state.items() if k[0] != "plan"), "the coupled halves ran as stream shards"
+        for what, a_, b_ in zip(("sampling 3F", "sampling 2F (dead branches dropped)", "inversion"), res[1], res[2]):
+            assert torch.equal(a_, b_), f"{fusion}, {what}: two streams != one -- {_diff_pattern(b_, a_)}"
         if fusion == "replace":
             # halves that do NOT overlap (here: both on one stream, as two streams sharing a hardware queue would behave) are
             # detected on the second split step and the engine returns to one launch sequence -- with the right bits throughout
@@ -570,10 +588,16 @@ def test_two_launch_streams_equal_one(small, fusion):
                 r = run(False)
             assert eng.split_streams == 1 and eng.split_overlap > 0.8 and torch.equal(r, res[1][0])
             eng._split_pair, eng._split_verified = None, False
-        # a hook mode that reads the neighbouring frame keeps the batch whole
+        # flow_fix splits as two coupled shards (VFACE_SPLIT_COUPLED=0 keeps it whole); wider couplings keep the batch whole
         sampler.hook_plan = HookPlan(fusion="flow_fix")
         sampler._register_step_hooks([synth.synth_flow(F_ - 1, h, w)[i][None].to(DEV) for i in range(F_ - 1)])
-        assert eng._split_plan(3 * F_) is None
+        eng.split_streams = 2
+        assert eng._split_plan(3 * F_) is not None and eng._split_coupled
+        os.environ["VFACE_SPLIT_COUPLED"] = "0"
+        try:
+            assert eng._split_plan(3 * F_) is None
+        finally:
+            del os.environ["VFACE_SPLIT_COUPLED"]
         sampler.hook_plan = HookPlan(fusion="temporal")
         sampler._register_step_hooks(None)
         assert eng._split_plan(3 * F_) is None
@@ -584,6 +608,7 @@ def test_two_launch_streams_equal_one(small, fusion):
     finally:
         sampler.hook_plan, eng.use_graph, eng._graphs, eng.split_streams, sampler.drop_dead_branches = old
         eng._split_state = {}
+        sampler.flow_gate = old_gate
         sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
 
 

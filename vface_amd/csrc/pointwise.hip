@@ -336,10 +336,13 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(const typename TT::elem*
             dbg_y0[(long)(f - 1) * h * w + pix] = y0;
         }
         const float wx1 = ix - fx0, wy1 = iy - fy0, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
-        const bool vx = x0 + 1 <= w - 1, vy = y0 + 1 <= h - 1;
-        const int x1 = vx ? x0 + 1 : x0, y1 = vy ? y0 + 1 : y0;
-        const float w00 = wx0 * wy0, w01 = vx ? wx1 * wy0 : 0.f, w10 = vy ? wx0 * wy1 : 0.f,
-                    w11 = (vx && vy) ? wx1 * wy1 : 0.f;
+        // The coordinate was clamped to [0, size - 1] (border padding), so a neighbour past the border (x0 + 1 > w - 1) only ever
+        // occurs with ix == w - 1 exactly, i.e. wx1 == +0: its weight is zero by arithmetic and needs no select -- the neighbour's
+        // index is clamped with a min instead.  (The selects this replaces -- `vx ? wx1 * wy0 : 0` on a VCC lane mask, and x0 + vx
+        // through an add-with-carry on the same mask -- are what returned the wrong branch for lanes 48-63 while attention waves of
+        // another queue shared the SIMD: tools/warp_coresidency_probe.py, HISTORY R5.)  Same bits: 0 * w = +0 either way.
+        const int x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
+        const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
         const unsigned cb = (unsigned)cc * (unsigned)sizeof(E);
         const V8 a = __builtin_bit_cast(V8, (u4_t)__builtin_amdgcn_raw_buffer_load_b128(rF, (unsigned)(y0 * w + x0) * row_b + cb, 0, 0));
         const V8 b = __builtin_bit_cast(V8, (u4_t)__builtin_amdgcn_raw_buffer_load_b128(rF, (unsigned)(y0 * w + x1) * row_b + cb, 0, 0));

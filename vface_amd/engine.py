@@ -289,6 +289,7 @@ class _GraphSegments:
         self.segments: list = []      # [(CUDAGraph, host_op | None)]
         self.keep: list = []          # tensors the host ops refer to
         self.cur = None
+        self.index = 0                # ordinal of the next exchange inside the forward (stated by the engine: FrameShard.set_index)
         self.n_started = 0            # exchanges the capture pass has started for real ..
         self.pending = None           # .. and the state dict of one that was started and not yet finished
         # what the engine reads from its exchange object
@@ -318,12 +319,17 @@ class _GraphSegments:
             self.cur = None
 
     # ---- the exchange interface (parallel.FrameShard), as seen by UNetEngine._attn1_sharded while capturing
+    def set_index(self, k: int) -> None:
+        self.index = int(k)
+
     def start_exchange(self, tail: torch.Tensor):
-        inner, state = self.inner, {}
+        inner, state, k = self.inner, {}, self.index
         recv = torch.empty_like(tail) if inner.rank > 0 else None      # (allocated in the shared pool: lives with the graphs)
         self.keep += [tail, recv, state]
 
         def op():
+            if hasattr(inner, "set_index"):
+                inner.set_index(k)                 # (the replayed host call states the same ordinal as the captured forward did)
             state["h"] = inner.start_exchange(tail, recv=recv)
         self.end(op)
         op()                       # the capture pass exchanges for real too (garbage slabs): the ranks' calls stay paired
@@ -363,6 +369,10 @@ class _CountingExchange:
     def __init__(self, inner):
         self.inner, self.tails = inner, []
         self.rank, self.world, self.first, self.count = inner.rank, inner.world, inner.first, inner.count
+
+    def set_index(self, k: int) -> None:
+        if hasattr(self.inner, "set_index"):
+            self.inner.set_index(k)
 
     def start_exchange(self, tail, recv=None):
         self.tails.append(tail)
@@ -814,7 +824,7 @@ class UNetEngine:
         fused(1, T)
         # my last frame's fused q|k goes to the next rank; the previous rank's arrives while chunk 0 / chunk 2 /
         # the v projections below are computed
-        handle = self.halo_exchange.start_exchange(T[(F_ - 1) * n:])
+        handle = self._halo_start(T[(F_ - 1) * n:])
         hip.gemm(xln, p["wqkv"], qkv, M=Fn, N=3 * d, K=d, lda=xln.stride(0), ldc=3 * d)
         hip.gemm(xln[Fn:], p["wqkv"][2 * d:], qkv[Fn:, 2 * d:], M=N * n - Fn, N=d, K=d, lda=xln.stride(0), ldc=3 * d)
         for ch in range(2, chunks):
@@ -923,7 +933,7 @@ class UNetEngine:
             halo = None
             if sharded:
                 fused(1, T)
-                handle = self.halo_exchange.start_exchange(T[(F_ - 1) * n:])
+                handle = self._halo_start(T[(F_ - 1) * n:])
                 for ch in range(2, chunks):
                     fused(ch, qkv[ch * Fn:(ch + 1) * Fn, :2 * d])
                 ev = self.exchange_events if not isinstance(self.halo_exchange, _GraphSegments) else None
@@ -968,6 +978,15 @@ class UNetEngine:
         hip.gemm(att, p["wo"]["w"], None, M=M, N=d, K=d, lda=d, ldc=0, bias=p["wo"]["b"], rowbias=a2vec, rows_per_sample=n,
                  split_k=False, residual32=t0, out32=t1)
         return self._ffn(t1, p, n)
+
+    def _halo_start(self, tail: torch.Tensor):
+        """``halo_exchange.start_exchange`` with the exchange's ordinal inside this forward stated first (FrameShard.set_index)."""
+        ex = self.halo_exchange
+        k = getattr(self, "_halo_k", 0)
+        self._halo_k = k + 1
+        if hasattr(ex, "set_index"):
+            ex.set_index(k)
+        return ex.start_exchange(tail)
 
     def _ffn_ok(self, M: int, c: int) -> bool:
         """``vface_ffn_fused_supported`` per (rows, width), asked once (a ctypes call per block per forward otherwise)."""
@@ -1063,6 +1082,7 @@ class UNetEngine:
         """UNetModel.forward (openaimodel.py:860-907) on an NHWC 16-bit input (channels padded to 8k).
         Returns eps as fp32 NHWC ``[N*H*W, out_channels]``."""
         self._ensure_packed()
+        self._halo_k = 0             # ordinal of the next boundary exchange of this forward (_halo_start)
         P, u = self._packed, self.unet
         emb_all, a2_all = self.embeddings(timesteps, context)
         blocks_in, mid, blocks_out = u.block_table()
@@ -1154,21 +1174,31 @@ class UNetEngine:
         return tuple(sig), flows
 
     _SPLIT_SAFE = ("replace", "fft", "fft_vfixed", "mix")      # hook modes that never read another FRAME (pnp_utils.py:133-262)
+    # ... and the one that reads exactly ONE neighbour (temporal_flow.py:222-237): its halves run as two in-process frame shards,
+    # half 0 handing its last frame's fused q|k to half 1 at every hooked flow layer (parallel.StreamShard)
+    _SPLIT_COUPLED = ("flow_fix",)
 
     def _split_plan(self, N: int):
         """Index tensors of the two frame halves of an N-sample batch (frames [0, F/2) and [F/2, F) of every chunk), or None when
         this forward has to stay whole: one stream asked for, frames sharded over ranks, a hook mode that couples frames
         (flow_fix's warp, temporal, adaIn), an odd frame count, or a batch too small to be worth two launch sequences."""
+        self._split_coupled = None
         if self.split_streams < 2 or self.halo_exchange is not None or N < 12:      # (8 samples: 11.75 vs 11.46 ms whole, profiles/r04_n)
             return None
-        chunks = 1
+        chunks, coupled = 1, []
         for kind, _, mod in self.unet.layer_table():
             if kind != "st":
                 continue
             cfg = getattr(mod.transformer_blocks[0].attn1, "_vface_cfg", None)
             if cfg is None or not cfg.switch_on or cfg.chunks not in (2, 3):
                 continue
-            if cfg.chunks == 3 and cfg.fusion not in self._SPLIT_SAFE:
+            if cfg.chunks == 3 and cfg.fusion in self._SPLIT_COUPLED and os.environ.get("VFACE_SPLIT_COUPLED", "1") != "0":
+                if cfg.flow is not None:
+                    if coupled and coupled[0].flow is not cfg.flow:
+                        return None          # (two different flow tensors in one forward: one halo field cannot serve both)
+                    if not any(c is cfg for c in coupled):
+                        coupled.append(cfg)
+            elif cfg.chunks == 3 and cfg.fusion not in self._SPLIT_SAFE:
                 return None
             there = cfg.chunks if self.live_chunks is None else self.live_chunks
             if chunks not in (1, there):
@@ -1176,6 +1206,9 @@ class UNetEngine:
             chunks = there
         if N % chunks or (N // chunks) % 2:
             return None
+        if coupled and coupled[0].flow.shape[0] != N // chunks - 1:
+            return None                      # (plan_fusion will raise on it: leave the whole batch to say so)
+        self._split_coupled = coupled or None
         key = (N, chunks)
         plan = self._split_state.get(("plan",) + key)
         if plan is None:
@@ -1253,15 +1286,46 @@ class UNetEngine:
         if probe:
             ev[0].record(cur)
         outs = []
-        for h, idx in enumerate(plan):
-            s = st["streams"][h]
-            s.wait_stream(cur)
-            with torch.cuda.stream(s), hip.workspace_domain(h + 1):
-                if probe:
-                    ev[1 + 2 * h].record(s)
-                outs.append(self._step_forward_one(Act(st["x"][h], len(idx), x.H, x.W), st["t"][h], st["ctx"][h]))
-                if probe:
-                    ev[2 + 2 * h].record(s)
+        coupled = self._split_coupled
+        halves = None
+        if coupled:
+            # flow_fix: the halves as two in-process frame shards (parallel.StreamShard).  Per half: its own exchange object, the flow
+            # fields between ITS frames, and -- half 1 -- the field from half 0's last frame into its first.  The slices are kept
+            # (one object per flow tensor and half): the graphs' private flow copies are refreshed by tensor identity.
+            from .parallel import StreamShard
+            fl = coupled[0].flow
+            F_all = fl.shape[0] + 1
+            fkey = (id(fl), fl._version)
+            if st.get("flow_key") != fkey:
+                st["flow_key"], st["flow_keep"] = fkey, fl
+                st["flow_slices"] = [fl[:F_all // 2 - 1], fl[F_all // 2:]]
+                st["flow_halo"] = fl[F_all // 2 - 1]
+            if "shard_objs" not in st:
+                shared = {}
+                st["shard_objs"] = [StreamShard(h, 2, F_all, shared) for h in range(2)]
+            halves = [(st["shard_objs"][h], st["flow_slices"][h] if st["flow_slices"][h].shape[0] else None,
+                       st["flow_halo"] if h else None) for h in range(2)]
+        saved = (self.halo_exchange, self.halo_flow, self.halo_hw, [(c, c.flow) for c in (coupled or [])])
+        try:
+            for h, idx in enumerate(plan):
+                s = st["streams"][h]
+                s.wait_stream(cur)
+                if halves is not None:
+                    shard, lflow, hflow = halves[h]
+                    self.halo_exchange, self.halo_flow = shard, hflow
+                    self.halo_hw = (int(saved[3][0][1].shape[-2]), int(saved[3][0][1].shape[-1]))
+                    for c, _ in saved[3]:
+                        c.flow = lflow
+                with torch.cuda.stream(s), hip.workspace_domain(h + 1):
+                    if probe:
+                        ev[1 + 2 * h].record(s)
+                    outs.append(self._step_forward_one(Act(st["x"][h], len(idx), x.H, x.W), st["t"][h], st["ctx"][h]))
+                    if probe:
+                        ev[2 + 2 * h].record(s)
+        finally:
+            self.halo_exchange, self.halo_flow, self.halo_hw = saved[0], saved[1], saved[2]
+            for c, f in saved[3]:
+                c.flow = f
         for s in st["streams"]:
             cur.wait_stream(s)
         if probe:

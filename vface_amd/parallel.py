@@ -51,6 +51,12 @@ class FrameShard:
         if world > 1 and dist is None:
             raise ValueError("world_size > 1 needs torch.distributed")
 
+    def set_index(self, k: int) -> None:
+        """Ordinal of the NEXT exchange inside its UNet forward (0 = the first hooked flow layer, 1 = the second ..): the engine
+        states it before every ``start_exchange`` -- eagerly and from the host calls between hipGraph segments alike -- so that an
+        exchange object that keeps per-layer state (``StreamShard``) never has to infer it from call counts."""
+        self.index = int(k)
+
     # ---- flow bookkeeping: global flow[i] maps frame i -> frame i+1 (temporal_flow.py:163-188, F-1 fields)
     def local_flow(self, global_flow: torch.Tensor) -> torch.Tensor:
         """Fields between consecutive frames INSIDE this shard: ``[count-1, 2, h, w]``."""
@@ -213,3 +219,63 @@ class LoopbackShard(FrameShard):
 
     def agree(self, ok: bool, over_budget: bool = False):
         return bool(ok), bool(over_budget)      # one process: its own verdict is everybody's
+
+
+class StreamShard(FrameShard):
+    """The two frame halves of ONE batch on one GPU as two shards that run AT THE SAME TIME on two HIP streams (the engine's two
+    launch streams under ``flow_fix``, whose warp reads the previous frame: UNetEngine._step_forward_split).  Half 0 hands the
+    fused q|k of its last frame to half 1 at every hooked flow layer, through device memory and an event:
+
+      half 0, on its stream:  slab -> slot[k] (device copy), then record event[k]            (start_exchange)
+      half 1, on its stream:  wait for event[k]; the warp (or the graph's receive buffer) then reads slot[k]   (finish_exchange)
+
+    What makes this hand-over safe, each a hazard the form withdrawn in round 4 may have had (its code was never committed):
+    * one slot and one event PER exchange ordinal k (``set_index``), never one re-used slot: half 0 does not wait for half 1, so it
+      reaches the second hooked layer and stores its slab there while half 1 may not yet have consumed the first;
+    * the ordinal is STATED by the engine, not counted here: a capturing call runs the forward three times (warm-up, capture
+      pass, first replay), a replay once -- a counter drifts between the two;
+    * half 0's host calls of a step are all enqueued BEFORE half 1's (the engine walks the halves in order), so when half 1
+      enqueues its wait the event's latest record IS this step's: a wait enqueued before that record would refer to the previous
+      step's and return at once -- reading the previous step's slab (the ~1e-3-sized, frame-3-then-5 difference of
+      gpurun_out/r4E_t.log is what a stale slab produces after three DDIM steps);
+    * slot[k] is re-written only by the next step's half 0, which starts after this step's join (both streams waited for);
+    * slots and events are allocated once and never freed (no caching-allocator re-use across streams);
+    * every stream-ordered call here goes to ``torch.cuda.current_stream()``: the warm-up forward of a capture runs on a side
+      stream, the capture pass's real exchanges on the capturing stream, replays on the half's launch stream."""
+
+    def __init__(self, rank: int, world: int, total_frames: int, shared: dict):
+        super().__init__(rank, world, total_frames, dist=object() if world > 1 else None)
+        self.shared = shared            # {"slots": {(rank, k): tensor}, "events": {(rank, k): Event}} of the batch's shards
+        self.shared.setdefault("slots", {})
+        self.shared.setdefault("events", {})
+        self.index = 0
+
+    def start_exchange(self, tail: torch.Tensor, recv=None):
+        if self.world == 1:
+            return None
+        k = self.index
+        if self.rank + 1 < self.world:
+            key = (self.rank, k)
+            slot = self.shared["slots"].get(key)
+            if slot is None or slot.shape != tail.shape or slot.dtype != tail.dtype:
+                slot = self.shared["slots"][key] = torch.empty(tail.shape, dtype=tail.dtype, device=tail.device)
+            slot.copy_(tail)
+            ev = self.shared["events"].get(key)
+            if ev is None:
+                ev = self.shared["events"][key] = torch.cuda.Event()
+            ev.record()                                   # on the current stream, behind the copy
+        return ("stream", k, None)
+
+    def finish_exchange(self, handle):
+        if handle is None or self.rank == 0:
+            return None
+        key = (self.rank - 1, handle[1])
+        ev = self.shared["events"].get(key)
+        if ev is None:
+            raise RuntimeError(f"StreamShard: half {self.rank} reached exchange {handle[1]} before half {self.rank - 1} issued it "
+                               "(the halves must be enqueued in order)")
+        torch.cuda.current_stream().wait_event(ev)
+        return self.shared["slots"][key]
+
+    def agree(self, ok: bool, over_budget: bool = False):
+        return bool(ok), bool(over_budget)      # one process; a half that runs eagerly still makes the same exchange calls
