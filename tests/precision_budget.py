@@ -28,9 +28,10 @@ from vface_amd.utils import synth  # noqa: E402
 class Emu:
     """rounding switches: w16 (weights), act16 (branch activations = MFMA operands), stream16 (residual carriers)."""
 
-    def __init__(self, sd, w16=True, act16=True, stream16=True, half=torch.float16, w16_filter=None, gn_in16=False):
+    def __init__(self, sd, w16=True, act16=True, stream16=True, half=torch.float16, w16_filter=None, gn_in16=False, gn_in16_filter=None):
         self.half = half
-        self.gn_in16 = gn_in16     # GroupNorm-apply fused into the conv's operand path reads the 16-bit copy of the stream
+        self.gn_in16 = gn_in16     # a ResBlock's in_layers GroupNorm normalises the 16-bit copy of its input (statistics stay fp32) ..
+        self.gn_in16_filter = gn_in16_filter      # .. in the ResBlocks whose state-dict prefix this predicate accepts (None: all)
         q = lambda t: t.to(half).float()
         self.a = q if act16 else (lambda t: t)
         self.s = q if stream16 else (lambda t: t)
@@ -51,7 +52,7 @@ def conv(c, x16, p, stride=1, pad=1):
 
 def res(c, l, x, emb_all):
     p = l.prefix
-    if c.gn_in16:   # statistics from the fp32 values (producer epilogue), normalisation applied to the rounded copy
+    if c.gn_in16 and (c.gn_in16_filter is None or c.gn_in16_filter(p)):   # statistics from the fp32 values (producer epilogue), normalisation applied to the rounded copy
         xr = c.a(x)
         N, C = x.shape[:2]
         xg = x.reshape(N, 32, -1)

@@ -414,6 +414,9 @@ class UNetEngine:
         self.fuse_temb = os.environ.get("VFACE_FUSE_TEMB", "1") != "0"
         # the UNet's `out` layer (GroupNorm -> SiLU -> conv3x3 to 4 channels) as one launch (csrc/outconv.hip).  VFACE_FUSE_OUT=0: A/B
         self.fuse_out = os.environ.get("VFACE_FUSE_OUT", "1") != "0"
+        # the concat buffers' fp32 carrier over all columns, read by the output blocks' GroupNorm (the layout up to round 4); default: the
+        # carrier covers the skip columns only and the concat GroupNorm reads the 16-bit copy (forward_nhwc).  VFACE_CONCAT32=1: A/B
+        self.concat32 = os.environ.get("VFACE_CONCAT32", "0") == "1"
         self._front_supported: Dict[tuple, bool] = {}
         self._ffn_supported: Dict[tuple, bool] = {}
         self.decompose_attn1 = False                   # bench.py's instrumented pass: vface_attn1_forward's launches call by call
@@ -647,6 +650,9 @@ class UNetEngine:
         return {"residual": x, "ldr": x.stride(0)}
 
     def _gn(self, x: Act, gn, eps: float, silu: bool) -> Act:
+        # (the fp32 carrier where there is one.  Reading the 16-bit copy in EVERY ResBlock -- 2 B per element instead of 4 -- was
+        #  measured in round 5: -0.1 ms of an 83 ms step for +0.6 % of the error budget, profiles/r05_h: not taken; the concat
+        #  GroupNorms, whose carrier had no other reader, do read 16 bits: forward_nhwc)
         src = x.src
         if x.cs is not None:
             st = hip.groupnorm_stats_from_cols(x.cs, nimg=x.N, hw=x.hw, C_=x.C, eps=eps)
@@ -965,7 +971,7 @@ class UNetEngine:
                           qk_map=self._map("qk_replace", N, F_) if fusion == hip.FUSION_REPLACE else None, v_map=v_map, **kw)
         if self.fuse_tail and p.get("tail_w") is not None and n % 128 == 0 and self._ffn_ok(M, c):
             # to_out + bias + attn2's row bias + residual -> norm3 -> FeedForward -> + x in ONE launch: t1 never exists in HBM
-            if self.fuse_post and p.get("tail_post") and post is not None and post[2] is not None:
+            if self.fuse_post and p.get("tail_post") and post is not None and (post[0] is not None or post[2] is not None):
                 hip.attn_out_ffn_proj_fused(att, t0, a2vec, p["tail_w"], p["wo"]["b"], p["ln3"][0], p["ln3"][1], p["ff1"]["b"], p["ff2p"],
                                             p["ff2"]["b"], p["proj_out"]["b"], x.t32, post[0], post[2], post[1], M=M, C_=c,
                                             rows_per_sample=n)
@@ -1119,17 +1125,25 @@ class UNetEngine:
             shapes.append((H, W, u.block_out_channels(block)))
         nb = len(blocks_in)
         h_ch = [u.block_out_channels(mid)] + [u.block_out_channels(b) for b in blocks_out[:-1]]
+        # The concat buffers.  An output block reads cat([h, skip]) twice: its ResBlock's in_layers GroupNorm and the 1x1 shortcut
+        # fused into its second convolution -- BOTH from the 16-bit copy (the statistics are the producers' column sums; rounding the
+        # GroupNorm's input costs nothing measurable: tests/precision_budget.py `gn_in16`, 1.2236e-3 vs 1.2273e-3 whole-UNet).  So the
+        # fp32 carrier exists for the SKIP columns only -- there it is the input path's residual stream, read by the next input
+        # block -- and the `h` columns (the previous output block's result, consumed by nothing else) are written once, 16-bit:
+        # 4 B per element less from their producers and 2 B less into every concat GroupNorm (6.5 GB per 96-sample step).
         cats, cats_cs, cats32 = [], [], []
         for j in range(nb):  # output block j consumes cat([h_{j}, skip_{nb-1-j}])
             sh, sw, sc = shapes[nb - 1 - j]
-            buf, cs, b32 = self._new_target(x.N * sh * sw, h_ch[j] + sc, sh * sw)
-            cats.append(buf)
-            cats_cs.append(cs)
-            cats32.append(b32)
+            rows = x.N * sh * sw
+            cats.append(self._new(rows, h_ch[j] + sc))
+            cats_cs.append(self._new_cs(rows, h_ch[j] + sc, sh * sw))
+            wide = self.concat32                 # (VFACE_CONCAT32=1, A/B: the carrier over ALL columns, read by the concat GroupNorm)
+            cats32.append(self._new(rows, (h_ch[j] + sc) if wide else sc, torch.float32) if (self.stream32 and sc % 8 == 0) else None)
 
-        def part(j, a, b):  # columns [a, b) of concat buffer j, of its statistics and of its fp32 carrier
-            cs, b32 = cats_cs[j], cats32[j]
-            return cats[j][:, a:b], (cs[:, a:b] if cs is not None else None), (b32[:, a:b] if b32 is not None else None)
+        def part(j, a, b):  # columns [a, b) of concat buffer j, of its statistics and (skip columns only) of its fp32 carrier
+            cs, b32, hc = cats_cs[j], cats32[j], (0 if self.concat32 else h_ch[j])
+            return (cats[j][:, a:b], (cs[:, a:b] if cs is not None else None),
+                    (b32[:, a - hc:b - hc] if (b32 is not None and a >= hc) else None))
 
         h = x
         for i, block in enumerate(blocks_in):
@@ -1138,7 +1152,7 @@ class UNetEngine:
         h = run(mid, h, part(0, 0, h_ch[0]))
         for j, block in enumerate(blocks_out):
             sh, sw, _ = shapes[nb - 1 - j]
-            inp = Act(cats[j], x.N, sh, sw, cats_cs[j], cats32[j])
+            inp = Act(cats[j], x.N, sh, sw, cats_cs[j], cats32[j] if self.concat32 else None)
             tgt = part(j + 1, 0, h_ch[j + 1]) if j + 1 < nb else None
             h = run(block, inp, tgt)
         oc = P["out.conv"]
@@ -1379,7 +1393,7 @@ class UNetEngine:
                                              None if self.halo_flow is None else tuple(self.halo_flow.shape))
         # (every switch that changes the captured launch sequence is part of the key: toggling one on a live engine must not
         # replay a stale graph)
-        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.fuse_post, self.fuse_temb, self.fuse_out, self.live_chunks,
+        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.fuse_post, self.fuse_temb, self.fuse_out, self.concat32, self.live_chunks,
                hip._ws_domain, self.decompose_attn1, self.exchange_events is not None, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)
