@@ -36,6 +36,7 @@ class Emu:
         self.a = q if act16 else (lambda t: t)
         self.s = q if stream16 else (lambda t: t)
         self.si = self.s           # rounding of a transformer block's INTERIOR running sums (t0, t1); default: as the stream
+        self.si_min_c = None       # .. applied only in blocks of at least this many channels (None: all)
         self.sd = {k: v.float() for k, v in sd.items()}
         self.sdh = {k: (q(v.float()) if (w16 and (w16_filter is None or w16_filter(k))) else v.float()) for k, v in sd.items()}
 
@@ -74,7 +75,8 @@ def st(c, l, x, context, registry, hw0):
     p = l.prefix
     B, C, H, W = x.shape
     g = c.a(F.group_norm(x, 32, c.f(p + ".norm.weight"), c.f(p + ".norm.bias"), 1e-6))
-    t0 = c.si(conv(c, g, p + ".proj_in", pad=0)).permute(0, 2, 3, 1).reshape(B, H * W, C)
+    si = c.si if (c.si_min_c is None or C >= c.si_min_c) else c.s      # (interior sums rounded only in blocks at least this wide)
+    t0 = si(conv(c, g, p + ".proj_in", pad=0)).permute(0, 2, 3, 1).reshape(B, H * W, C)
     tp = p + ".transformer_blocks.0"
     ln = lambda v, q: c.a(F.layer_norm(v, (C,), c.f(f"{tp}.{q}.weight"), c.f(f"{tp}.{q}.bias"), 1e-5))
     cfg = registry.get(f"{tp}.attn1") if registry else None
@@ -99,7 +101,7 @@ def st(c, l, x, context, registry, hw0):
     # attn2 on a single token == to_out(to_v(ctx)) broadcast, fp32 row bias
     a2 = F.linear(c.a(F.linear(c.a(context.reshape(B, -1)), c.w(f"{tp}.attn2.to_v.weight"))),
                   c.w(f"{tp}.attn2.to_out.0.weight"), c.f(f"{tp}.attn2.to_out.0.bias"))
-    t1 = c.si(F.linear(o, c.w(f"{tp}.attn1.to_out.0.weight"), c.f(f"{tp}.attn1.to_out.0.bias")) + a2[:, None, :] + t0)
+    t1 = si(F.linear(o, c.w(f"{tp}.attn1.to_out.0.weight"), c.f(f"{tp}.attn1.to_out.0.bias")) + a2[:, None, :] + t0)
     gg = F.linear(ln(t1, "norm3"), c.w(tp + ".ff.net.0.proj.weight"), c.f(tp + ".ff.net.0.proj.bias"))
     aa, gate = gg.chunk(2, dim=-1)
     ff = c.a(aa * F.gelu(gate))

@@ -1333,13 +1333,15 @@ def test_gemm_big_tile_equals_128_row_kernel_bit_for_bit(dt, M, N, K):
     a, w = rnd((M, K), 1, dt).to(DEV), rnd((N, K), 2, dt, 1 / math.sqrt(K)).to(DEV)
     bias = rnd((N,), 3, torch.float32).to(DEV)
     res32 = rnd((M, N), 6, torch.float32).to(DEV)
+    res16 = rnd((M, N), 8, dt).to(DEV)
     a0 = rnd((M, K // 2), 7, dt).to(DEV)
     wide = torch.zeros(M, K + 64, dtype=dt, device=DEV)
     wide[:, 32:32 + K] = a
     cases = [("plain", dict(), a.double() @ w.double().t()),
              ("bias", dict(bias=bias), a.double() @ w.double().t() + bias.double()),
              ("bias+res32", dict(bias=bias, residual32=res32), a.double() @ w.double().t() + bias.double() + res32.double()),
-             ("res32", dict(residual32=res32), a.double() @ w.double().t() + res32.double())]
+             ("res32", dict(residual32=res32), a.double() @ w.double().t() + res32.double()),
+             ("bias+res16", dict(bias=bias, residual=res16, ldr=N), a.double() @ w.double().t() + bias.double() + res16.double())]
     for name, kw, ref in cases:
         outs = []
         for fl in (h.TUNE_NO_BIG_TILE, h.TUNE_BIG_TILE):

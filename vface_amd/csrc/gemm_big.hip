@@ -22,8 +22,8 @@
 // * Operand roles, fragment layout and the per-accumulator MFMA order (K tile by K tile, half 0 then half 1) are gemm.hip's:
 //   the results are BIT-IDENTICAL to that kernel's, so which of the two a launch takes may depend on the batch (tests).
 // * Epilogues (template EPI): 0: + bias, round, transposed through LDS as 16-bit rows, 16-byte stores; 1: GEGLU (weight rows
-//   interleaved in 16-row value / gate blocks, packing.pack_geglu) the same way; 2: + bias + fp32 residual-stream rows, one
-//   rounding, transposed in fp32; 3: the fp32 residual-stream form -- + bias + per-sample row bias + fp32 residual rows -> fp32
+//   interleaved in 16-row value / gate blocks, packing.pack_geglu) the same way; 2: + bias + residual rows (the fp32 stream's, or
+//   16-bit ones), one rounding, transposed in fp32; 3: the fp32 residual-stream form -- + bias + per-sample row bias + fp32 residual rows -> fp32
 //   carrier (+ optional 16-bit copy, + optional per-64-row column statistics of the carrier), gemm.hip's NT = 5 epilogue on each
 //   80-channel half of the wave's tile.
 #include <type_traits>
@@ -382,11 +382,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         // residual rows as a RING of one row tile (40 registers): pass `it` of row tile i + 1 is requested the moment pass `it` of row
         // tile i has been summed -- five passes ahead of its use; two full row tiles in flight do not fit beside the accumulators
         f4_t r32[5][2];
+        const bool res16 = !p.res_f32;      // 16-bit residual rows (a block's interior running sum kept in 16 bits): one 16-byte load per chunk
         auto load_res = [&](int i, int it) {
             const long m = wrow0 + i * 16 + rr[it];
-            const unsigned off = m < p.M ? (unsigned)((m * p.ldr + ncol0 + cc[it] * 8) * 4) : OOB;
-            r32[it][0] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)off, 0, 0));
-            r32[it][1] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)off, 16, 0));
+            if (res16) {
+                const unsigned off = m < p.M ? (unsigned)((m * p.ldr + ncol0 + cc[it] * 8) * 2) : OOB;
+                const V8 h = __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)off, 0, 0));
+                r32[it][0] = f4_t{to_f32(h[0]), to_f32(h[1]), to_f32(h[2]), to_f32(h[3])};
+                r32[it][1] = f4_t{to_f32(h[4]), to_f32(h[5]), to_f32(h[6]), to_f32(h[7])};
+            } else {
+                const unsigned off = m < p.M ? (unsigned)((m * p.ldr + ncol0 + cc[it] * 8) * 4) : OOB;
+                r32[it][0] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)off, 0, 0));
+                r32[it][1] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rR, (int)off, 16, 0));
+            }
         };
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -468,7 +476,8 @@ bool vf_gemm_big_ok(const GemmParams& p) {
     }
     if (p.C && (((uintptr_t)p.C & 15) || (p.ldc & 7))) return false;
     if ((p.lda & 7) || (p.ldw & 7)) return false;
-    if (p.residual && (!p.res_f32 || (p.flags & GEMM_GEGLU) || ((uintptr_t)p.residual & 15) || (p.ldr & 3))) return false;
+    if (p.residual && ((p.flags & GEMM_GEGLU) || ((uintptr_t)p.residual & 15) || (p.ldr & (p.res_f32 ? 3 : 7)))) return false;
+    if (p.residual && !p.res_f32 && p.C32) return false;      // (16-bit residual rows: the 16-bit-output form only)
     if (p.bias && ((uintptr_t)p.bias & 15)) return false;
     return true;
 }
@@ -496,7 +505,7 @@ int vf_launch_gemm_big(const GemmParams& p_in, int dtype, hipStream_t stream) {
         // extents of the residual and output views for the epilogue's buffer descriptors (bytes; below 4 GiB - 16)
         const unsigned long nout = (p.flags & GEMM_GEGLU) ? (unsigned long)p.N / 2 : (unsigned long)p.N;
         const unsigned long cb = p.C ? ((unsigned long)(p.M - 1) * p.ldc + nout) * 2ul : 0ul;
-        const unsigned long rb = p.residual ? ((unsigned long)(p.M - 1) * p.ldr + p.N) * 4ul : 0ul;
+        const unsigned long rb = p.residual ? ((unsigned long)(p.M - 1) * p.ldr + p.N) * (p.res_f32 ? 4ul : 2ul) : 0ul;
         const unsigned long c32b = p.C32 ? ((unsigned long)(p.M - 1) * p.ldc32 + p.N) * 4ul : 0ul;
         if (cb >= 0xFFFFFFF0ul || rb >= 0xFFFFFFF0ul || c32b >= 0xFFFFFFF0ul) return VF_ERR_SHAPE;
         p.c_bytes = (unsigned)cb; p.res_bytes = (unsigned)rb; p.c32_bytes = (unsigned)c32b;

@@ -417,6 +417,7 @@ class UNetEngine:
         # the concat buffers' fp32 carrier over all columns, read by the output blocks' GroupNorm (the layout up to round 4); default: the
         # carrier covers the skip columns only and the concat GroupNorm reads the 16-bit copy (forward_nhwc).  VFACE_CONCAT32=1: A/B
         self.concat32 = os.environ.get("VFACE_CONCAT32", "0") == "1"
+        self.interior16 = os.environ.get("VFACE_INTERIOR16", "1") != "0"      # (see _st; VFACE_INTERIOR16=0: fp32 interior sums, A/B)
         self._front_supported: Dict[tuple, bool] = {}
         self._ffn_supported: Dict[tuple, bool] = {}
         self.decompose_attn1 = False                   # bench.py's instrumented pass: vface_attn1_forward's launches call by call
@@ -1019,8 +1020,13 @@ class UNetEngine:
                 self._gemm(t2, p["proj_out"], out, colstats=cs, hw=x.H * x.W, out32=o32, **self._resid(x))
             return Act(out, x.N, x.H, x.W, cs, o32)
         g = self._gn(x, p["gn"], 1e-6, False)
-        t0 = self._new(x.M, c, torch.float32 if s32 else None)
-        if s32:
+        # interior16: the block's INTERIOR running sums (t0 after proj_in, t1 after attention) of the 640- / 1280-channel blocks in 16
+        # bits -- 12 B per element less through HBM per block (proj_in, two LayerNorms, to_out's residual in and out, ff.net[2]'s
+        # residual); the main residual stream (x_in + proj_out) stays fp32.  Emulated cost on the whole UNet: 1.2400e-3 vs 1.2236e-3
+        # (tests/precision_budget.py `si_min_c`; the level-0 blocks, where it would cost 4x that, keep t1 in registers anyway)
+        wide = s32 and not (self.interior16 and c >= 640)
+        t0 = self._new(x.M, c, torch.float32 if wide else None)
+        if wide:
             self._gemm(g.t, p["proj_in"], None, hw=x.H * x.W, out32=t0)
         else:
             self._gemm(g.t, p["proj_in"], t0, hw=x.H * x.W)
@@ -1393,7 +1399,7 @@ class UNetEngine:
                                              None if self.halo_flow is None else tuple(self.halo_flow.shape))
         # (every switch that changes the captured launch sequence is part of the key: toggling one on a live engine must not
         # replay a stale graph)
-        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.fuse_post, self.fuse_temb, self.fuse_out, self.concat32, self.live_chunks,
+        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.fuse_post, self.fuse_temb, self.fuse_out, self.concat32, self.interior16, self.live_chunks,
                hip._ws_domain, self.decompose_attn1, self.exchange_events is not None, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)
