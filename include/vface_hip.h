@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VFACE_ABI_VERSION 5   /* 5: + vface_st_front, vface_attn_out_ffn_fused, vface_attn_out_ffn_proj_fused, vface_gn_silu_conv3x3_small, vface_linear_small; vface_attention's v_sets carries the live-set count in bits 8..15, vface_pack_unet_input / vface_ddim_step take the two-branch batch; nothing else of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
+#define VFACE_ABI_VERSION 6   /* 6: + the VFACE_TUNE_BIG_TILE / VFACE_TUNE_NO_BIG_TILE flag bits of vface_gemm (csrc/gemm_big.hip: the 256 x 320 tile, chosen by the library from 192 tiles on; same results), nothing else of 5 changed; 5: + vface_st_front, vface_attn_out_ffn_fused, vface_attn_out_ffn_proj_fused, vface_gn_silu_conv3x3_small, vface_linear_small; vface_attention's v_sets carries the live-set count in bits 8..15, vface_pack_unet_input / vface_ddim_step take the two-branch batch; nothing else of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
 
 #define VFACE_OK 0
 #define VFACE_ERR_ARG (-1)

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     for name in decls:
         assert hasattr(lib, name), f"{name} declared in include/vface_hip.h but not exported"
     lib.vface_abi_version.restype = ctypes.c_int
-    assert lib.vface_abi_version() == 5
+    assert lib.vface_abi_version() == 6
 
 
 def test_ctypes_table_matches_header():
@@ -326,8 +326,8 @@ def test_workspace_domain_nests_and_restores():
 
 
 def test_split_plan_halves_frames_across_chunks_and_refuses_coupled_modes():
-    """UNetEngine._split_plan (the two launch streams): frames [0, F/2) and [F/2, F) of EVERY chunk; hook modes that read another
-    frame (flow_fix, temporal, adaIn), odd frame counts, batches under 12 samples and sharded engines keep one launch sequence;
+    """UNetEngine._split_plan (the two launch streams): frames [0, F/2) and [F/2, F) of EVERY chunk; hook modes that read more than one
+    other frame (temporal, adaIn), odd frame counts, batches under 12 samples and sharded engines keep one launch sequence;
     a batch without its last chunk (live_chunks) is halved over the chunks it has."""
     from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler, HookPlan
     from vface_amd.ldm.models.diffusion.ddpm import LatentDiffusion
@@ -343,10 +343,21 @@ def test_split_plan_halves_frames_across_chunks_and_refuses_coupled_modes():
         a, b = (t.tolist() for t in eng._split_plan(24))
         assert a == [0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19] and b == [4, 5, 6, 7, 12, 13, 14, 15, 20, 21, 22, 23]
         assert eng._split_plan(9) is None and eng._split_plan(15) is None      # too small / odd frame count
-    for fusion in ("flow_fix", "temporal", "adaIn"):
+    for fusion in ("temporal", "adaIn"):
         sampler.hook_plan = HookPlan(fusion=fusion)
         sampler._register_step_hooks(None)
         assert eng._split_plan(24) is None, fusion
+    # flow_fix reads exactly one neighbour frame: its halves run as two coupled in-process shards (parallel.StreamShard, round 5);
+    # without a flow field it is "fft" (no coupling); a field count that does not match the frames keeps the batch whole
+    import torch
+    sampler.hook_plan = HookPlan(fusion="flow_fix")
+    sampler._register_step_hooks(None)
+    assert eng._split_plan(24) is not None and not eng._split_coupled
+    sampler._register_step_hooks(torch.zeros(7, 2, 4, 4))
+    a, b = (t.tolist() for t in eng._split_plan(24))
+    assert a == [0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19] and len(eng._split_coupled) == 1
+    sampler._register_step_hooks(torch.zeros(5, 2, 4, 4))
+    assert eng._split_plan(24) is None
     sampler.hook_plan = HookPlan(fusion="replace", enabled=False)
     sampler._register_step_hooks(None)
     a, b = (t.tolist() for t in eng._split_plan(16))                            # unhooked (inversion): plain halves

@@ -17,7 +17,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != c:
             continue
-        m = re.search(r"(conv_patch_kernel|gemm_kernel|ffn_fused_kernel|st_front_kernel|attn_kernel|gn_apply_kernel|layernorm_kernel|splitk_reduce_kernel|gn_silu_conv3x3_small_kernel|linear_small_kernel)<([^>]*)>", r["Kernel_Name"])
+        m = re.search(r"(conv_patch_kernel|gemm256_kernel|gemm_kernel|ffn_fused_kernel|st_front_kernel|attn_kernel|gn_apply_kernel|layernorm_kernel|splitk_reduce_kernel|gn_silu_conv3x3_small_kernel|linear_small_kernel)<([^>]*)>", r["Kernel_Name"])
         key = (m.group(1) + "<" + m.group(2) + ">") if m else "other"
         agg[key].append(float(r["Counter_Value"]))
     res[c] = {k: (len(v), sum(v)) for k, v in agg.items()}

@@ -134,7 +134,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.vface_abi_version() != 5:
+    if lib.vface_abi_version() != 6:
         raise VFaceHipError("libvface_hip.so ABI version mismatch")
     _lib = lib
     return lib
