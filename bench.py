@@ -658,14 +658,31 @@ def main():
                                                   "--Base_dir", "/tmp/vface_bench_e2e", "--drop_dead_branches"])
             with contextlib.redirect_stdout(sys.stderr):
                 st2 = cli.run_synthetic(opt2)["batches"][-1]["stage_seconds"]
+            # ... and with the next batch's inversion beside this batch's sampling (--pipeline_inversion): three batches,
+            # the MIDDLE one is the steady state (its wall time: from the previous batch's last frame to its own)
+            opt3 = cli.build_parser().parse_args(["--synthetic", "--with_vae", "--raft_flow", "--paste_back", "--skip_save", "--n_frames", "24",
+                                                  "--n_samples", "8", "--fusion", "flow_fix", "--ddim_steps", str(a.ddim_steps),
+                                                  "--Base_dir", "/tmp/vface_bench_e2e", "--drop_dead_branches", "--pipeline_inversion"])
+            with contextlib.redirect_stdout(sys.stderr):
+                mid = cli.run_synthetic(opt3)["batches"][1]
             e2e = {"workload": "8 frames 512x512 -> 1024x1024 pasted frames: VAE encode, flow (7 pairs, 20 updates), 50-step inversion (2F "
                                "samples), 50-step sampling (flow_fix), VAE decode, paste-back incl. the background's VAE round trip; "
                                "synthetic weights and frames; conditioning encoders, face alignment and video I/O are not part of it",
                    "stage_seconds": st, "seconds_per_8_frames": tot, "frames_per_s": 8.0 / tot,
                    "with_drop_dead_branches": {"stage_seconds": st2, "seconds_per_8_frames": sum(st2.values()),
                                                "frames_per_s": 8.0 / sum(st2.values()),
-                                               "note": "the same pipeline with --drop_dead_branches (bit-identical frames)"}}
+                                               "note": "the same pipeline with --drop_dead_branches (bit-identical frames)",
+                                               "pipelined_inversion": {
+                                                   "stage_seconds": mid["stage_seconds"], "seconds_per_8_frames": sum(mid["stage_seconds"].values()),
+                                                   "frames_per_s": 8.0 / sum(mid["stage_seconds"].values()),
+                                                   "wall_seconds_incl_host_generation_of_the_synthetic_frames": mid["batch_wall_seconds"],
+                                                   "note": "+ --pipeline_inversion: batch k + 1's DDIM inversion runs beside batch k's sampling on two "
+                                                           "HIP streams (DDIMSampler.sample_while_inverting; frames bit-identical to the sequential "
+                                                           "order: tests/test_unet_gpu.py); the middle batch of three, the sum of its stages as "
+                                                           "above (the next batch's encoding and flow are stages of this one: they run before it "
+                                                           "samples), each stage's wall time with the GPU drained on both sides"}}}
             log(f"  {tot:.2f} s per 8 frames = {8.0 / tot:.2f} frames/s end to end: " + ", ".join(f"{k} {v * 1e3:.0f} ms" for k, v in st.items()))
+            log(f"  with --drop_dead_branches {8.0 / sum(st2.values()):.2f} frames/s; + --pipeline_inversion {8.0 / sum(mid['stage_seconds'].values()):.2f} frames/s")
         except Exception as ex:       # an extra never costs the metric line
             e2e = {"error": f"{type(ex).__name__}: {ex}"}
             log(f"  end-to-end extra failed: {e2e['error']}")

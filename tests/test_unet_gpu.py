@@ -25,6 +25,15 @@ DEV = "cuda"
 SMALL = ounet.UNetSpec(model_channels=64)
 
 
+def _diff_pattern(a, b):
+    """Which frames / how many elements / how large: enough to tell a stale or torn boundary slab (frame F/2 first, later frames
+    only after further DDIM steps; rounding-sized) from an ordering bug in a half's own work (any frame of that half) at one look."""
+    d = (a.double() - b.double()).abs()
+    per = [(i, int((d[i] > 0).sum()), float(d[i].max()), float(d[i].max() / b[i].double().abs().max().clamp_min(1e-30)))
+           for i in range(a.shape[0]) if bool((d[i] > 0).any())]
+    return "; ".join(f"frame {i}: {n} elements differ, max abs {m:.3e} (rel {r:.1e})" for i, n, m, r in per) or "equal"
+
+
 def small_cfg(mc=64):
     return dict(image_size=32, in_channels=9, out_channels=4, model_channels=mc, attention_resolutions=[4, 2, 1],
                 num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
@@ -138,6 +147,31 @@ def test_standalone_functions_vs_reference_golden():
     for case in ("subpixel", "oob"):
         w = warp_image(img[:1].to(DEV), fl[case][None].to(DEV)).cpu()
         assert (w[0] - gw[f"warp_{case}"]).abs().max() < 6e-3, case
+
+
+@pytest.mark.parametrize("drop", [False, True])
+def test_cli_pipelined_inversion_is_bit_identical(tmp_path, drop):
+    """--pipeline_inversion (DDIMSampler.sample_while_inverting: batch k + 1's DDIM inversion beside batch k's sampling, on two
+    streams, hooks switched per step) writes the frames of the sequential order, bit for bit -- three batches (inversion alone,
+    two overlapped pairs, sampling alone), shipped hook schedule incl. the flow warp, with and without dead-branch elimination."""
+    import yaml
+    from vface_amd.scripts import VFace_inference_batch as cli
+    cfg = {"model": {"params": {"unet_config": {"params": small_cfg()}}}}
+    ypath = tmp_path / "small.yaml"
+    ypath.write_text(yaml.safe_dump(cfg))
+    outs = {}
+    for mode in ("seq", "pipe"):
+        args = ["--synthetic", "--config", str(ypath), "--n_frames", "12", "--n_samples", "4", "--H", "256", "--W", "256", "--max_steps", "3",
+                "--fusion", "flow_fix", "--flow_gate", "flow_hw", "--Base_dir", str(tmp_path / mode), "--ddim_steps", "50"]
+        args += ["--pipeline_inversion"] if mode == "pipe" else []
+        args += ["--drop_dead_branches"] if drop else []
+        res = cli.main(args)
+        assert len(res["batches"]) == 3 and all(b["finite"] for b in res["batches"])
+        if mode == "pipe":
+            assert [("sampling_beside_next_inversion" in b["stage_seconds"]) for b in res["batches"]] == [True, True, False]
+        outs[mode] = [torch.load(tmp_path / mode / f"samples_batch{k}.pt") for k in range(3)]
+    for k in range(3):
+        assert torch.equal(outs["seq"][k], outs["pipe"][k]), f"batch {k}: pipelined != sequential ({_diff_pattern(outs['pipe'][k], outs['seq'][k])})"
 
 
 def test_cli_synthetic_smoke(tmp_path):
@@ -517,15 +551,6 @@ def test_hipgraph_replay_equals_kernel_by_kernel_launches(small):
     finally:
         sampler.hook_plan, eng.use_graph, eng._graphs = old_plan, old_flag, {}
         sampler.make_schedule(50, ddim_eta=0.0, verbose=False)
-
-
-def _diff_pattern(a, b):
-    """Which frames / how many elements / how large: enough to tell a stale or torn boundary slab (frame F/2 first, later frames
-    only after further DDIM steps; rounding-sized) from an ordering bug in a half's own work (any frame of that half) at one look."""
-    d = (a.double() - b.double()).abs()
-    per = [(i, int((d[i] > 0).sum()), float(d[i].max()), float(d[i].max() / b[i].double().abs().max().clamp_min(1e-30)))
-           for i in range(a.shape[0]) if bool((d[i] > 0).any())]
-    return "; ".join(f"frame {i}: {n} elements differ, max abs {m:.3e} (rel {r:.1e})" for i, n, m, r in per) or "equal"
 
 
 @pytest.mark.parametrize("fusion", ["replace", "fft", "mix", "none", "flow_fix"])

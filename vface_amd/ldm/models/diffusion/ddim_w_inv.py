@@ -136,6 +136,23 @@ class DDIMSampler(object):
                       x0=None, img_callback=None, log_every_t=100, temperature=1., noise_dropout=0.,
                       score_corrector=None, flow=None, corrector_kwargs=None, unconditional_guidance_scale=1.,
                       unconditional_conditioning=None, src_im=None, max_steps=None, **kwargs):
+        state, steps = self._sampling_plan(cond, shape, target_conditioning=target_conditioning, inverse_results_dir=inverse_results_dir,
+                                           x_T=x_T, ddim_use_original_steps=ddim_use_original_steps, callback=callback,
+                                           quantize_denoised=quantize_denoised, mask=mask, x0=x0, img_callback=img_callback,
+                                           log_every_t=log_every_t, temperature=temperature, noise_dropout=noise_dropout,
+                                           score_corrector=score_corrector, flow=flow, unconditional_guidance_scale=unconditional_guidance_scale,
+                                           unconditional_conditioning=unconditional_conditioning, max_steps=max_steps, **kwargs)
+        for _ in steps:
+            pass
+        return state["img"], state["intermediates"]
+
+    def _sampling_plan(self, cond, shape, target_conditioning=None, inverse_results_dir=None, x_T=None,
+                       ddim_use_original_steps=False, callback=None, quantize_denoised=False, mask=None, x0=None,
+                       img_callback=None, log_every_t=100, temperature=1., noise_dropout=0., score_corrector=None, flow=None,
+                       unconditional_guidance_scale=1., unconditional_conditioning=None, max_steps=None, **kwargs):
+        """The sampling loop (ddim_w_inv.py:254-355) as ``(state, generator)``: every ``next()`` enqueues ONE DDIM step (hook
+        registration :303,305 included) and updates ``state["img"]``; ``ddim_sampling`` drives it to the end, and
+        ``sample_while_inverting`` interleaves it with the next batch's inversion loop."""
         if ddim_use_original_steps or mask is not None or quantize_denoised or score_corrector is not None:
             raise NotImplementedError("original-step sampling / masks / quantisation / score correctors are not used "
                                       "by scripts/VFace_inference_batch.py")
@@ -146,7 +163,7 @@ class DDIMSampler(object):
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
         img = img.contiguous()
         timesteps = self.ddim_timesteps
-        intermediates = {'x_inter': [img], 'pred_x0': [img]}
+        state = {"img": img, "intermediates": {'x_inter': [img], 'pred_x0': [img]}}
         time_range = np.flip(timesteps)
         total_steps = timesteps.shape[0]
         flow_dev = _dev_flow(flow, device)
@@ -159,25 +176,30 @@ class DDIMSampler(object):
             raise RuntimeError(f"The size of the flow field {tuple(flow_dev.shape[-2:])} must match the latent map "
                                f"{tuple(shape[-2:])} (temporal_flow.py:43: grid + flow)")
         self._register_step_hooks(flow_dev)  # the pre-loop registrations (:289,291) are overwritten before any UNet call
-        for i, step in enumerate(time_range):
-            if max_steps is not None and i >= max_steps:
-                break
-            self._register_step_hooks(flow_dev)
-            index = total_steps - i - 1
-            ts = torch.full((b,), int(step), device=device, dtype=torch.long)
-            img, pred_x0 = self.p_sample_ddim_with_inverse(
-                img, cond, ts, index=index, target_conditioning=target_conditioning,
-                inverse_results_dir=inverse_results_dir, temperature=temperature, noise_dropout=noise_dropout,
-                unconditional_guidance_scale=unconditional_guidance_scale, flow=flow_dev,
-                unconditional_conditioning=unconditional_conditioning, **kwargs)
-            if callback:
-                callback(i)
-            if img_callback:
-                img_callback(pred_x0, i)
-            if index % log_every_t == 0 or index == total_steps - 1:
-                intermediates['x_inter'].append(img)
-                intermediates['pred_x0'].append(pred_x0)
-        return img, intermediates
+
+        def steps():
+            img = state["img"]
+            for i, step in enumerate(time_range):
+                if max_steps is not None and i >= max_steps:
+                    break
+                self._register_step_hooks(flow_dev)
+                index = total_steps - i - 1
+                ts = torch.full((b,), int(step), device=device, dtype=torch.long)
+                img, pred_x0 = self.p_sample_ddim_with_inverse(
+                    img, cond, ts, index=index, target_conditioning=target_conditioning,
+                    inverse_results_dir=inverse_results_dir, temperature=temperature, noise_dropout=noise_dropout,
+                    unconditional_guidance_scale=unconditional_guidance_scale, flow=flow_dev,
+                    unconditional_conditioning=unconditional_conditioning, **kwargs)
+                if callback:
+                    callback(i)
+                if img_callback:
+                    img_callback(pred_x0, i)
+                if index % log_every_t == 0 or index == total_steps - 1:
+                    state["intermediates"]['x_inter'].append(img)
+                    state["intermediates"]['pred_x0'].append(pred_x0)
+                state["img"] = img
+                yield i
+        return state, steps()
 
     def _inv_latent(self, t: int, src, device):
         if isinstance(src, Mapping):
@@ -260,6 +282,19 @@ class DDIMSampler(object):
         """ddim_w_inv.py:360-490: hooks off, batch 2F = [target ; source], no guidance (the entry point passes
         ``unconditional_conditioning=None``); stores the target half per step -- into ``inverse_dir`` if it is a
         path (``ddim_latents_{t}.pt``, as the reference) or into it if it is a dict (device resident)."""
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=False)
+        state, steps = self._invert_plan(x, cond, shape, unconditional_guidance_scale=unconditional_guidance_scale,
+                                         unconditional_conditioning=unconditional_conditioning, inverse_dir=inverse_dir,
+                                         batch_size=batch_size, max_steps=max_steps, **kwargs)
+        for _ in steps:
+            pass
+        return state["x"], state["intermediates"]
+
+    def _invert_plan(self, x, cond, shape, unconditional_guidance_scale=1., unconditional_conditioning=None, inverse_dir=None,
+                     batch_size=6, max_steps=None, **kwargs):
+        """The inversion loop as ``(state, generator)`` on the schedule ``make_schedule`` has set: every ``next()`` switches the hooks
+        off (:389 -- again at every step, so that a sampling loop interleaved with this one may switch its own on in between),
+        enqueues ONE inversion step and stores the target half's latent."""
         if unconditional_conditioning is not None and unconditional_guidance_scale != 1.:
             raise NotImplementedError("guided inversion is not used by the VFace entry point (:540)")
         device = x.device
@@ -271,11 +306,7 @@ class DDIMSampler(object):
             if kw0 is not None:
                 kwargs = dict(kwargs, test_model_kwargs={k: (v[:batch_size] if torch.is_tensor(v) else v) for k, v in kw0.items()})
         b = x.shape[0]
-        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=False)
         timesteps = self.ddim_timesteps
-        intermediates = {'x_inter': [x]}
-        register_spa_attn_injection(self, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True,
-                                    attn_component="attn1", chunks=3)
         kw = kwargs.get('test_model_kwargs')
         if kw is None:
             raise Exception("ddim_invert needs test_model_kwargs (inpaint_image, inpaint_mask)")
@@ -285,28 +316,84 @@ class DDIMSampler(object):
         eng = unet.engine
         _, C, H, W = x.shape
         ac = self._alphas_cumprod_host
-        x = f32(x)
-        for i, step in enumerate(timesteps):
-            if max_steps is not None and i >= max_steps:
-                break
-            ts = torch.full((b,), int(step), device=device, dtype=torch.long)
-            x9 = torch.empty(b * H * W, 16, dtype=eng.dtype, device=device)
-            hip.nchw_to_nhwc(torch.cat([x, inpaint, mask], 1).contiguous(), x9, N=b, C_=9, hw=H * W, cpad=16)
-            eps = eng.step_forward_nhwc(Act(x9, b, H, W), ts, cond)
-            a_next = float(ac[int(step)])
-            cur = max(0, int(step) - (1000 // len(timesteps)))
-            a_cur = float(ac[cur])
-            # x <- (x - sqrt(1-a_cur) e) * sqrt(a_next)/sqrt(a_cur) + sqrt(1-a_next) e   (:449), as the DDIM update
-            # kernel with a_t = a_cur, a_prev = a_next, scale = 0 on an eps laid out [e ; e ; e]
-            x_new = torch.empty_like(x)
-            hip.ddim_step(eps, x, None, x_new, F=b, C_=C, hw=H * W, lde=eps.stride(0), scale=0.0, a_t=a_cur,
-                          a_prev=a_next, sigma_t=0.0, sqrt_one_minus_at=float(np.sqrt(np.float32(1.0) - np.float32(a_cur))),
-                          single_branch=True)
-            x = x_new
-            intermediates['x_inter'].append(x)
-            save = x[:batch_size].detach().clone()
-            if isinstance(inverse_dir, dict):
-                inverse_dir[int(step)] = save
-            elif inverse_dir is not None:
-                torch.save(save, os.path.join(inverse_dir, f"ddim_latents_{step}.pt"))
-        return x, intermediates
+        state = {"x": f32(x), "intermediates": {'x_inter': [x]}}
+
+        def steps():
+            x = state["x"]
+            for i, step in enumerate(timesteps):
+                if max_steps is not None and i >= max_steps:
+                    break
+                register_spa_attn_injection(self, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True,
+                                            attn_component="attn1", chunks=3)
+                ts = torch.full((b,), int(step), device=device, dtype=torch.long)
+                x9 = torch.empty(b * H * W, 16, dtype=eng.dtype, device=device)
+                hip.nchw_to_nhwc(torch.cat([x, inpaint, mask], 1).contiguous(), x9, N=b, C_=9, hw=H * W, cpad=16)
+                eps = eng.step_forward_nhwc(Act(x9, b, H, W), ts, cond)
+                a_next = float(ac[int(step)])
+                cur = max(0, int(step) - (1000 // len(timesteps)))
+                a_cur = float(ac[cur])
+                # x <- (x - sqrt(1-a_cur) e) * sqrt(a_next)/sqrt(a_cur) + sqrt(1-a_next) e   (:449), as the DDIM update
+                # kernel with a_t = a_cur, a_prev = a_next, scale = 0 on an eps laid out [e ; e ; e]
+                x_new = torch.empty_like(x)
+                hip.ddim_step(eps, x, None, x_new, F=b, C_=C, hw=H * W, lde=eps.stride(0), scale=0.0, a_t=a_cur,
+                              a_prev=a_next, sigma_t=0.0, sqrt_one_minus_at=float(np.sqrt(np.float32(1.0) - np.float32(a_cur))),
+                              single_branch=True)
+                x = x_new
+                state["intermediates"]['x_inter'].append(x)
+                save = x[:batch_size].detach().clone()
+                if isinstance(inverse_dir, dict):
+                    inverse_dir[int(step)] = save
+                elif inverse_dir is not None:
+                    torch.save(save, os.path.join(inverse_dir, f"ddim_latents_{step}.pt"))
+                state["x"] = x
+                yield i
+        return state, steps()
+
+    # ------------------------------------------------------------------ inversion of the NEXT batch beside sampling of this one
+    @torch.no_grad()
+    def sample_while_inverting(self, sample_kwargs: dict, invert_kwargs: dict):
+        """``sample(**sample_kwargs)`` of one batch and ``ddim_invert(**invert_kwargs)`` of the NEXT batch, step by step on two HIP
+        streams at once.  The entry point's batches are independent (VFace_inference_batch.py:413, 529-553: a batch's inversion only
+        feeds its own sampling), so the two 50-step loops of consecutive batches can share the chip: one launch sequence each
+        (the engine's own two-stream split is off meanwhile), hooks switched per step (on for the sampling forward, off for the
+        inversion forward), results bit-identical to running the loops one after the other (tests).  Returns
+        ``((samples, intermediates), (x_inverted, intermediates))``."""
+        sk, ik = dict(sample_kwargs), dict(invert_kwargs)
+        S, eta = sk.pop("S"), sk.pop("eta", 0.)
+        if ik.pop("S") != S or ik.pop("eta", 0.) != eta:
+            raise ValueError("sample_while_inverting: both loops walk ONE schedule (the same S and eta)")
+        for k in ("callback", "normals_sequence", "quantize_x0", "corrector_kwargs", "verbose", "tar"):
+            sk.pop(k, None)
+        for k in ("src_lm", "tar_lm"):
+            ik.pop(k, None)
+        batch_size, (C, H, W) = sk.pop("batch_size"), sk.pop("shape")
+        ik.pop("shape", None)
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=False)
+        st_s, g_s = self._sampling_plan(sk.pop("conditioning"), (batch_size, C, H, W), **sk)
+        st_i, g_i = self._invert_plan(ik.pop("x"), ik.pop("cond"), None, **ik)
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_pipe_streams", None) is None:
+            self._pipe_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        eng = self.model.model.diffusion_model.engine
+        saved_split = eng.split_streams
+        eng.split_streams = 1          # the two loops ARE the two launch sequences
+        for s in self._pipe_streams:
+            s.wait_stream(cur)
+        try:
+            live = [True, True]
+            while any(live):
+                for n, (g, s) in enumerate(zip((g_s, g_i), self._pipe_streams)):
+                    if live[n]:
+                        # (its own split-K scratch: a scratch is used in order by the launches of ONE stream)
+                        with torch.cuda.stream(s), hip.workspace_domain(3 + n):
+                            try:
+                                next(g)
+                            except StopIteration:
+                                live[n] = False
+        finally:
+            eng.split_streams = saved_split
+            for s in self._pipe_streams:
+                cur.wait_stream(s)
+        for t in [st_s["img"], st_i["x"]] + (list(ik["inverse_dir"].values()) if isinstance(ik.get("inverse_dir"), dict) else []):
+            t.record_stream(cur)       # (allocated on a side stream, consumed on the caller's from here on)
+        return (st_s["img"], st_s["intermediates"]), (st_i["x"], st_i["intermediates"])

@@ -91,6 +91,9 @@ def build_parser() -> argparse.ArgumentParser:
                         "667,703-707,738; pnp_utils.py:136-142,195-199,255-256) -- and the inversion runs on the target half only "
                         "(only nosie[:batch_size] is saved, ddim_w_inv.py:464-486): -33 %% / -50 %% of the UNet work")
     p.add_argument("--max_steps", type=int, default=None, help="stop after this many DDIM steps (smoke runs)")
+    p.add_argument("--pipeline_inversion", action="store_true",
+                   help="run the DDIM inversion of batch k + 1 beside the sampling of batch k, on two HIP streams (the batches are "
+                        "independent: VFace_inference_batch.py:413, 529-553); frames bit-identical to the sequential order")
     return p
 
 
@@ -248,21 +251,29 @@ def run_synthetic(opt) -> dict:
     os.makedirs(opt.Base_dir, exist_ok=True)
     results, t_all = [], time.time()
     paster, raft = None, None
-    for batch_id in range(opt.n_frames // F_):  # DataLoader(batch_size=n_samples, drop_last=True) (:376-382)
+    nbatches = opt.n_frames // F_       # DataLoader(batch_size=n_samples, drop_last=True) (:376-382)
+    # --pipeline_inversion: the DDIM inversion of batch k + 1 runs beside the sampling of batch k (DDIMSampler.sample_while_inverting:
+    # the batches are independent, :413, :529-553); batch 0's inversion runs alone, the last batch's sampling too
+    pipelined = bool(getattr(opt, "pipeline_inversion", False)) and not opt.no_inversion and nbatches > 1
+
+    def stage(stages, name, t_start):      # wall seconds of a pipeline stage, GPU drained on both sides
+        torch.cuda.synchronize()
+        stages[name] = stages.get(name, 0.0) + time.time() - t_start
+        return time.time()
+
+    def prepare(batch_id):
+        """Everything of a batch up to (not including) its DDIM inversion: conditioning, VAE encoding, flow."""
+        nonlocal raft
         tag = lambda s: f"cli.{s}.{batch_id}"
         d = lambda t: t.to(dev)
         stages = {}
-
-        def stage(name, t_start):      # wall seconds of a pipeline stage, GPU drained on both sides
-            torch.cuda.synchronize()
-            stages[name] = stages.get(name, 0.0) + time.time() - t_start
-            return time.time()
         c, uc, tc = (d(synth.synth_normal(tag(k), (F_, 1, 768))) for k in ("c", "uc", "tc"))
+        img = None
         if opt.with_vae:
             img = d(torch.stack([synth.synth_normal(tag(f"img{f}"), (3, opt.H, opt.W)).clamp(-1, 1) for f in range(F_)]))
-            ts_ = stage("_", time.time())
+            ts_ = stage(stages, "_", time.time())
             z_inp = model.get_first_stage_encoding(model.encode_first_stage(img)).detach()       # :456-457
-            stage("vae_encode", ts_)
+            stage(stages, "vae_encode", ts_)
         else:
             z_inp = d(synth.synth_normal(tag("inp"), (F_, opt.C, h, w)) * 0.18215)
         mask = d(synth.synth_mask(F_, h, w))
@@ -278,16 +289,16 @@ def run_synthetic(opt) -> dict:
                 raft = raft.to(dev).eval()
             video = img if opt.with_vae else d(torch.stack([synth.synth_normal(tag(f"img{f}"), (3, opt.H, opt.W)).clamp(-1, 1)
                                                             for f in range(F_)]))
-            ts_ = stage("_", time.time())
+            ts_ = stage(stages, "_", time.time())
             flow = tflow.return_flow(video, raft)
-            stage("flow", ts_)
+            stage(stages, "flow", ts_)
             sampler.flow_resample = "area"
         elif opt.flow_pixels:   # a pixel-resolution field whose latent resample is a +-2-cell motion
             flow = [f[None] * opt.f for f in synth.synth_flow(F_ - 1, opt.H, opt.W, seed=opt.seed + batch_id)]
         else:
             flow = [f[None] for f in synth.synth_flow(F_ - 1, h, w, seed=opt.seed + batch_id)]
-        kw = {"inpaint_image": z_inp, "inpaint_mask": mask}
         inv_store = {}
+        invert_kw = None
         if opt.no_inversion:
             sampler.make_schedule(opt.ddim_steps, ddim_eta=opt.ddim_eta, verbose=False)
             for s in sampler.ddim_timesteps:
@@ -296,34 +307,59 @@ def run_synthetic(opt) -> dict:
             # :531-540: invert [target ; source] (2F), hooks off; the target half is cached per timestep
             z2 = d(synth.synth_normal(tag("z2"), (2 * F_, opt.C, h, w)))
             kw2 = {"inpaint_image": torch.cat([z_inp, z_inp]), "inpaint_mask": torch.cat([mask, mask])}
-            ts_ = stage("_", time.time())
-            sampler.ddim_invert(x=z2, cond=torch.cat([tc, c]), S=opt.ddim_steps, shape=[opt.C, h, w], eta=opt.ddim_eta,
-                                unconditional_guidance_scale=opt.scale, unconditional_conditioning=None,
-                                inverse_dir=inv_store, batch_size=F_, test_model_kwargs=kw2, max_steps=opt.max_steps)
-            stage("inversion", ts_)
+            invert_kw = dict(x=z2, cond=torch.cat([tc, c]), S=opt.ddim_steps, shape=[opt.C, h, w], eta=opt.ddim_eta,
+                             unconditional_guidance_scale=opt.scale, unconditional_conditioning=None,
+                             inverse_dir=inv_store, batch_size=F_, test_model_kwargs=kw2, max_steps=opt.max_steps)
+        return {"id": batch_id, "c": c, "uc": uc, "tc": tc, "z_inp": z_inp, "mask": mask, "flow": flow, "inv_store": inv_store,
+                "invert_kw": invert_kw, "inverted": invert_kw is None, "stages": stages}
+
+    def sample_kwargs(b):
         # :541 start code = the cached latent of the second-highest timestep ("ddim_latents_961.pt" at 50 steps)
         sampler.make_schedule(opt.ddim_steps, ddim_eta=opt.ddim_eta, verbose=False)
         ts = [int(s) for s in sampler.ddim_timesteps]
+        inv_store = b["inv_store"]
         start_t = ts[-2] if ts[-2] in inv_store else max(inv_store)
         x_T = inv_store[start_t]
         if opt.max_steps is not None:  # smoke runs: the remaining cache entries are never read
             for s in ts:
                 inv_store.setdefault(s, x_T)
+        return dict(S=opt.ddim_steps, conditioning=b["c"], target_conditioning=b["tc"], inverse_results_dir=inv_store, batch_size=F_,
+                    shape=[opt.C, h, w], verbose=False, unconditional_guidance_scale=opt.scale, unconditional_conditioning=b["uc"],
+                    eta=opt.ddim_eta, x_T=x_T, flow=b["flow"] if opt.fusion == "flow_fix" else None,
+                    test_model_kwargs={"inpaint_image": b["z_inp"], "inpaint_mask": b["mask"]}, max_steps=opt.max_steps)
+
+    cur = prepare(0)
+    torch.cuda.synchronize()
+    t_batch = time.time()       # a batch's wall time = from the previous batch's last frame to its own (its preparation included)
+    for batch_id in range(nbatches):
+        stages = cur["stages"]
+        if not cur["inverted"]:
+            ts_ = stage(stages, "_", time.time())
+            sampler.ddim_invert(**cur["invert_kw"])
+            stage(stages, "inversion", ts_)
+            cur["inverted"] = True
+        nxt = prepare(batch_id + 1) if (pipelined and batch_id + 1 < nbatches) else None
+        if nxt is not None:                      # (its encoding / flow are this batch's wall time: they run before this batch samples)
+            for k, v in nxt["stages"].items():
+                if k != "_":
+                    stages["next_" + k] = v
+            nxt["stages"] = {}
+        torch.cuda.synchronize()
         t0 = time.time()
-        samples, _ = sampler.sample(S=opt.ddim_steps, conditioning=c, target_conditioning=tc,
-                                    inverse_results_dir=inv_store, batch_size=F_, shape=[opt.C, h, w], verbose=False,
-                                    unconditional_guidance_scale=opt.scale, unconditional_conditioning=uc,
-                                    eta=opt.ddim_eta, x_T=x_T, flow=flow if opt.fusion == "flow_fix" else None,
-                                    test_model_kwargs=kw, max_steps=opt.max_steps)
+        if nxt is not None:
+            (samples, _), _ = sampler.sample_while_inverting(sample_kwargs(cur), nxt["invert_kw"])
+            nxt["inverted"] = True
+        else:
+            samples, _ = sampler.sample(**sample_kwargs(cur))
         torch.cuda.synchronize()
         dt_s = time.time() - t0
-        stages["sampling"] = dt_s
+        stages["sampling" if nxt is None else "sampling_beside_next_inversion"] = dt_s
         pixels = None
         if opt.with_vae:
             ts_ = time.time()
             x_samples = model.decode_first_stage(samples)                                          # :596
             pixels = torch.clamp((x_samples + 1.0) / 2.0, min=0.0, max=1.0)                       # :597
-            stage("vae_decode", ts_)
+            stage(stages, "vae_decode", ts_)
         pasted, paste_s = None, None
         if opt.paste_back:
             if not opt.with_vae:
@@ -353,12 +389,16 @@ def run_synthetic(opt) -> dict:
             torch.save(samples.cpu(), os.path.join(opt.Base_dir, f"samples_batch{batch_id}.pt"))
             if pixels is not None:
                 torch.save(pixels.cpu(), os.path.join(opt.Base_dir, f"pixels_batch{batch_id}.pt"))
-        results.append({"batch": batch_id, "frames": F_, "sample_seconds": dt_s,
+        torch.cuda.synchronize()
+        results.append({"batch": batch_id, "frames": F_, "sample_seconds": dt_s, "batch_wall_seconds": time.time() - t_batch,
+                        "samples": samples if getattr(opt, "return_samples", False) else None,
                         "finite": bool(torch.isfinite(samples).all()) and (pixels is None or bool(torch.isfinite(pixels).all())),
                         "pixels": None if pixels is None else list(pixels.shape),
                         "pasted": None if pasted is None else list(pasted.shape), "paste_seconds": paste_s,
                         "stage_seconds": {k: v for k, v in stages.items() if k != "_"}})
         print(f"batch {batch_id}: {F_} frames sampled in {dt_s:.2f} s")
+        t_batch = time.time()
+        cur = nxt if nxt is not None else (prepare(batch_id + 1) if batch_id + 1 < nbatches else None)
     return {"batches": results, "total_seconds": time.time() - t_all}
 
 
