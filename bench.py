@@ -114,7 +114,8 @@ class FamilyTimer:
     """HIP-event timing (on the launch stream) of every launch of the instrumented pass, by kernel family:
       conv       by kernel: `patch3` = conv_patch_kernel<3x3> (conv.hip), `patch2` = its 2x2 parity-phase form (four launches
                  per call), `patch8x8` = its 8x8 form (four images per workgroup; the time includes the split-K reduce pass),
-                 `im2col` = gemm.hip's implicit GEMM (stride 2, the 9->320 convolution); `out_fused` = outconv.hip (GroupNorm + SiLU +
+                 `im2col` = gemm.hip's implicit GEMM (stride 2); `in16` = inconv.hip (the 9 -> 320 input convolution, K = 144 in one
+                 MFMA pass, bound by its stores: FLOPs as executed over the 16 stored channels); `out_fused` = outconv.hip (GroupNorm + SiLU +
                  the 320->4 convolution in one launch, vector dot products: priced at its ALGORITHMIC 2 M 4 9 Cin FLOPs);
       gemm       gemm_kernel<T, MODE_PLAIN, ..>: every Linear / 1x1 conv, keyed by shape and epilogue form: `ff1_MxNxK` = the GEGLU projections,
                  `MxNxK+rb+r32+o32+cs+a2` the rest (row bias, fp32 residual rows in, fp32 carrier out, column statistics, dual-source K);
@@ -154,7 +155,10 @@ class FamilyTimer:
             VH, VW = (2 * H, 2 * W) if upsample else (H, W)
             OH, OW = (VH - 1) // stride + 1, (VW - 1) // stride + 1
             patch = 0 if (kw.get("flags", 0) & hip.EPI_OUT_F32) else hip.conv_uses_patch_kernel(H, W, cin, cout, 3, stride, upsample, kw.get("flags", 0))
-            timer._timed("conv", {1: "patch3", 2: "patch8x8"}.get(patch, "im2col"), 2.0 * nimg * OH * OW * cout * 9 * cin, 1, call)
+            kind = {1: "patch3", 2: "patch8x8"}.get(patch, "im2col")
+            if cin == 16 and stride == 1 and not upsample and not (OH * OW) % 64 and not OW % 16 and not cout % 80:
+                kind = "in16"      # (vf_conv_in16_ok's geometry: the UNet's input convolution on inconv.hip)
+            timer._timed("conv", kind, 2.0 * nimg * OH * OW * cout * 9 * cin, 1, call)
         hip.conv3x3 = conv3x3
         orig_up = hip.upsample2x_conv3x3
 

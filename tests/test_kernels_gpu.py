@@ -1425,3 +1425,46 @@ def test_gemm_big_tile_refuses_what_it_cannot_do():
             outs.append((o, o32, cs))
         for x, y in zip(*outs):
             assert torch.equal(x, y)
+
+
+# ------------------------------------------------------------------------------------------ the input convolution (csrc/inconv.hip)
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("nimg,H,W,cout", [(3, 64, 64, 320), (2, 32, 48, 160), (5, 16, 16, 80), (1, 8, 16, 400)])
+def test_input_conv_16_stored_channels(dt, nimg, H, W, cout):
+    """conv3x3 over 16 stored channels (openaimodel.py:639-645: the UNet's 9 -> 320 input convolution, channels zero-padded) on
+    csrc/inconv.hip -- K = 144 in one MFMA pass, outputs stored straight from the accumulator layout: the fp32 carrier against an
+    fp64 convolution (16-bit operands are exact there: only the fp32 accumulation order differs), the 16-bit copy = the carrier
+    rounded once, the per-64-pixel column statistics = the sums of the carrier, strided views with nothing written outside them,
+    and the generic-window kernel (VFACE_TUNE_NO_PATCH) to fp32 rounding."""
+    from vface_amd import packing
+    h = hip()
+    x = rnd((nimg, H, W, 16), 1, dt).to(DEV)
+    w = rnd((cout, 16, 3, 3), 2, dt, 1 / 12.0)
+    wp = packing.pack_conv3x3(w.float(), 16).to(device=DEV, dtype=dt)
+    assert wp.shape == (cout, 144)
+    bias = rnd((cout,), 3, torch.float32).to(DEV)
+    M = nimg * H * W
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double(), bias.double().cpu(), padding=1).permute(0, 2, 3, 1).reshape(M, cout)
+    outs = {}
+    for tag, fl in (("in16", 0), ("generic", h.TUNE_NO_PATCH)):
+        o16 = torch.full((M, cout + 32), 7.0, dtype=dt, device=DEV)
+        o32 = torch.full((M, cout + 8), 7.0, dtype=torch.float32, device=DEV)
+        cs = torch.full((M // 64, cout + 4, 2), 7.0, dtype=torch.float32, device=DEV)
+        h.conv3x3(x.reshape(M, 16), wp, o16[:, 16:16 + cout], nimg=nimg, H=H, W=W, cin=16, cout=cout, ldx=16, ldy=cout + 32, bias=bias,
+                  colstats=cs[:, 4:], out32=o32[:, 8:], flags=fl, split_k=False)
+        outs[tag] = (o16, o32, cs)
+        assert rel_l2(o32[:, 8:].double().cpu(), ref) < 2e-6, tag
+        assert torch.equal(o16[:, 16:16 + cout], o32[:, 8:].to(dt)), f"{tag}: the 16-bit copy is the carrier rounded once"
+        assert bool((o16[:, :16] == 7).all()) and bool((o16[:, 16 + cout:] == 7).all()) and bool((o32[:, :8] == 7).all()) and bool((cs[:, :4] == 7).all())
+        v = o32[:, 8:].double().reshape(M // 64, 64, cout)
+        assert torch.allclose(cs[:, 4:, 0].double(), v.sum(1), rtol=1e-5, atol=1e-4), tag
+        assert torch.allclose(cs[:, 4:, 1].double(), (v * v).sum(1), rtol=1e-5, atol=1e-4), tag
+    assert torch.allclose(outs["in16"][1], outs["generic"][1], rtol=1e-5, atol=2e-5)
+    # the carrier alone (no 16-bit copy, no statistics), and the copy alone
+    o32 = torch.empty(M, cout, dtype=torch.float32, device=DEV)
+    h.conv3x3(x.reshape(M, 16), wp, None, nimg=nimg, H=H, W=W, cin=16, cout=cout, ldx=16, ldy=0, bias=bias, out32=o32, split_k=False)
+    assert torch.equal(o32, outs["in16"][1][:, 8:])
+    o16 = torch.empty(M, cout, dtype=dt, device=DEV)
+    h.conv3x3(x.reshape(M, 16), wp, o16, nimg=nimg, H=H, W=W, cin=16, cout=cout, ldx=16, ldy=cout, split_k=False)
+    ref0 = ref - bias.double().cpu()
+    assert rel_l2(o16.double().cpu(), ref0) < (1e-3 if dt == torch.float16 else 8e-3)

@@ -1081,6 +1081,8 @@ int vf_launch_gemm(const GemmParams& p_in, int dtype, hipStream_t stream) {
         if (gb >= 0xFFFFFFF0ul) return VF_ERR_SHAPE;
         p.gn_ab_bytes = (unsigned)gb;
     }
+    // the UNet's 9 (16 stored) -> 320 input convolution: K = 144 in one MFMA pass, bound by its stores (inconv.hip)
+    if (vf_conv_in16_ok(p)) return vf_launch_conv_in16(p, dtype, stream);
     int karg = 0;
     const int kchoice = vf_conv_kernel_choice(p, &karg);      // (conv.hip: the one statement of the rule)
     if (kchoice == 1) return vf_launch_conv_patch(p, dtype, stream);

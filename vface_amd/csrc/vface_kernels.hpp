@@ -86,6 +86,8 @@ int vf_launch_gemm_patch(const GemmParams& p, int dtype, hipStream_t stream);
 bool vf_gemm_big_ok(const GemmParams& p);
 bool vf_gemm_big_choice(const GemmParams& p);                                  // ... and the rule says it should                                      // gemm_big.hip: the 256 x 320 tile takes this plain-GEMM launch
 int vf_launch_gemm_big(const GemmParams& p, int dtype, hipStream_t stream);
+bool vf_conv_in16_ok(const GemmParams& p);                                       // inconv.hip: the 16-stored-channel input convolution (K = 144 in one MFMA pass)
+int vf_launch_conv_in16(const GemmParams& p, int dtype, hipStream_t stream);
 int vf_conv_q8_split(const GemmParams& p);                                      // the 8x8 level through the patch kernel: 0 | K split
 int vf_launch_conv_q8(const GemmParams& p, int dtype, hipStream_t stream);     // (main pass only: the caller runs the split-K reduce)
 bool vf_attention_shared_scores_supported(int dh, int v_sets);
