@@ -161,9 +161,22 @@ __global__ __launch_bounds__(512, 2) void conv_patch_kernel(GemmParams p) {
     }
 
     const int nchunks_all = p.Cin >> 6;
-    // Q8: this workgroup's share of K = channel chunks [c_begin, nchunks) (the fused 1x1 source goes with the last share)
-    const int c_begin = Q8 ? (int)(((long)sk * nchunks_all) / p.split_k) : 0;
-    const int nchunks = Q8 ? (int)(((long)(sk + 1) * nchunks_all) / p.split_k) : nchunks_all;
+    // Q8: this workgroup's share of K = channel chunks [c_begin, nchunks); the fused 1x1 source goes with the last share, so the
+    // chunk boundaries are placed on the K TILES of window + 1x1 source together (a 1280-channel window with a 2560-channel
+    // shortcut: 180 + 40 tiles = 54 | 54 | 54 | 58 over four shares; equal chunk counts made it 45 | 45 | 45 | 85 and the launch as
+    // long as its last share).  Every share keeps at least one chunk; geometry only: the same split for every batch.
+    int c_begin = 0, nchunks = nchunks_all;
+    if constexpr (Q8) {
+        const long total = (long)nchunks_all * TAPS + ((TAIL && p.A2) ? ((p.K - p.K1) >> 6) : 0);
+        int prev = 0;
+        for (int k = 1; k <= p.split_k; ++k) {
+            int b = k == p.split_k ? nchunks_all : (int)((k * total / p.split_k + TAPS / 2) / TAPS);
+            b = min(max(b, prev + 1), nchunks_all - (p.split_k - k));
+            if (k == sk) c_begin = b;
+            if (k == sk + 1) { nchunks = b; break; }
+            prev = b;
+        }
+    }
     const int kt0 = c_begin * TAPS;                       // global index of this workgroup's first K tile (weight columns)
     const int T1 = (nchunks - c_begin) * TAPS;            // K tiles of the window
     const int ntail = (TAIL && p.A2 && (!Q8 || sk == p.split_k - 1)) ? ((p.K - p.K1) >> 6) : 0;     // K tiles of the fused 1x1 source
