@@ -1468,3 +1468,46 @@ def test_input_conv_16_stored_channels(dt, nimg, H, W, cout):
     h.conv3x3(x.reshape(M, 16), wp, o16, nimg=nimg, H=H, W=W, cin=16, cout=cout, ldx=16, ldy=cout, split_k=False)
     ref0 = ref - bias.double().cpu()
     assert rel_l2(o16.double().cpu(), ref0) < (1e-3 if dt == torch.float16 else 8e-3)
+
+
+@pytest.mark.parametrize("dh,n,B", [(40, 1100, 3), (80, 640, 2), (160, 256, 3), (160, 300, 2), (160, 128, 2)])
+def test_attention_wave_count_and_query_tiling_do_not_change_bits(dh, n, B):
+    """The plain attention kernel's launch forms -- eight waves per workgroup (dh = 40: the default since round 5; variant bit 3 =
+    four) and dh = 160's three forms by map size -- walk the same key blocks per query in the same order: same bits on ordinary
+    inputs.  (On inputs that trip the speculative reference the RERUN is a workgroup's decision, so a query's bits may depend on
+    which queries share its workgroup -- a function of the map, never of the batch: there every form is held to the fp64 attention
+    instead.)"""
+    h = hip()
+    dt, heads = torch.float16, 8
+    d = heads * dh
+    scale = dh ** -0.5
+    kw = dict(B=B, heads=heads, n=n, nk=n, dh=dh, ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d, bsv=n * 3 * d, ldo=d, bso=n * d,
+              scale=scale)
+    base = rnd((B, n, 3 * d), 31, dt)
+    peaked = base.clone()
+    peaked[..., :d] *= 5.0
+    spike = base.clone()
+    spike[:, n - 3, d:2 * d] *= 40.0                 # one late key far above everything the first block saw
+    for name, qkv in (("plain", base), ("peaked", peaked), ("spike", spike)):
+        qd = qkv.to(DEV)
+        outs = {}
+        for variant in (0, 8) if dh != 160 else (0,):
+            out = torch.zeros(B, n, d, dtype=dt, device=DEV)
+            h.attention(qd, qd[:, :, d:], qd[:, :, 2 * d:], out, variant=variant, **kw)
+            outs[variant] = out
+        if dh == 160:
+            # the forms are chosen by the map size: the same queries as part of a longer / shorter query set (keys unchanged) take
+            # another form -- rows [0, 64) of this call against a call that only asks for those
+            out = outs[0]
+            kw64 = dict(kw, n=64)
+            part = torch.zeros(B, 64, d, dtype=dt, device=DEV)
+            h.attention(qd, qd[:, :, d:], qd[:, :, 2 * d:], part, **dict(kw64, ldo=d, bso=64 * d))
+            assert torch.equal(out[:, :64], part), name
+        elif name == "plain":
+            assert torch.equal(outs[0], outs[8]), name
+        sp = lambda t: t.reshape(B, n, heads, dh).permute(0, 2, 1, 3).double()
+        s_ = sp(qkv[..., :d]) @ sp(qkv[..., d:2 * d]).transpose(-1, -2) * scale
+        ref = (torch.softmax(s_, -1) @ sp(qkv[..., 2 * d:])).permute(0, 2, 1, 3).reshape(B, n, d).float()
+        for variant, out in outs.items():
+            assert torch.isfinite(out).all(), (name, variant)
+            assert rel_l2(out.float().cpu(), ref) < (1e-3 if name == "plain" else 3e-3), (name, variant)

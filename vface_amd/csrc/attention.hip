@@ -62,13 +62,15 @@ constexpr int v_pitch_bytes32(int dvp) {
 // costs more than the issue slots it returns -- the two co-resident workgroups' matrix and vector phases do not overlap as
 // freely as that budget assumed.  Kept behind variant bit 2 as a tested A/B form, never chosen by the dispatcher.
 // NWV: waves per workgroup, 4 or 8: eight waves share one staged K / V block, so a wave issues half the LDS-DMA pieces per block
-// and the K / V stream through L2 halves, for a barrier across eight waves instead of four.  Measured: nothing for the plain dh = 40
-// kernel (665 vs 665 us; variant bit 3 selects it there), -5 % for the shared-score form, which takes it by default.
+// and the K / V stream through L2 halves, for a barrier across eight waves instead of four.  Measured: -5 % for the shared-score
+// form (round 3), -3 ... -12 % for the plain dh = 40 kernel since its speculative reference (round 5; equal before it), slower for
+// dh = 80 (353 vs 329 us); both dh = 40 forms take it by default (variant bit 3: four waves).  dh = 160 at 256 keys takes it with
+// two query tiles per wave: ONE workgroup per (sample, head) -- that level is bound by the latency of its four key blocks.
 // GL: LIVE value sets of the G (GL < G: the batch came without its last chunk(s) -- the sampler's dead-branch elimination): the sets
 // g >= GL are neither read nor written and their column tiles are skipped; the tile layout, the ones column and every instruction
 // that touches a live set are those of GL == G, so the live outputs are the full call's bit for bit.
 template <class TT, int DH, int QT, int G, bool LAZY, bool W32 = false, int NWV = 4, int GL = G>
-__global__ __launch_bounds__(64 * NWV, 2) void attn_kernel(AttnParams p) {
+__global__ __launch_bounds__(64 * NWV, (NWV == 8 && DH > 128) ? 1 : 2) void attn_kernel(AttnParams p) {
     constexpr int NTH = 64 * NWV;
     static_assert(GL >= 1 && GL <= G && (GL == G || !W32), "live sets");
     using E = typename TT::elem;
@@ -696,10 +698,19 @@ int dispatch_l(const AttnParams& p, hipStream_t stream) {
         case 32: return launch<TT, 32, 2, 1, LAZY>(p, stream);
         case 40:
             if (LAZY && (p.variant & 5) == 4) return launch<TT, 40, 4, 1, LAZY, LAZY>(p, stream);      // A/B: the 32 x 32 x 16 form
-            if (p.variant & 8) return launch<TT, 40, 4, 1, LAZY, false, 8>(p, stream);                 // A/B: eight waves per workgroup
-            return (p.variant & 1) ? launch<TT, 40, 2, 1, LAZY>(p, stream) : launch<TT, 40, 4, 1, LAZY>(p, stream);
-        case 80: return launch<TT, 80, 2, 1, LAZY>(p, stream);
-        case 160: return launch<TT, 160, 1, 1, LAZY>(p, stream);
+            if (p.variant & 1) return launch<TT, 40, 2, 1, LAZY>(p, stream);                           // A/B: two query tiles per wave
+            // eight waves per workgroup by default since round 5 (one staged K / V block serves 512 queries; bit-identical to the
+            // four-wave form): 2 472 -> 2 388 us at 96 samples, 1 268 -> 1 201 at 48, 679 -> 600 at 24 (profiles/r05_m; in round 3,
+            // before the speculative reference, the two forms measured equal); variant bit 3: four waves (A/B)
+            return (p.variant & 8) ? launch<TT, 40, 4, 1, LAZY>(p, stream) : launch<TT, 40, 4, 1, LAZY, false, 8>(p, stream);
+        case 80:
+            if (p.variant & 1) return launch<TT, 80, 4, 1, LAZY>(p, stream);                          // A/B: four query tiles per wave
+            if (p.variant & 8) return launch<TT, 80, 2, 1, LAZY, false, 8>(p, stream);                 // A/B: eight waves per workgroup
+            return launch<TT, 80, 2, 1, LAZY>(p, stream);
+        // dh = 160 (the 16 x 16 and 8 x 8 levels: 256 / 64 keys): a workgroup is bound by the latency of its few key blocks, one
+        // workgroup per CU (88 KB of LDS) -- two query tiles per wave halve the workgroups and the K / V re-reads where the map has the
+        // queries for it (208 -> see profiles/r05_m at 96 samples); per-query arithmetic is the same either way
+        case 160: return p.n >= 256 ? launch<TT, 160, 2, 1, LAZY, false, 8>(p, stream) : p.n >= 128 ? launch<TT, 160, 2, 1, LAZY>(p, stream) : launch<TT, 160, 1, 1, LAZY>(p, stream);
         default: return VF_ERR_SHAPE;
     }
 }
