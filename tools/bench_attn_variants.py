@@ -33,7 +33,7 @@ def main():
             heads, dh = 8, d // 8
             qkv = torch.randn(B * n, 3 * d, device=DEV, generator=g).half()
             ref = None
-            for variant in (0, 1, 8):
+            for variant in (0, 1, 8, 9):
                 if dh == 160 and variant:
                     continue
                 out = torch.empty(B * n, d, dtype=torch.float16, device=DEV)

@@ -698,7 +698,7 @@ int dispatch_l(const AttnParams& p, hipStream_t stream) {
         case 32: return launch<TT, 32, 2, 1, LAZY>(p, stream);
         case 40:
             if (LAZY && (p.variant & 5) == 4) return launch<TT, 40, 4, 1, LAZY, LAZY>(p, stream);      // A/B: the 32 x 32 x 16 form
-            if (p.variant & 1) return launch<TT, 40, 2, 1, LAZY>(p, stream);                           // A/B: two query tiles per wave
+            if (p.variant & 1) return (p.variant & 8) ? launch<TT, 40, 2, 1, LAZY>(p, stream) : launch<TT, 40, 2, 1, LAZY, false, 8>(p, stream);   // A/B: two query tiles per wave
             // eight waves per workgroup by default since round 5 (one staged K / V block serves 512 queries; bit-identical to the
             // four-wave form): 2 472 -> 2 388 us at 96 samples, 1 268 -> 1 201 at 48, 679 -> 600 at 24 (profiles/r05_m; in round 3,
             // before the speculative reference, the two forms measured equal); variant bit 3: four waves (A/B)
