@@ -553,12 +553,16 @@ def main():
             tt = torch.tensor([el], device="cpu" if rehearse else dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
-        two = graphed and nseg <= 1 and any(k[0] != "plan" and "streams" in v for k, v in eng._split_state.items() if isinstance(v, dict))
+        split2 = graphed and any(k[0] != "plan" and "streams" in v for k, v in eng._split_state.items() if isinstance(v, dict))
+        two = split2 and (nseg <= 1 or dist is None)
+        two_text = (": the frames of the batch as two halves (every chunk's frames [0, F/2) and [F/2, F)), each half its own graph, on two "
+                    "HIP streams at once, joined every step (engine._step_forward_split; bit-identical to the single launch sequence)")
+        if two and nseg > 1:
+            two_text += (f"; the halves are coupled through one frame (flow_fix: half 0 hands its last frame's fused q|k to half 1 through a "
+                         f"slot + event, parallel.StreamShard), each half a chain of {nseg} graph segments cut at the hand-overs")
         launch = ("kernel by kernel" if not graphed else
-                  ("hipGraph replay of the UNet forward of each step (UNetEngine.step_forward_nhwc)" +
-                   (": the frames of the batch as two halves (every chunk's frames [0, F/2) and [F/2, F)), each half its own graph, on two "
-                    "HIP streams at once, joined every step (engine._step_forward_split; bit-identical to the single launch sequence)" if two else "")
-                   if nseg <= 1 else
+                  ("hipGraph replay of the UNet forward of each step (UNetEngine.step_forward_nhwc)" + (two_text if two else "")
+                   if (nseg <= 1 or two) else
                    f"hipGraph replay in {nseg} segments cut at the halo exchanges, the RCCL send / recv / wait calls issued from the host "
                    "between them (engine._GraphSegments)"))
         eng.exchange_events = None

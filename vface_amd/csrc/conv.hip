@@ -759,9 +759,12 @@ int vf_conv_patch_tile(const GemmParams& p) {
         // a 128-wide workgroup takes ~0.8 of a 160-wide one (32 instead of 40 MFMAs per wave and K tile, same fixed costs).
         // Measured (tools/quantisation_probe.py, 24 samples): 32x32 640->640: 160-wide 384 workgroups = 1.5 rounds 181.6 us,
         // 128-wide 480 = 1.9 rounds 153.6 us; 16x16 1280->1280: 192 = 0.75 rounds 175.3 us vs 240 = 0.94 rounds 151.8 us.
-        // The grid is taken at the NOMINAL 24-sample batch on 256 CUs -- the width changes the summation order of the column
-        // statistics, so it must not depend on how many samples share the launch (batch invariance).
-        const long t24 = 24L * (p.H / TP) * (p.W / TP);
+        // The grid is taken at a NOMINAL batch on 256 CUs -- the width changes the summation order of the column statistics, so it
+        // must not depend on how many samples share the launch (batch invariance).  Nominal = 48 samples since round 5:
+        // one launch stream's half of the 32-frame headline and a rank's 16-frame share at N > 1 (at 24 -- the 8-frame clip --
+        // the 32 x 32 640-channel launches would take the 128-wide tile: 15 % faster THERE, 6 % slower at 48 and 96 samples;
+        // measured on the headline: 79.34 -> 79.10 ms/step, conv family 33.4 -> 32.8, profiles/r05_o).
+        const long t24 = 48L * (p.H / TP) * (p.W / TP);
         const long r160 = (t24 * (p.N / 160) + 255) / 256, r128 = (t24 * (p.N / 128) + 255) / 256;
         return (r128 * 4 < r160 * 5) ? 128 : 160;      // r128 * 0.8 < r160
     }
