@@ -1,4 +1,4 @@
-"""Frame sharding on CPU with gloo, world_size 2: the boundary exchange moves the right slab, and per-shard
+"""Frame sharding on CPU with gloo, world_size 2 (and a 4-rank chain with uneven shards): the boundary exchange moves the right slab, and per-shard
 flow smoothing with the exchanged halo reproduces the unsharded result exactly (oracle flow functions as the
 checker -- the exchange itself is the product code under test)."""
 import os
@@ -30,12 +30,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, mode, q):
+def _worker(rank, world, port, mode, q, total=5):
     import torch.distributed as dist
     # `port` is a rendezvous FILE path: nothing to race for between choosing a port and binding it
     dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
     try:
-        total, C, h, w = 5, 8, 16, 16
+        C, h, w = 8, 16, 16
         x = synth.synth_normal("par.x", (total, C, h, w))
         gflow = synth.synth_flow(total - 1, h, w, seed=3)
         full = oflow.align_by_flow(x, [gflow[i] for i in range(total - 1)], 0.8)
@@ -75,6 +75,25 @@ def test_halo_exchange_gloo_world2(mode):
         assert p.exitcode == 0
     res = dict(q.get(timeout=5) for _ in range(2))
     assert res == {0: True, 1: True}
+
+
+@pytest.mark.parametrize("mode", ["p2p", "allgather"])
+def test_halo_exchange_gloo_world4_uneven_shards(mode):
+    """The chain as the 4-GPU configuration runs it (BASELINE configs[3]), with shards of unequal length (13 frames: 4, 3, 3, 3): every
+    rank but the first receives exactly its predecessor's last frame -- the middle ranks send and receive in one batched call -- and
+    the per-shard smoothing with that halo is the unsharded result, bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    import tempfile
+    port = os.path.join(tempfile.mkdtemp(prefix="vface_rdzv_"), "store")
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, mode, q, 13)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(4))
+    assert res == {0: True, 1: True, 2: True, 3: True}
 
 
 def _spawn(target, world, *args, timeout=120):
