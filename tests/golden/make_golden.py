@@ -391,6 +391,32 @@ def gen_full_unet_fft():
     save("lowp", **lowp)
 
 
+@torch.no_grad()
+def gen_full_unet_sampler_batch():
+    """Round 6: the 859.5 M-parameter UNet on the batch the reference's SAMPLER assembles
+    (ddim_w_inv.py:632-655: ``x_in = cat([x, x, ddim_inv_t])`` with ``inpaint_image`` / ``inpaint_mask`` appended, ``t_in = cat([t] * 3)``,
+    ``c_in = cat([uc, c, tc])``) under fusion="fft" on the input-block attn1 -- chunks 0 and 1 enter with identical inputs, which is
+    what the build's shared uncond/cond prefix relies on.  F = 2 at 64 x 64; fp32 eps -> full_unet_sampler_batch.npz."""
+    import ldm.models.pnp_utils as pnp
+    unet = ref_unet(320)
+    sampler, dd = make_sampler(unet)
+    F_, h, w = 2, 64, 64
+    x = synth.synth_normal("sb.x", (F_, 4, h, w))
+    inv = synth.synth_normal("sb.inv", (F_, 4, h, w))
+    inp = synth.synth_normal("sb.inp", (F_, 4, h, w)) * 0.18215
+    mask = synth.synth_mask(F_, h, w)
+    ctx = synth.synth_normal("sb.ctx", (3 * F_, 1, 768))
+    x_in = torch.cat([x, x, inv])
+    x_in = torch.cat([x_in, torch.cat([inp] * 3), torch.cat([mask] * 3)], dim=1)          # (:632-633, :654-655)
+    t = torch.full((3 * F_,), 481, dtype=torch.long)
+    pnp.register_spa_attn_injection(sampler, 1, switch_on=False, input_blocks=True, middle_block=True,
+                                    output_blocks=True, attn_component="attn1", chunks=3)
+    pnp.register_spa_attn_injection(sampler, 1, switch_on=True, input_blocks=True, middle_block=False,
+                                    output_blocks=False, attn_component="attn1", flow=None, chunks=3,
+                                    block_indices=list(range(9)), fusion="fft", split_ratio_fft=0.8, alpha=0.8)
+    save("full_unet_sampler_batch", fft=unet(x_in, t, context=ctx).numpy())
+
+
 def _round_weights_(module, dtype=torch.float16):
     for prm in module.parameters():
         prm.data = prm.data.to(dtype).float()
@@ -535,6 +561,7 @@ if __name__ == "__main__":
     if a.full:
         gens["full"] = gen_full_unet
         gens["full_fft"] = gen_full_unet_fft
+        gens["full_sampler_batch"] = gen_full_unet_sampler_batch
     for name, fn in gens.items():
         if a.only and name not in a.only.split(","):
             continue

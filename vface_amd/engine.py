@@ -302,8 +302,19 @@ class _GraphSegments:
         self.cur.capture_begin(pool=self.pool, capture_error_mode="thread_local")
 
     def end(self, host_op):
-        self.cur.capture_end()
-        self.segments.append((self.cur, host_op))
+        # A segment in which the forward launched nothing (two exchange calls back to back: half 0 of a coupled split has
+        # nothing to wait for) is not kept -- torch says so with a warning at capture_end; replaying it would be a no-op launch
+        # per step.  Its host call, if any, still runs at its place in the chain.
+        import warnings
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            self.cur.capture_end()
+        empty = any("Graph is empty" in str(w.message) for w in caught)
+        for w in caught:
+            if "Graph is empty" not in str(w.message):
+                warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+        if not empty or host_op is not None:
+            self.segments.append((None if empty else self.cur, host_op))
         self.cur = None
 
     def abort(self):
@@ -424,6 +435,12 @@ class UNetEngine:
         # the batch holds only the first `live_chunks` chunks of the hooks' three (the sampler's dead-branch elimination leaves
         # the recon third out: DDIMSampler.drop_dead_branches); None = every chunk is there
         self.live_chunks: Optional[int] = None
+        # The batch is the sampler's own [x ; x ; inv_t] with t repeated (ddim_w_inv.py:632-655): chunks 0 and 1 enter the UNet
+        # with IDENTICAL inputs and diverge only where attn2's row bias (the context) is first added.  The sampler states it per
+        # call (DDIMSampler.p_sample_ddim_with_inverse; never true for a batch handed in through apply_model): the first
+        # ResBlock and the first SpatialTransformer's front -- and, where the hook leaves chunk 1's q,k equal to chunk 0's
+        # (no hook, `replace`, `fft`), its attention -- then run on 2F samples, chunk 0 reading chunk 1's rows (_shared_block).
+        self.share_prefix = False
         # fp32 residual stream: residual sums are carried between kernels in fp32, 16-bit copies exist only
         # where a matrix-core operand needs them.  VFACE_STREAM32=0 restores the all-16-bit activations (A/B switch).
         self.stream32 = os.environ.get("VFACE_STREAM32", "1") != "0"
@@ -609,6 +626,10 @@ class UNetEngine:
         if key not in self._maps:
             if kind == "qk_replace":
                 m = torch.arange(B, dtype=torch.int32) % c
+            elif kind in ("share_qk", "share_v"):
+                # _st_front_shared with a warp: slot 0 = chunk 1's warped q|k, slot 1 = chunk 0's q|k and the v of chunks 0, 1
+                idx = torch.arange(B, dtype=torch.int32)
+                m = torch.where(idx < c, idx + c, torch.where((idx < 2 * c) & torch.tensor(kind == "share_qk"), idx - c, idx))
             else:  # v_fixed: chunk 0 identity, chunk k >= 1 -> its first frame
                 idx = torch.arange(B, dtype=torch.int32)
                 m = torch.where(idx < c, idx, (idx // c) * c)
@@ -986,6 +1007,150 @@ class UNetEngine:
                  split_k=False, residual32=t0, out32=t1)
         return self._ffn(t1, p, n)
 
+    # ------------------------------------------------------------------ chunks 0 and 1 of the sampler's batch share their prefix
+    def _share_ok(self, block, h: Act) -> bool:
+        """Can input block 1 -- ``[ResBlock, SpatialTransformer]`` -- of a ``[x ; x ; inv_t]`` batch run its chunk-0 / chunk-1
+        prefix once (``_shared_block``)?  Needs the whole batch (no dead-branch elimination), the fused front and the fused
+        tail with ``proj_out`` behind it (the launches whose operands can be handed over as row ranges), and a hook mode whose
+        chunk-1 edit is either the identity on identical inputs (none, ``replace``, ``fft``, ``mix``) or the flow warp."""
+        L = 3 if self.live_chunks is None else self.live_chunks      # chunks in the batch: 3, or 2 = [uncond ; cond] (dead-branch elimination)
+        if len(block) != 2 or block[0][0] != "res" or block[1][0] != "st" or L not in (2, 3):
+            return False
+        if h.N % L or h.t32 is None or h.cs is None or h.hw % 128 or not self.stream32:
+            return False
+        P = self._packed
+        pr, p = P[block[0][1]], P[block[1][1]]
+        c, n, F_ = p["c"], h.hw, h.N // L
+        if pr["conv2"]["cout"] != c or c % 8:
+            return False
+        if not (self.fuse_front and self.fuse_ffn and self.fuse_tail and self.fuse_post) or p.get("front_w") is None or \
+                p.get("tail_w") is None or not p.get("tail_post"):
+            return False
+        key = ((L - 1) * F_ * n, c, n)
+        ok = self._front_supported.get(key)
+        if ok is None:
+            ok = self._front_supported[key] = bool(hip.st_front_supported(key[0], c, n))
+        if not ok or not self._ffn_ok(F_ * n, c) or not self._ffn_ok((L - 1) * F_ * n, c):
+            return False
+        attn1 = block[1][2].transformer_blocks[0].attn1
+        cfg = getattr(attn1, "_vface_cfg", None)
+        if cfg is not None and cfg.switch_on and cfg.chunks != 3:
+            return False
+        try:
+            pl = plan_fusion(cfg, h.N, n, self.halo_hw if self.halo_exchange is not None else None, self.live_chunks)
+        except Exception:
+            return False          # (the whole-batch path raises it where the caller expects it)
+        if pl["staged"] or pl["v_fixed"]:
+            return False
+        if L == 2:
+            # [uncond ; cond] alone: shared only where chunk 1 IS chunk 0 at this layer (no hook, fft, mix) -- the one case whose
+            # chunk-1 bits the three-chunk shared form changes, so that dropping the recon third keeps ITS bits; replace / flow_fix
+            # are bit-identical shared or not, and stay on the whole-batch launches here
+            return pl["fusion"] == hip.FUSION_NONE or (pl["fusion"] == hip.FUSION_LINEAR and pl["warp_hw"] is None)
+        return pl["fusion"] in (hip.FUSION_NONE, hip.FUSION_REPLACE, hip.FUSION_LINEAR)
+
+    def _shared_block(self, block, h: Act, out, emb_all: torch.Tensor, a2_all: torch.Tensor) -> Act:
+        """Input block 1 of the sampler's ``[uncond ; cond ; recon]`` batch (ddim_w_inv.py:632-655: ``x_in = cat([x, x, inv_t])``,
+        ``t_in = cat([t] * 3)``): the ResBlock and everything of the SpatialTransformer in front of attn2's row bias see the same
+        numbers for chunks 0 and 1, and every kernel here is batch-invariant -- so they run on the LAST 2F samples (a contiguous
+        row range of the 3F-sample buffers) and chunk 0 reads chunk 1's rows.  ``h``: input block 0's output over all 3F samples
+        (the skip connection needs it whole).  Chunks 0 and 2 come out bit-identical to the whole-batch launches; chunk 1 too
+        under ``flow_fix`` / ``replace`` / no hook; under ``fft`` / ``mix`` its q,k ARE chunk 0's (what the reference's
+        ``combine_fft_high_low(q0, q1)`` returns for q1 = q0 up to its FFT's fp32 rounding, face_swap_utils.py:425-464) instead of
+        the folded-weight projection of the same rows."""
+        P = self._packed
+        (_, pre_r, _), (_, pre_s, mod) = block
+        L = 3 if self.live_chunks is None else self.live_chunks
+        F_ = h.N // L
+        Fn = F_ * h.hw
+        hv = Act(h.t[Fn:] if h.t is not None else None, (L - 1) * F_, h.H, h.W, h.cs[Fn // 64:], h.t32[Fn:])
+        co = P[pre_r]["conv2"]["cout"]
+        r = self._res(hv, P[pre_r], emb_all[F_:], self._new_target(hv.M, co, hv.hw, need16=False))
+        p = P[pre_s]
+        a, b = p["a2_slice"]
+        self._st_front_shared(r, p, mod.transformer_blocks[0].attn1, a2_all[:, a:b], out, F_, L)
+        return Act(out[0], h.N, h.H, h.W, out[1], out[2])
+
+    def _st_front_shared(self, x: Act, p: dict, attn1, a2vec: torch.Tensor, post, F_: int, L: int = 3) -> None:
+        """``_st_front`` for ``_shared_block``: ``x`` holds the 2F samples [A ; C] -- A stands for chunks 0 AND 1, C is chunk 2 --,
+        ``a2vec`` / ``post`` cover all 3F.  Front, dual-source projections and (hook permitting) attention on 2F; the tail, where
+        attn2's row bias separates chunk 0 from chunk 1, as two launches: rows A with chunk 0's bias -> chunk 0, rows [A ; C]
+        with chunk 1's and 2's -> chunks 1, 2.  ``L = 2``: the batch is [uncond ; cond] alone, ``x`` holds A only (``_share_ok``
+        admits the hook modes that leave chunk 1 equal to chunk 0 here)."""
+        c, n = p["c"], x.hw
+        d, heads = c, attn1.heads
+        Fn = F_ * n
+        M2, M3 = (L - 1) * Fn, 3 * Fn
+        cfg = getattr(attn1, "_vface_cfg", None)
+        fw = attn1.__dict__.get("forward")
+        if fw is not None and not getattr(fw, "_vface", False):
+            raise hip.VFaceHipError("attn1.forward was replaced by a closure this engine does not know; use "
+                                    "vface_amd.ldm.models.pnp_utils.register_spa_attn_injection")
+        pl = plan_fusion(cfg, L * F_, n, self.halo_hw if self.halo_exchange is not None else None, self.live_chunks)
+        fusion, flow, alpha, hw = pl["fusion"], pl["flow"], pl["alpha"], pl["warp_hw"]
+        warp = hw is not None
+        assert L == 3 or not warp
+        sharded = warp and self.halo_exchange is not None
+        ab = hip.groupnorm_coeffs_from_cols(x.cs, p["gn"][0], p["gn"][1], nimg=(L - 1) * F_, hw=n, C_=c, eps=1e-6)
+        t0 = self._new(M2, c, torch.float32)
+        # with a warp, chunk 1's q|k differ from chunk 0's: the attention then runs over three sample slots -- slot 0 = the warped
+        # q|k of chunk 1, slot 1 = A (q|k of chunk 0, v of chunks 0 and 1), slot 2 = C -- addressed through the sample maps
+        qkv3 = self._new(M3, 3 * d) if warp else None
+        qkv = qkv3[Fn:] if warp else self._new(M2, 3 * d)
+        ln = self._new(M2, c) if (fusion == hip.FUSION_LINEAR and L == 3) else None
+        hip.st_front(x.t32, ab, p["front_w"], p["proj_in"]["b"], p["ln1"][0], p["ln1"][1], t0, qkv, M=M2, C_=c, hw=n, NQ=3 * d,
+                     rows_full=M2 if fusion == hip.FUSION_NONE else Fn, nq_lo=0 if fusion == hip.FUSION_NONE else 2 * d, ln=ln)
+        if fusion == hip.FUSION_LINEAR and L == 3:
+            wlin = self._wlin(p, *pl["wlin"])
+            ldl = ln.stride(0)
+
+            def fused(src, dst):      # own rows `src`, structure rows = A (chunk 0's LayerNorm output)
+                hip.gemm(src, wlin, dst, M=Fn, N=2 * d, K=2 * d, lda=ldl, ldc=dst.stride(0), ldw=2 * d, a2=ln, lda2=ldl, k1=d,
+                         split_k=False)
+            if warp:
+                T = self._new(Fn, 2 * d)
+                fused(ln, T)                                  # chunk 1 (its own rows are A's)
+                halo = None
+                if sharded:
+                    handle = self._halo_start(T[(F_ - 1) * n:])
+                fused(ln[Fn:], qkv[Fn:, :2 * d])              # chunk 2
+                if sharded:
+                    ev = self.exchange_events if not isinstance(self.halo_exchange, _GraphSegments) else None
+                    if ev is not None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                    halo = self.halo_exchange.finish_exchange(handle)
+                    if ev is not None:
+                        e1.record()
+                        ev.append((e0, e1))
+                hip.flow_warp(T, qkv3[:Fn, :2 * d], flow, F=F_, h=hw[0], w=hw[1], C_=2 * d, ld_src=2 * d, fs_src=n * 2 * d,
+                              ld_dst=3 * d, fs_dst=n * 3 * d, alpha=alpha, prev=halo, ld_prev=2 * d,
+                              flow_prev=self.halo_flow if halo is not None else None)
+            else:
+                fused(ln[Fn:], qkv[Fn:, :2 * d])              # chunk 2; chunk 1's FSAI(q0, q0) is q0
+        kw = dict(heads=heads, n=n, nk=n, dh=d // heads, ldq=3 * d, ldk=3 * d, ldv=3 * d, bsq=n * 3 * d, bsk=n * 3 * d,
+                  bsv=n * 3 * d, ldo=d, bso=n * d,
+                  scale=float(np.float32(1.0) / np.sqrt(np.float32(d // heads))))   # fp32 arithmetic, as capi.cpp computes it
+        if warp:
+            att = self._new(M3, d)
+            hip.attention(qkv3, qkv3[:, d:], qkv3[:, 2 * d:], att, B=3 * F_, qk_map=self._map("share_qk", 3 * F_, F_),
+                          v_map=self._map("share_v", 3 * F_, F_), **kw)
+            att_0, att_12 = att, att[Fn:]
+        else:
+            att = self._new(M2, d)
+            if fusion == hip.FUSION_REPLACE and hip.load().vface_attention_shared_scores_supported(d // heads, 3):
+                hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=F_, v_sets=3, v_sets_live=2, set_stride=F_, **kw)
+            else:
+                hip.attention(qkv, qkv[:, d:], qkv[:, 2 * d:], att, B=(L - 1) * F_,
+                              qk_map=self._map("qk_replace", 2 * F_, F_) if fusion == hip.FUSION_REPLACE else None, **kw)
+            att_0, att_12 = att, att
+        o16, cs, o32 = post
+        for r0, rows, a_, s0 in ((0, Fn, att_0, 0), (Fn, (L - 1) * Fn, att_12, F_)):
+            hip.attn_out_ffn_proj_fused(a_, t0, a2vec[s0:], p["tail_w"], p["wo"]["b"], p["ln3"][0], p["ln3"][1], p["ff1"]["b"], p["ff2p"],
+                                        p["ff2"]["b"], p["proj_out"]["b"], x.t32, o16[r0:] if o16 is not None else None,
+                                        o32[r0:] if o32 is not None else None, cs[r0 // 64:] if cs is not None else None,
+                                        M=rows, C_=c, rows_per_sample=n)
+
     def _halo_start(self, tail: torch.Tensor):
         """``halo_exchange.start_exchange`` with the exchange's ordinal inside this forward stated first (FrameShard.set_index)."""
         ex = self.halo_exchange
@@ -1154,6 +1319,9 @@ class UNetEngine:
         h = x
         for i, block in enumerate(blocks_in):
             j = nb - 1 - i
+            if i == 1 and self.share_prefix and self._share_ok(block, h):
+                h = self._shared_block(block, h, part(j, h_ch[j], cats[j].shape[1]), emb_all, a2_all)
+                continue
             h = run(block, h, part(j, h_ch[j], cats[j].shape[1]))
         h = run(mid, h, part(0, 0, h_ch[0]))
         for j, block in enumerate(blocks_out):
@@ -1224,6 +1392,14 @@ class UNetEngine:
             if chunks not in (1, there):
                 return None
             chunks = there
+        if self.share_prefix:
+            # the batch is the sampler's [x ; x ; inv_t]: each half must again be three chunks of the same frames
+            # (_shared_block), also when no hook says so
+            want = 3 if self.live_chunks is None else self.live_chunks
+            if chunks == 1:
+                chunks = want
+            elif chunks != want:
+                return None
         if N % chunks or (N // chunks) % 2:
             return None
         if coupled and coupled[0].flow.shape[0] != N // chunks - 1:
@@ -1399,7 +1575,7 @@ class UNetEngine:
                                              None if self.halo_flow is None else tuple(self.halo_flow.shape))
         # (every switch that changes the captured launch sequence is part of the key: toggling one on a live engine must not
         # replay a stale graph)
-        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.fuse_post, self.fuse_temb, self.fuse_out, self.concat32, self.interior16, self.live_chunks,
+        key = (x.N, x.H, x.W, tuple(x.t.shape), x.t.dtype, self._version, self.stream32, self.fuse_gn, self.fuse_ffn, self.fuse_front, self.fuse_tail, self.fuse_post, self.fuse_temb, self.fuse_out, self.concat32, self.interior16, self.live_chunks, self.share_prefix,
                hip._ws_domain, self.decompose_attn1, self.exchange_events is not None, sig,
                tuple(context.shape), torch.cuda.current_stream().cuda_stream, shard_sig)
         g = self._graphs.get(key)
@@ -1429,7 +1605,8 @@ class UNetEngine:
         g["x"].copy_(x.t)
         g["t"].copy_(timesteps)
         for graph, host_op in g["segments"]:
-            graph.replay()
+            if graph is not None:
+                graph.replay()
             if host_op is not None:
                 host_op()
         return g["eps"]

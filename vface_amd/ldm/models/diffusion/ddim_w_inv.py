@@ -75,6 +75,11 @@ class DDIMSampler(object):
         self.flow_resample = None
         # exact dead-branch elimination (module docstring): sampling without the recon third, inversion without the source half
         self.drop_dead_branches = False
+        # chunks 0 and 1 of the batch this sampler assembles are the same x at the same t (:632-655: `x_in = cat([x, x, inv_t])`)
+        # and only diverge at the first attn2: their common prefix runs once (UNetEngine._shared_block).  Exact for chunks 0 and 2;
+        # chunk 1 under `fft` takes q0, k0 where the reference's FFT round trip returns them up to fp32 rounding.
+        # VFACE_SHARE_PREFIX=0 / `share_prefix = False`: every chunk computed on its own (A/B switch)
+        self.share_prefix = os.environ.get("VFACE_SHARE_PREFIX", "1") != "0"
 
     def register_buffer(self, name, attr):
         # the reference forces .to("cuda") here (:149-153); buffers follow the model's device instead
@@ -255,12 +260,14 @@ class DDIMSampler(object):
         else:
             c_in = torch.cat(list(parts), dim=0)
             self._c_in_cache = (parts, tuple(p._version for p in parts), c_in)
-        saved_live = eng.live_chunks
+        saved_live, saved_share = eng.live_chunks, eng.share_prefix
         eng.live_chunks = 2 if drop else None      # the hooks still say chunks = 3: the batch holds the first two of them
+        # x_in / t_in above ARE [x ; x ; inv_t] / [t ; t ; t]: chunks 0 and 1 are the same input up to the first attn2
+        eng.share_prefix = bool(self.share_prefix)
         try:
             eps = eng.step_forward_nhwc(Act(x_in, nb * F_, H, W), t_in, c_in)  # fp32 [nb F*HW, 4]
         finally:
-            eng.live_chunks = saved_live
+            eng.live_chunks, eng.share_prefix = saved_live, saved_share
         a_t, a_prev = float(self.ddim_alphas[index]), float(self.ddim_alphas_prev[index])
         sigma_t, s1m = float(self.ddim_sigmas[index]), float(self.ddim_sqrt_one_minus_alphas[index])
         noise = noise_like(x.shape, device, repeat_noise) * temperature  # drawn even when sigma_t == 0 (:697)
