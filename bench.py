@@ -604,6 +604,7 @@ def main():
                 ("BASELINE configs[1]: 8-frame 512x512 clip, structure attention injection only (the headline of rounds 1-4)", 8, "replace", 512),
                 ("BASELINE configs[2]: 32-frame 512x512 clip + frequency-spectrum attention interpolation", 32, "fft", 512),
                 ("shipped hook schedule (ddim_w_inv.py:303-305), config 4's per-GPU share: 16 frames + flow_fix", 16, "flow_fix", 512),
+                ("shipped hook schedule (ddim_w_inv.py:303-305) at the headline's size: 32 frames + flow_fix", 32, "flow_fix", 512),
                 ("BASELINE configs[4]'s per-GPU share: 32 frames at 768x768 (96x96 latents, n = 9216 tokens at level 0), all three "
                  "modules (flow_fix, flow gate generalised to the flow field's h*w: the reference's n == 4096 gate never fires "
                  "at this size)", 32, "flow_fix", 768)):
@@ -620,6 +621,11 @@ def main():
                 eng.split_streams = 2
                 same2 = bool(torch.equal(e["final_latents"], e1["final_latents"]))
                 log(f"  two launch streams {'==' if same2 else '!='} one launch sequence after {a.extra_steps} steps (one sequence: {e1['ms_step']:.2f} ms/step)")
+                if not same2:
+                    # fail closed: a two-stream result that is not the single sequence's bits is not reported as a timing --
+                    # this workload's line is the one-sequence run, and the engine stays on one launch sequence for what follows
+                    e, eng.split_streams = e1, 1
+                    log("  MISMATCH: reporting the one-sequence timing; the engine stays on one launch sequence")
             extras.append({"workload": name, "frames_per_gpu": f2, "fusion": fus, "res": res2, "latent": [e["h"], e["h"]],
                            "launch_streams": 2 if "two halves" in e["launch"] else 1, "two_streams_bits_equal_one_sequence": same2,
                            "steps": a.extra_steps if res2 == 512 else max(3, a.extra_steps // 2), "warmup": 2,
@@ -722,6 +728,20 @@ def main():
         by_family["attention"]["kernel"] = "attn_kernel<T, DH, QT, G, LAZY> (attention.hip); algorithmic FLOPs 4 n nk dh per (output sample, head)"
         by_family["norm"]["kernel"] = "layernorm_kernel, gn_apply_kernel, gn_finalize_cols, flow_warp_kernel (pointwise.hip): HBM-bound, algorithmic bytes"
         covered = sum(by_family[k]["ms"] for k in by_family)
+        # north_star's "fraction of the attention-GEMM roofline", as a KERNEL figure: the launches that compute attn1's
+        # q|k|v projections and softmax(QK^T)V -- the attention kernels, the plain / dual-source (FSAI-folded) projection GEMMs of the 640- /
+        # 1280-channel blocks, and the level-0 front kernel (which also holds proj_in: its FLOPs as executed are counted with it) -- FLOPs
+        # as executed over their own event-timed duration, against the dense MFMA peak
+        def _is_qkv(key):
+            m = key.split("+")[0].split("x")
+            return len(m) == 3 and all(v.isdigit() for v in m) and (int(m[1]) == 3 * int(m[2]) or "+a2" in key)
+        a1 = [c for k, c in fam.get("gemm", {}).items() if k == "st_front" or _is_qkv(k)] + list(fam.get("attention", {}).values())
+        a1_ms, a1_fl = sum(c["ms"] for c in a1), sum(c["flops"] for c in a1)
+        attn1_kernel = None if not a1_ms else {
+            "tflops": a1_fl / (a1_ms * 1e-3) / 1e12, "frac": a1_fl / (a1_ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, "ms_per_step": a1_ms / a.steps,
+            "tflop_per_step": a1_fl / a.steps / 1e12,
+            "kernels": "attn_kernel (all head dims) + the attn1 projection GEMMs (M x 3d x d and the dual-source FSAI-folded M x 2d x 2d) + "
+                       "st_front_kernel (level 0: GroupNorm-apply, proj_in, LayerNorm and the q|k|v projection in one launch, all of its FLOPs)"}
         mfma_fams = ("gemm", "conv", "attention")
         dom = max(mfma_fams, key=lambda k: by_family[k]["ms"])
         d = by_family[dom]
@@ -747,13 +767,24 @@ def main():
                        # torch.equal of the latents after the K timed steps (graph replay, two streams) and after the same K steps
                        # launched kernel by kernel in one sequence (the instrumented pass)
                        "timed_region_bits_equal_kernel_by_kernel": same_bits,
+                       # the engine's own check on the second split step of each kind of split ("free" / "coupled" halves): eps of the two
+                       # launch sequences == eps of one sequence over the whole batch (UNetEngine.split_checked); and the same comparison
+                       # over `extra_steps` DDIM steps of every two-stream flow_fix extra below (None: no such extra ran)
+                       "two_sequence_selfcheck": dict(eng.split_checked),
+                       "two_streams_bits_equal_one_sequence": (None if not any(x.get("two_streams_bits_equal_one_sequence") is not None for x in extras)
+                                                               else all(x["two_streams_bits_equal_one_sequence"] for x in extras
+                                                                        if x.get("two_streams_bits_equal_one_sequence") is not None)),
                        "unet_algorithmic_tflops_per_gpu": unet_tflops,
                        "unet_algorithmic_frac_of_mfma_peak": unet_tflops / MFMA_PEAK_TFLOPS if unet_tflops else None,
                        "host_enqueue_ms_per_step": r["enqueue_ms"],
                        # north_star also asks for the rate as a fraction of the attention-GEMM roofline: the attn1 QKV
                        # projections + QK^T + PV are 160.9 GFLOP per sample-forward at 64x64 = 24.1 TFLOP per
                        # swapped frame; at the 2.5 PFLOP/s dense peak that alone would allow 103.6 frames/s per GPU
-                       "attention_gemm_roofline_frac": (fps / world) * 24.135e12 / (MFMA_PEAK_TFLOPS * 1e12) if h == 64 else None},
+                       "attention_gemm_roofline_frac": (fps / world) * 24.135e12 / (MFMA_PEAK_TFLOPS * 1e12) if h == 64 else None,
+                       # ... the figure above is the attention-GEMM SHARE of the whole step's rate; this one is the roofline fraction of the
+                       # attn1 kernels themselves: (projection + attention FLOPs as executed) / their own event-timed ms / peak
+                       "attn1_kernel_roofline_frac": attn1_kernel["frac"] if attn1_kernel else None,
+                       "attn1_kernel_roofline": attn1_kernel},
             "exchange": r["exchange"],
             "ranks_seen": ranks_seen,
             # the like-for-like single-GPU figure of an N > 1 line: the N = 1 DEFAULT is BASELINE configs[2] (32 frames, fft),

@@ -373,3 +373,31 @@ def test_split_plan_halves_frames_across_chunks_and_refuses_coupled_modes():
     eng.halo_exchange = None
     eng.split_streams = 1
     assert eng._split_plan(24) is None
+
+
+def test_every_built_kernel_keeps_its_values_in_registers():
+    """no instantiation that ships in libvface_hip.so carries scratch (a spilled kernel is a kernel whose schedule
+    nobody chose) -- read from the code-object notes of csrc/build/*.o (tools/codeobj_audit.py; no GPU needed).  Round 5 still had
+    eight: an attention A/B form, the 160-wide fused-GroupNorm convolution and the 160-wide 2 x 2 window with a residual operand;
+    they are no longer built (conv.hip launch_patch / vf_conv_patch_tile hand those launches the 128-wide tile or refuse them)."""
+    import glob
+    import sys
+    import tempfile
+    objs = sorted(glob.glob(os.path.join(ROOT, "vface_amd", "csrc", "build", "*.o")))
+    if not objs or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("no build objects / no llvm-readelf here (the driver's build() leaves both in this container)")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import codeobj_audit as audit
+    spilled, n = [], 0
+    with tempfile.TemporaryDirectory() as td:
+        for obj in objs:
+            co = audit.extract(obj, td)
+            if co is None:
+                continue
+            for sym, k in audit.notes(co).items():
+                n += 1
+                # (SGPR spills go to lanes of a VGPR, not to memory: they are not scratch)
+                if int(k[".private_segment_fixed_size"]) or int(k[".vgpr_spill_count"]):
+                    spilled.append((sym, int(k[".private_segment_fixed_size"])))
+    assert n > 200, n
+    assert not spilled, spilled

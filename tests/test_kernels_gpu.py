@@ -211,11 +211,13 @@ def test_attention_shared_scores(dt, dh, sets, n):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("dh,n", [(40, 500), (40, 1024), (8, 100), (16, 64), (32, 320)])
-def test_attention_shared_scores_two_live_sets_of_three_bit_identical(dt, dh, n):
+@pytest.mark.parametrize("dh,n,variant", [(40, 500, 0), (40, 1024, 0), (40, 4096, 0), (40, 500, 8), (40, 1024, 8), (8, 100, 0), (16, 64, 0), (32, 320, 0)])
+def test_attention_shared_scores_two_live_sets_of_three_bit_identical(dt, dh, n, variant):
     """The sampler's dead-branch elimination hands the hooked layers [chunk 0 ; chunk 1] of a three-chunk hook: the shared-score
     kernel then runs its THREE-set instantiation with two live sets (``v_sets_live=2``) -- no read of the third chunk's values
-    (the batch ends after the second), no write of its outputs -- and the two live outputs are the full call's bit for bit."""
+    (the batch ends after the second), no write of its outputs -- and the two live outputs are the full call's bit for bit.
+    dh = 40 runs eight waves per workgroup in both calls by default (round 6: the two-live-set form too); ``variant=8`` = four waves
+    for the live call, against the same eight-wave full call."""
     h = hip()
     Fr, heads = 2, 8
     d = heads * dh
@@ -225,6 +227,7 @@ def test_attention_shared_scores_two_live_sets_of_three_bit_identical(dt, dh, n)
               bsv=n * 3 * d, ldo=d, bso=n * d, scale=dh ** -0.5)
     full = torch.zeros(3 * Fr, n, d, dtype=dt, device=DEV)
     h.attention(qd, qd[:, :, d:], qd[:, :, 2 * d:], full, B=Fr, v_sets=3, set_stride=Fr, **kw)
+    kw["variant"] = variant
     q2 = qd[:2 * Fr].contiguous()                       # a batch that really ends after chunk 1
     SENT = 3.0
     live = torch.full((2 * Fr + 1, n, d), SENT, dtype=dt, device=DEV)

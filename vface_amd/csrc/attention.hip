@@ -672,10 +672,12 @@ int dispatch_l(const AttnParams& p, hipStream_t stream) {
             case 8: return launch<TT, 8, 2, 3, LAZY, false, 4, 2>(p, stream);
             case 16: return launch<TT, 16, 2, 3, LAZY, false, 4, 2>(p, stream);
             case 32: return launch<TT, 32, 2, 3, LAZY, false, 4, 2>(p, stream);
-            // (four waves per workgroup: bit-identical to the eight-wave form the full call takes by default -- the eight-wave
-            // instantiation with two live sets did NOT reproduce the full call's bits on the GPU (cause not found: open item in
-            // DESIGN.md), so it is not instantiated)
-            case 40: return launch<TT, 40, 2, 3, LAZY, false, 4, 2>(p, stream);
+            // eight waves per workgroup like the full call (variant bit 3: four, bit-identical).  Round 4's note that the eight-wave
+            // instantiation "did not reproduce the full call's bits" dates from the form that MASKED the dead set's LDS-DMA lanes out;
+            // with the dead slots loading from an out-of-range offset under the full call's lane masks (stage_block) both wave counts
+            // give the full call's bits (round 6: tools/attn_live_sets_probe.py, tests/test_kernels_gpu.py)
+            case 40:
+                return (p.variant & 8) ? launch<TT, 40, 2, 3, LAZY, false, 4, 2>(p, stream) : launch<TT, 40, 2, 3, LAZY, false, 8, 2>(p, stream);
             default: return VF_ERR_SHAPE;
         }
     }
@@ -704,7 +706,7 @@ int dispatch_l(const AttnParams& p, hipStream_t stream) {
             // before the speculative reference, the two forms measured equal); variant bit 3: four waves (A/B)
             return (p.variant & 8) ? launch<TT, 40, 4, 1, LAZY>(p, stream) : launch<TT, 40, 4, 1, LAZY, false, 8>(p, stream);
         case 80:
-            if (p.variant & 1) return launch<TT, 80, 4, 1, LAZY>(p, stream);                          // A/B: four query tiles per wave
+            // (the four-query-tiles-per-wave A/B form of rounds 3-5 spilled 28 B at 256 registers and lost its A/B: not built)
             if (p.variant & 8) return launch<TT, 80, 2, 1, LAZY, false, 8>(p, stream);                 // A/B: eight waves per workgroup
             return launch<TT, 80, 2, 1, LAZY>(p, stream);
         // dh = 160 (the 16 x 16 and 8 x 8 levels: 256 / 64 keys): a workgroup is bound by the latency of its few key blocks, one

@@ -643,15 +643,21 @@ int launch_patch(const GemmParams& p, hipStream_t stream) {
     constexpr int NPIECES = ((TP + KW - 1) * (TP + KH - 1) + 7) / 8;
     const size_t lds = 2 * (size_t)NPIECES * 1024 + NSLOT * (size_t)BN * 128 + (KH == 3 ? 2048 : 0);
     const int rm = p.res_f32 ? 2 : (p.residual ? 1 : 0);
-    auto kern = rm == 2 ? conv_patch_kernel<TT, NT, KH, KW, false, false, 2>
-              : rm == 1 ? conv_patch_kernel<TT, NT, KH, KW, false, false, 1> : conv_patch_kernel<TT, NT, KH, KW, false, false, 0>;
+    // Every instantiation built here keeps its values in registers (0 B scratch: tools/codeobj_audit.py, tests/test_host_cpu.py).  Three
+    // forms did not at 160 channels per tile and are NOT built: the 2 x 2 window with a residual operand (12 / 16 B) and the fused
+    // GroupNorm (36 B) -- vf_conv_patch_tile hands such launches the 128-wide tile or none (the im2col kernel / an error for gn_ab).
+    auto kern = conv_patch_kernel<TT, NT, KH, KW, false, false, 0>;
+    if constexpr (!(KH == 2 && NT == 5)) {
+        if (rm == 2) kern = conv_patch_kernel<TT, NT, KH, KW, false, false, 2>;
+        else if (rm == 1) kern = conv_patch_kernel<TT, NT, KH, KW, false, false, 1>;
+    } else if (rm) return VF_ERR_SHAPE;
     int which = rm;
     if constexpr (NT == 5 && KH == 3 && sizeof(typename TT::elem) == 2) {
         if (p.flags & 0x4000) { kern = conv_patch_kernel<TT, NT, KH, KW, true>; which = 3; }   // diagnostic stamps (tools/stamp_conv.py)
     }
-    if constexpr (KH == 3) {
+    if constexpr (KH == 3 && NT == 4) {
         if (p.gn_ab) { kern = conv_patch_kernel<TT, NT, KH, KW, false, true>; which = 4; }       // fused GroupNorm-apply + SiLU
-    }
+    } else if (p.gn_ab) return VF_ERR_SHAPE;
     static VfOncePerDevice attr_set[5];
     if (!attr_set[which].set_lds(reinterpret_cast<const void*>(kern), (int)lds)) return VF_ERR_LAUNCH;
     const int ntm = (p.M / (p.OH * p.OW)) * (p.H / TP) * (p.W / TP), ntn = p.N / BN;
@@ -753,7 +759,8 @@ int vf_conv_patch_tile(const GemmParams& p) {
     if (p.residual && !p.res_f32 && (((uintptr_t)p.residual & 15) || (p.ldr & 7))) return 0;
     if (((uintptr_t)p.C & 15) || (p.C && (p.ldc & 7))) return 0;
     const bool ok160 = p.N % 160 == 0, ok128 = p.N % 128 == 0;
-    if (p.gn_ab && ok128) return 128;      // the fused-normalisation build: its 128-wide instantiation keeps every value in registers
+    if (p.gn_ab) return ok128 ? 128 : 0;   // the fused-normalisation build exists 128 wide only (the 160-wide one spilled 36 B)
+    if (p.KH == 2 && (p.residual || p.res_f32)) return ok128 ? 128 : 0;      // ... and so does the 2 x 2 window with a residual operand
     if (ok160 && ok128 && !(p.flags & (GEMM_PATCH_BN160 | 0x4000))) {
         // Both widths tile N (640, 1280, 1920 channels): one workgroup per CU, so a launch takes ceil(workgroups / CUs) rounds, and
         // a 128-wide workgroup takes ~0.8 of a 160-wide one (32 instead of 40 MFMAs per wave and K tile, same fixed costs).

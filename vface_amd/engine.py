@@ -474,6 +474,13 @@ class UNetEngine:
         self._split_pair = None
         self._split_verified = False
         self.split_overlap = None      # step time / (half A + half B) of the measured split step: ~0.5 = the halves ran at once
+        # Self-check of the two-sequence form: the SECOND split step of every split configuration kind ("free": halves
+        # that never read each other; "coupled": flow_fix's halves handing one frame over, parallel.StreamShard) is also run as ONE
+        # launch sequence over the whole batch and the two eps compared bit for bit (one extra forward per kind and engine).  A
+        # mismatch -- round 4 / 5: a kernel of one half mis-executing beside the other half's attention waves -- makes the engine
+        # return the single sequence's result and stay on one launch sequence for good.  VFACE_SPLIT_SELFCHECK=0 skips it.
+        self.split_selfcheck = os.environ.get("VFACE_SPLIT_SELFCHECK", "1") != "0"
+        self.split_checked: Dict[str, bool] = {}       # kind -> the halves' eps equalled the single sequence's
         hip.load()
 
     # ------------------------------------------------------------------ weights
@@ -717,9 +724,9 @@ class UNetEngine:
         """Can GroupNorm-apply + SiLU of ``x`` ride in the operand path of the 3x3 convolution ``w``?  Needs producer-side
         column statistics, a 16-bit copy of ``x`` and a launch that runs the patch-staged kernel."""
         mode = self.fuse_gn
-        if mode.endswith("128"):          # only where the spill-free 128-wide instantiation runs (Cout a multiple of 128)
-            if w["cout"] % 128:
-                return False
+        if w["cout"] % 128:               # the fused form exists in the 128-wide tile only (the 160-wide one spilled: not built since round 6)
+            return False
+        if mode.endswith("128"):          # (the spelling of rounds 4-5, when "out" / "both" also took the spilled 160-wide form)
             mode = mode[:-3]
         if mode == "off" or (which == "in" and mode != "both"):
             return False
@@ -1541,6 +1548,17 @@ class UNetEngine:
         for idx, o in zip(plan, outs):
             o.record_stream(cur)
             ev.index_copy_(0, idx, o.reshape(len(idx), -1))
+        kind = "coupled" if coupled else "free"
+        if self.split_selfcheck and st["calls"] == 2 and kind not in self.split_checked:
+            whole = self._step_forward_one(x, timesteps, context)
+            same = bool(torch.equal(whole, st["eps"]))
+            self.split_checked[kind] = same
+            if not same:
+                import warnings
+                warnings.warn(f"vface_amd: the two launch sequences ({kind} halves) did NOT reproduce the single sequence's bits on this "
+                              "device: back to one launch sequence")
+                self.split_streams = 1
+                return whole
         return st["eps"]
 
     def step_forward_nhwc(self, x: Act, timesteps: torch.Tensor, context: torch.Tensor) -> torch.Tensor:
