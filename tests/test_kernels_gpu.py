@@ -891,11 +891,14 @@ def test_flow_to_latent_matches_oracle():
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("cin,cout,H,W,nimg,silu", [(64, 160, 16, 16, 2, True), (320, 320, 32, 32, 3, True), (128, 128, 16, 48, 2, False)])
+@pytest.mark.parametrize("cin,cout,H,W,nimg,silu", [(64, 160, 16, 16, 2, True), (320, 320, 32, 32, 3, True), (128, 128, 16, 48, 2, False),
+                                                    (320, 640, 32, 32, 3, True), (64, 256, 16, 16, 2, True)])
 def test_conv_patch_kernel_fused_groupnorm_silu(dt, cin, cout, H, W, nimg, silu):
     """GroupNorm-apply (+ SiLU) in the patch-staged convolution's operand path (north-star "GroupNorm+SiLU+conv fused";
     openaimodel.py:201-205): equals -- BIT FOR BIT -- the separate normalisation pass followed by the plain convolution on
-    the same 16-bit input (same a, b, same arithmetic, zero padding applied after the normalisation), and torch."""
+    the same 16-bit input (same a, b, same arithmetic, zero padding applied after the normalisation), and torch.
+    Since round 6 the fused form exists in the 128-channel tile only (the 160-wide instantiation carried 36 B of scratch and is
+    not built): an output width that is not a multiple of 128 is REFUSED -- never run without its normalisation."""
     h = hip()
     from vface_amd.packing import pack_conv3x3
     x = rnd((nimg, cin, H, W), 1, dt) * 1.5 + 0.3
@@ -909,6 +912,11 @@ def test_conv_patch_kernel_fused_groupnorm_silu(dt, cin, cout, H, W, nimg, silu)
     ab = h.groupnorm_coeffs_from_cols(cs, gm.to(DEV), bt.to(DEV), nimg=nimg, hw=H * W, C_=cin, eps=1e-5)
     wp = pack_conv3x3(w).to(DEV)
     fused = torch.zeros(nimg * H * W, cout, dtype=dt, device=DEV)
+    if cout % 128:
+        with pytest.raises(h.VFaceHipError):
+            h.conv3x3(xn, wp, fused, nimg=nimg, H=H, W=W, cin=cin, cout=cout, ldx=cin, ldy=cout, bias=b.to(DEV), gn_ab=ab, gn_silu=silu,
+                      flags=h.TUNE_PATCH)
+        return
     h.conv3x3(xn, wp, fused, nimg=nimg, H=H, W=W, cin=cin, cout=cout, ldx=cin, ldy=cout, bias=b.to(DEV), gn_ab=ab, gn_silu=silu,
               flags=h.TUNE_PATCH)
     st = h.groupnorm_stats_from_cols(cs, nimg=nimg, hw=H * W, C_=cin, eps=1e-5)

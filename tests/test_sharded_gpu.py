@@ -285,3 +285,128 @@ def test_capture_failure_on_one_shard_keeps_exchanges_paired_and_results_exact(w
         eng.use_graph, eng._graphs = old[0], old[1]
         eng._graph_failed.clear(); eng._graph_failed.update(old[2])
         eng.halo_exchange = None
+
+
+def _rccl_selfloop(port, outdir):
+    """Child process of ``test_rccl_world_size_one_*``: one rank, backend "nccl" (= RCCL on ROCm), every exchange form of the sharded
+    forward looped back to this rank THROUGH RCCL."""
+    import json
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    from vface_amd import hip
+    from vface_amd.engine import Act
+    from vface_amd.ldm.models.diffusion.ddim_w_inv import DDIMSampler
+    from vface_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from vface_amd.ldm.models.pnp_utils import register_spa_attn_injection as reg
+    from vface_amd.parallel import FrameShard, LoopbackShard, process_group_timeout
+    from vface_amd.utils import synth
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev,
+                            timeout=process_group_timeout())
+    res = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+    one = torch.ones(4, device=dev)
+    dist.all_reduce(one)
+    res["all_reduce"] = one.tolist()
+
+    class RcclSelfLoop(FrameShard):
+        """Shard ``rank`` of a ``world``-rank clip whose ranks all run in THIS process, one after another: a slab goes to the next shard
+        through RCCL -- shard r sends it to this (the only) rank and receives it into a per-exchange store, shard r+1 sends the stored
+        slab to this rank again and receives it as its halo; ``mode="allgather"``: the same two moves as one-rank all-gathers.  What the
+        engine sees (rank / world / first / count, handles, ``agree`` over an RCCL all-reduce) is what a real multi-rank run sees."""
+
+        def __init__(self, rank, world, total, mode, store):
+            super().__init__(rank, world, total, dist=dist, mode=mode)
+            self.store, self.index, self.calls = store, 0, 0
+
+        def begin_forward(self):
+            pass
+
+        def start_exchange(self, tail, recv=None):
+            k, works, halo = self.index, [], None
+            self.calls += 1
+            if self.rank > 0:                                  # take the previous shard's slab k
+                halo = recv if recv is not None else torch.empty_like(tail)
+                works += self._move(self.store[(self.rank - 1, k)], halo)
+            if self.rank + 1 < self.world:                     # leave ours for the next shard
+                slot = self.store.get((self.rank, k))
+                if slot is None or slot.shape != tail.shape:
+                    slot = self.store[(self.rank, k)] = torch.empty_like(tail)
+                works += self._move(tail.contiguous(), slot)
+            return ("p2p", works, halo)
+
+        def _move(self, src, dst):
+            if self.mode == "allgather":
+                return [dist.all_gather_into_tensor(dst.view((1,) + tuple(src.shape)).reshape(src.shape), src, async_op=True)]
+            return dist.batch_isend_irecv([dist.P2POp(dist.isend, src, 0), dist.P2POp(dist.irecv, dst, 0)])
+
+    total, world, h, w = 5, 2, 32, 32
+    cfg = dict(image_size=32, in_channels=9, out_channels=4, model_channels=64, attention_resolutions=[4, 2, 1], num_res_blocks=2,
+               channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True, transformer_depth=1, context_dim=768, legacy=False)
+    ldm = LatentDiffusion(cfg)
+    synth.fill_module_(ldm.unet, seed=0)
+    ldm = ldm.to(dev)
+    sampler = DDIMSampler(ldm)
+    sampler.flow_gate = "flow_hw"
+    gflow = synth.synth_flow(total - 1, h, w)
+    eng = ldm.unet.engine
+    keep = {}
+
+    def step(shard, graph):
+        x, ctx = _shard_inputs(total, h, w, shard.first, shard.count, dev)
+        tt = torch.full((3 * shard.count,), 481, dtype=torch.long, device=dev)
+        shard.install(eng, gflow, dev)
+        key = ("flows", shard.rank, shard.world)
+        if key not in keep:
+            keep[key] = [f[None].to(dev) for f in shard.local_flow(gflow)]
+        reg(sampler, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True)
+        reg(sampler, 1, switch_on=True, input_blocks=True, middle_block=False, output_blocks=False, chunks=3,
+            flow=keep[key], block_indices=list(range(9)), fusion="flow_fix", split_ratio_fft=0.8, alpha=0.8)
+        N, C, H, W = x.shape
+        cpad = (C + 7) // 8 * 8
+        xin = torch.empty(N * H * W, cpad, dtype=eng.dtype, device=dev)
+        hip.nchw_to_nhwc(x.float().contiguous(), xin, N=N, C_=C, hw=H * W, cpad=cpad)
+        eng.use_graph = graph
+        shard.begin_forward()
+        return eng.step_forward_nhwc(Act(xin, N, H, W), tt, ctx).clone().reshape(N, H * W, -1)
+
+    full = step(LoopbackShard(0, 1, total, {}), False)
+    for mode in ("p2p", "allgather"):
+        eng._graphs, eng._graph_failed = {}, set()
+        store = {}
+        shards = [RcclSelfLoop(r, world, total, mode, store) for r in range(world)]
+        equal = []
+        for graph in (False, True, True):        # kernel by kernel; the capturing call; a pure replay of the five segments
+            for sh in shards:
+                out = step(sh, graph)
+                ref = torch.cat([full[c * total + sh.first:c * total + sh.first + sh.count] for c in range(3)])
+                equal.append(bool(torch.equal(out, ref)))
+        torch.cuda.synchronize()
+        res[mode] = {"equal": equal, "segments": sorted(len(g["segments"]) for g in eng._graphs.values()),
+                     "graph_failed": len(eng._graph_failed), "exchange_calls": [sh.calls for sh in shards]}
+    eng.halo_exchange = None
+    dist.barrier()
+    dist.destroy_process_group()
+    with open(os.path.join(outdir, "rccl.json"), "w") as f:
+        json.dump(res, f)
+
+
+def test_rccl_world_size_one_exchange_forms_between_graph_segments(tmp_path):
+    """ONE contact with RCCL before the driver's multi-GPU run.  ``init_process_group("nccl", device_id=..)`` with
+    WORLD_SIZE = 1, an all-reduce, and both exchange forms of the frame-sharded ``flow_fix`` forward -- point-to-point
+    (``batch_isend_irecv``) and all-gather -- looped back to this rank through RCCL, issued eagerly and from the host BETWEEN the five
+    hipGraph segments of the captured forward (capture beside RCCL's watchdog thread); every shard's eps ``torch.equal`` to the unsharded
+    kernel-by-kernel forward."""
+    import json
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_rccl_selfloop, args=(_free_port(), str(tmp_path)))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0, p.exitcode
+    res = json.load(open(os.path.join(str(tmp_path), "rccl.json")))
+    print(res)
+    assert res["backend"] == "nccl" and res["world"] == 1 and res["all_reduce"] == [1.0] * 4
+    for mode in ("p2p", "allgather"):
+        r = res[mode]
+        assert all(r["equal"]) and len(r["equal"]) == 6, (mode, r)
+        assert r["segments"] == [5, 5] and r["graph_failed"] == 0, (mode, r)
