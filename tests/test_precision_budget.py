@@ -86,4 +86,7 @@ def test_smoke_bound_is_the_emulations():
         emu = pb.rel(pb.forward(pb.Emu(sd, w16=True, act16=True, stream16=False), spec, x, t, ctx, reg()), ref)
     print(f"emulated smoke case: {emu:.3e} (constant {smoke.EMULATED_REL_L2:.3e}, bound {smoke.SMOKE_BOUND:.3e})")
     assert abs(emu - smoke.EMULATED_REL_L2) / smoke.EMULATED_REL_L2 < 0.02
-    assert smoke.SMOKE_BOUND == 1.25 * smoke.EMULATED_REL_L2
+    # the bound follows the emulation only UNDER a fixed ceiling, and the emulated figure itself is held under a fixed one: a change that
+    # adds rounding points cannot raise its own tolerance
+    assert smoke.SMOKE_BOUND == min(smoke.SMOKE_CEILING, 1.25 * smoke.EMULATED_REL_L2) and smoke.SMOKE_CEILING == 1.5e-3
+    assert emu < 1.30e-3, emu

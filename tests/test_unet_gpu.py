@@ -149,8 +149,8 @@ def test_standalone_functions_vs_reference_golden():
         assert (w[0] - gw[f"warp_{case}"]).abs().max() < 6e-3, case
 
 
-@pytest.mark.parametrize("drop", [False, True])
-def test_cli_pipelined_inversion_is_bit_identical(tmp_path, drop):
+@pytest.mark.parametrize("drop,vae", [(False, False), (True, False), (True, True)])
+def test_cli_pipelined_inversion_is_bit_identical(tmp_path, drop, vae):
     """--pipeline_inversion (DDIMSampler.sample_while_inverting: batch k + 1's DDIM inversion beside batch k's sampling, on two
     streams, hooks switched per step) writes the frames of the sequential order, bit for bit -- three batches (inversion alone,
     two overlapped pairs, sampling alone), shipped hook schedule incl. the flow warp, with and without dead-branch elimination."""
@@ -165,13 +165,16 @@ def test_cli_pipelined_inversion_is_bit_identical(tmp_path, drop):
                 "--fusion", "flow_fix", "--flow_gate", "flow_hw", "--Base_dir", str(tmp_path / mode), "--ddim_steps", "50"]
         args += ["--pipeline_inversion"] if mode == "pipe" else []
         args += ["--drop_dead_branches"] if drop else []
+        args += ["--with_vae"] if vae else []        # (the VAE-in-the-loop path -- encode, DDIM, decode -- pipelined too)
         res = cli.main(args)
         assert len(res["batches"]) == 3 and all(b["finite"] for b in res["batches"])
         if mode == "pipe":
             assert [("sampling_beside_next_inversion" in b["stage_seconds"]) for b in res["batches"]] == [True, True, False]
         outs[mode] = [torch.load(tmp_path / mode / f"samples_batch{k}.pt") for k in range(3)]
-    for k in range(3):
-        assert torch.equal(outs["seq"][k], outs["pipe"][k]), f"batch {k}: pipelined != sequential ({_diff_pattern(outs['pipe'][k], outs['seq'][k])})"
+        if vae:
+            outs[mode] += [torch.load(tmp_path / mode / f"pixels_batch{k}.pt") for k in range(3)]
+    for k in range(len(outs["seq"])):
+        assert torch.equal(outs["seq"][k], outs["pipe"][k]), f"output {k}: pipelined != sequential ({_diff_pattern(outs['pipe'][k], outs['seq'][k])})"
 
 
 def test_cli_synthetic_smoke(tmp_path):

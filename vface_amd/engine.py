@@ -1243,7 +1243,11 @@ class UNetEngine:
         hands the same tensor object every step, so they are computed once per clip (the cache holds the tensor itself --
         its storage cannot be recycled under us -- and its version counter, so an in-place edit invalidates it)."""
         P = self._packed
-        cached = getattr(self, "_a2_cache", None)
+        # (one entry per context OBJECT, a few of them: two loops interleaved through one engine -- this batch's sampling and the
+        #  next batch's inversion, DDIMSampler.sample_while_inverting -- alternate two contexts and would evict a single entry at
+        #  every step of the eager path)
+        cache = self.__dict__.setdefault("_a2_lru", {})
+        cached = self.__dict__.get("_a2_cache") or cache.get(id(context))
         if cached is not None and cached[0] is context and cached[1] == context._version and cached[2] is P:
             return cached[3]
         ctx = context.reshape(N, -1)
@@ -1259,7 +1263,10 @@ class UNetEngine:
             if kind == "st":
                 a, b = P[prefix]["a2_slice"]
                 self._gemm(v_all[:, a:b], P[prefix]["a2_out"], a2_all[:, a:b], flags=hip.EPI_OUT_F32)
-        self._a2_cache = (context, context._version, P, a2_all)
+        cache.pop(id(context), None)
+        cache[id(context)] = (context, context._version, P, a2_all)      # most recently used last; the entry keeps its tensor alive
+        while len(cache) > 4:
+            cache.pop(next(iter(cache)))
         return a2_all
 
     def forward_nhwc(self, x: Act, timesteps: torch.Tensor, context: torch.Tensor) -> torch.Tensor:

@@ -230,25 +230,6 @@ def splitk_workspace(device, M: int, N: int, K: int, flags: int = 0, rows_per_sa
 
 
 # ---------------------------------------------------------------------------------------------- wrappers
-# EXPERIMENT switch (A/B runs only; unset = the library's own rule): VFACE_BIG_RULE = "off" | "min:<tiles>" | "eff:<max waste>:<min tiles>"
-def _parse_big_rule():
-    r = os.environ.get("VFACE_BIG_RULE")
-    if not r:
-        return None
-    if r == "off":
-        return lambda tiles: False
-    k = r.split(":")
-    if k[0] == "min":
-        return lambda tiles, m=int(k[1]): tiles >= m
-    if k[0] == "eff":
-        w, m = float(k[1]), int(k[2])
-        return lambda tiles: tiles >= m and (-(-tiles // 256)) * 256 / tiles <= w
-    raise ValueError(r)
-
-
-_BIG_RULE = _parse_big_rule()
-
-
 def gemm(a: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, M: int, N: int, K: int, lda: int, ldc: int,
          ldw: Optional[int] = None, bias=None, rowbias=None, rows_per_sample: int = 1, residual=None, ldr: int = 0,
          a2=None, lda2: int = 0, k1: int = 0, a2_row_mod: int = 0, flags: int = 0, colstats=None, split_k: bool = True,
@@ -256,8 +237,6 @@ def gemm(a: torch.Tensor, wt: torch.Tensor, out: torch.Tensor, *, M: int, N: int
     """out[M, :N] = a[M, :K] @ wt[:N, :K]^T (+ epilogue).  Tensors are device buffers; M/N/K/ld* describe the view.
     ``residual32`` / ``out32``: the fp32 residual stream (``vface_stream32``); ``out`` may be None with ``out32``."""
     lib = load()
-    if _BIG_RULE is not None and not (flags & (TUNE_BIG_TILE | TUNE_NO_BIG_TILE)):
-        flags |= TUNE_BIG_TILE if _BIG_RULE(((M + 255) // 256) * (N // 320)) else TUNE_NO_BIG_TILE
     ws, ws_bytes = splitk_workspace(a.device, M, N, K, flags, rows_per_sample) if split_k else (None, 0)
     rc = lib.vface_gemm(_p(a), lda, _p(a2), lda2, k1, a2_row_mod, _p(wt), ldw if ldw is not None else K, M, N, K,
                         _p(bias), _p(rowbias), rows_per_sample, rowbias.stride(0) if rowbias is not None else 0,

@@ -298,10 +298,11 @@ class DDIMSampler(object):
         return state["x"], state["intermediates"]
 
     def _invert_plan(self, x, cond, shape, unconditional_guidance_scale=1., unconditional_conditioning=None, inverse_dir=None,
-                     batch_size=6, max_steps=None, **kwargs):
-        """The inversion loop as ``(state, generator)`` on the schedule ``make_schedule`` has set: every ``next()`` switches the hooks
-        off (:389 -- again at every step, so that a sampling loop interleaved with this one may switch its own on in between),
-        enqueues ONE inversion step and stores the target half's latent."""
+                     batch_size=6, max_steps=None, interleaved=False, **kwargs):
+        """The inversion loop as ``(state, generator)`` on the schedule ``make_schedule`` has set: the hooks are switched off once in
+        front of the loop (:389), every ``next()`` enqueues ONE inversion step and stores the target half's latent.
+        ``interleaved`` (``sample_while_inverting``): a sampling loop runs between this one's steps and switches its own hooks on, so
+        they are switched off again at EVERY step."""
         if unconditional_conditioning is not None and unconditional_guidance_scale != 1.:
             raise NotImplementedError("guided inversion is not used by the VFace entry point (:540)")
         device = x.device
@@ -325,13 +326,19 @@ class DDIMSampler(object):
         ac = self._alphas_cumprod_host
         state = {"x": f32(x), "intermediates": {'x_inter': [x]}}
 
+        def hooks_off():
+            register_spa_attn_injection(self, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True,
+                                        attn_component="attn1", chunks=3)
+
         def steps():
             x = state["x"]
+            if not interleaved:
+                hooks_off()
             for i, step in enumerate(timesteps):
                 if max_steps is not None and i >= max_steps:
                     break
-                register_spa_attn_injection(self, 1, switch_on=False, input_blocks=True, middle_block=True, output_blocks=True,
-                                            attn_component="attn1", chunks=3)
+                if interleaved:
+                    hooks_off()
                 ts = torch.full((b,), int(step), device=device, dtype=torch.long)
                 x9 = torch.empty(b * H * W, 16, dtype=eng.dtype, device=device)
                 hip.nchw_to_nhwc(torch.cat([x, inpaint, mask], 1).contiguous(), x9, N=b, C_=9, hw=H * W, cpad=16)
@@ -369,15 +376,20 @@ class DDIMSampler(object):
         S, eta = sk.pop("S"), sk.pop("eta", 0.)
         if ik.pop("S") != S or ik.pop("eta", 0.) != eta:
             raise ValueError("sample_while_inverting: both loops walk ONE schedule (the same S and eta)")
-        for k in ("callback", "normals_sequence", "quantize_x0", "corrector_kwargs", "verbose", "tar"):
-            sk.pop(k, None)
+        # arguments `sample` / `ddim_invert` accept and do not act on (:186-252, :360-372) may be dropped; one that WOULD act is an
+        # error here rather than a silent difference from the sequential order (`callback` / `img_callback` are passed on)
+        for k, unused in (("normals_sequence", None), ("quantize_x0", False), ("corrector_kwargs", None), ("verbose", None), ("tar", None),
+                          ("src_im", None)):
+            v = sk.pop(k, unused)
+            if k in ("quantize_x0",) and v:
+                raise NotImplementedError(f"sample_while_inverting: {k}={v!r} is not part of the VFace path")
         for k in ("src_lm", "tar_lm"):
             ik.pop(k, None)
         batch_size, (C, H, W) = sk.pop("batch_size"), sk.pop("shape")
         ik.pop("shape", None)
         self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=False)
         st_s, g_s = self._sampling_plan(sk.pop("conditioning"), (batch_size, C, H, W), **sk)
-        st_i, g_i = self._invert_plan(ik.pop("x"), ik.pop("cond"), None, **ik)
+        st_i, g_i = self._invert_plan(ik.pop("x"), ik.pop("cond"), None, interleaved=True, **ik)
         cur = torch.cuda.current_stream()
         if getattr(self, "_pipe_streams", None) is None:
             self._pipe_streams = (torch.cuda.Stream(), torch.cuda.Stream())

@@ -4,7 +4,11 @@ import torch
 # rel-L2 that fp16 weights + one rounding per matrix-core operand (fp32 accumulation, statistics and residual stream) cost on the
 # smoke case, emulated on the CPU oracle (tests/precision_budget.py); the asserted bound is 1.25 x it, as for the bf16 UNet test
 EMULATED_REL_L2 = 1.26e-3
-SMOKE_BOUND = 1.25 * EMULATED_REL_L2
+# ... under an ABSOLUTE ceiling that does not move with the build's own rounding points: 1.5e-3, below the reference's own
+# fp16-autocast error on this size (2.06e-3, tests/golden/lowp.npz); tests/test_precision_budget.py also holds the emulated figure
+# itself under 1.30e-3, so a change that narrows the arithmetic cannot raise its own bound
+SMOKE_CEILING = 1.5e-3
+SMOKE_BOUND = min(SMOKE_CEILING, 1.25 * EMULATED_REL_L2)
 
 
 def smoke_case():
