@@ -67,9 +67,11 @@ def _run(rank, world, port, outdir):
         dist.destroy_process_group()
 
 
-def _shard_inputs(total, h, w, f0, fc, dev):
+def _shard_inputs(total, h, w, f0, fc, dev, sampler_batch=False):
+    """``sampler_batch``: chunks 0 and 1 get the same x (the batch the sampler assembles, ddim_w_inv.py:632-655) -- what the engine's
+    shared uncond / cond prefix (``share_prefix``) requires."""
     from vface_amd.utils import synth
-    xs = [synth.synth_normal(f"shard.x.{c}", (total, 9, h, w)) for c in range(3)]      # per chunk, per global frame
+    xs = [synth.synth_normal(f"shard.x.{0 if (sampler_batch and c == 1) else c}", (total, 9, h, w)) for c in range(3)]      # per chunk, per global frame
     cs = [synth.synth_normal(f"shard.c.{c}", (total, 1, 768)) for c in range(3)]
     x = torch.cat([t[f0:f0 + fc] for t in xs]).to(dev)
     ctx = torch.cat([t[f0:f0 + fc] for t in cs]).to(dev)
@@ -155,8 +157,11 @@ def test_two_rank_flow_fix_equals_unsharded(tmp_path):
     assert not failures, "; ".join(failures)
 
 
-def test_segmented_hipgraph_replay_of_sharded_forward_equals_unsharded():
-    """hipGraph replay of a FRAME-SHARDED forward: the forward is captured as graph segments cut at
+@pytest.mark.parametrize("share", [False, True])
+def test_segmented_hipgraph_replay_of_sharded_forward_equals_unsharded(share):
+    """(``share``: the sampler's batch with the uncond / cond prefix run once, UNetEngine._shared_block -- its warp branch with the
+    boundary exchange between chunk 1's fused projection and the warp.)
+    hipGraph replay of a FRAME-SHARDED forward: the forward is captured as graph segments cut at
     the two exchanges (engine._GraphSegments), the send / receive / wait calls run from the host between segment replays.
     Every shard's replayed eps must equal the unsharded kernel-by-kernel run bit for bit -- on the capturing call and on a
     pure replay -- and the capture must really be 5 segments (2 hooked level-0 layers x (start, finish))."""
@@ -178,7 +183,7 @@ def test_segmented_hipgraph_replay_of_sharded_forward_equals_unsharded():
     eng = ldm.unet.engine
 
     def step(shard, graph):
-        x, ctx = _shard_inputs(total, h, w, shard.first, shard.count, dev)
+        x, ctx = _shard_inputs(total, h, w, shard.first, shard.count, dev, sampler_batch=share)
         tt = torch.full((3 * shard.count,), 481, dtype=torch.long, device=dev)
         shard.install(eng, gflow, dev)
         flow = shard.local_flow(gflow)
@@ -197,10 +202,15 @@ def test_segmented_hipgraph_replay_of_sharded_forward_equals_unsharded():
         return eng.step_forward_nhwc(Act(xin, N, H, W), tt, ctx).clone().reshape(N, H * W, -1)
 
     keep = {}
-    old = eng.use_graph, eng._graphs
+    old = eng.use_graph, eng._graphs, eng.share_prefix
+    calls = []
+    orig = eng._shared_block
+    eng._shared_block = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
     try:
         eng._graphs = {}
-        full = step(LoopbackShard(0, 1, total, {}), False)
+        eng.share_prefix = False
+        full = step(LoopbackShard(0, 1, total, {}), False)      # the reference: unsharded, every chunk on its own, kernel by kernel
+        eng.share_prefix = share
         store = {}
         shards = [LoopbackShard(r, world, total, store) for r in range(world)]
         for call in range(2):           # call 0 captures (warm-up + capture pass + first replay), call 1 only replays
@@ -211,8 +221,10 @@ def test_segmented_hipgraph_replay_of_sharded_forward_equals_unsharded():
         assert not eng._graph_failed, "capture fell back to kernel-by-kernel launches"
         segs = sorted(len(g["segments"]) for g in eng._graphs.values())
         assert segs == [5, 5], segs
+        assert bool(calls) == share
     finally:
-        eng.use_graph, eng._graphs = old
+        eng.use_graph, eng._graphs, eng.share_prefix = old
+        del eng._shared_block
         eng.halo_exchange = None
 
 
@@ -353,7 +365,7 @@ def _rccl_selfloop(port, outdir):
     keep = {}
 
     def step(shard, graph):
-        x, ctx = _shard_inputs(total, h, w, shard.first, shard.count, dev)
+        x, ctx = _shard_inputs(total, h, w, shard.first, shard.count, dev, sampler_batch=True)
         tt = torch.full((3 * shard.count,), 481, dtype=torch.long, device=dev)
         shard.install(eng, gflow, dev)
         key = ("flows", shard.rank, shard.world)
@@ -371,10 +383,14 @@ def _rccl_selfloop(port, outdir):
         return eng.step_forward_nhwc(Act(xin, N, H, W), tt, ctx).clone().reshape(N, H * W, -1)
 
     full = step(LoopbackShard(0, 1, total, {}), False)
-    for mode in ("p2p", "allgather"):
+    for mode in ("p2p", "allgather", "p2p+shared_prefix"):
         eng._graphs, eng._graph_failed = {}, set()
+        # (the bench's multi-GPU line goes through the sampler: its batch runs the uncond / cond prefix once -- the inputs of this test
+        #  give chunks 0 and 1 the same x, so the shared and the unshared forward agree bit for bit under flow_fix)
+        eng.share_prefix = mode.endswith("shared_prefix")
+        mode_x = mode.split("+")[0]
         store = {}
-        shards = [RcclSelfLoop(r, world, total, mode, store) for r in range(world)]
+        shards = [RcclSelfLoop(r, world, total, mode_x, store) for r in range(world)]
         equal = []
         for graph in (False, True, True):        # kernel by kernel; the capturing call; a pure replay of the five segments
             for sh in shards:
@@ -406,7 +422,7 @@ def test_rccl_world_size_one_exchange_forms_between_graph_segments(tmp_path):
     res = json.load(open(os.path.join(str(tmp_path), "rccl.json")))
     print(res)
     assert res["backend"] == "nccl" and res["world"] == 1 and res["all_reduce"] == [1.0] * 4
-    for mode in ("p2p", "allgather"):
+    for mode in ("p2p", "allgather", "p2p+shared_prefix"):
         r = res[mode]
         assert all(r["equal"]) and len(r["equal"]) == 6, (mode, r)
         assert r["segments"] == [5, 5] and r["graph_failed"] == 0, (mode, r)
