@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VFACE_ABI_VERSION 6   /* 6: + the VFACE_TUNE_BIG_TILE / VFACE_TUNE_NO_BIG_TILE flag bits of vface_gemm (csrc/gemm_big.hip: the 256 x 320 tile, chosen by the library from 192 tiles on; same results), nothing else of 5 changed; 5: + vface_st_front, vface_attn_out_ffn_fused, vface_attn_out_ffn_proj_fused, vface_gn_silu_conv3x3_small, vface_linear_small; vface_attention's v_sets carries the live-set count in bits 8..15, vface_pack_unet_input / vface_ddim_step take the two-branch batch; nothing else of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
+#define VFACE_ABI_VERSION 7   /* 7: + the VFACE_TUNE_BIG_W256 / VFACE_TUNE_BIG_W320 flag bits of vface_gemm (the big tile's width: 256 x 256 beside 256 x 320, chosen by the library per launch; same results), nothing else of 6 changed; 6: + the VFACE_TUNE_BIG_TILE / VFACE_TUNE_NO_BIG_TILE flag bits of vface_gemm (csrc/gemm_big.hip: the 256 x 320 tile, chosen by the library from 192 tiles on; same results), nothing else of 5 changed; 5: + vface_st_front, vface_attn_out_ffn_fused, vface_attn_out_ffn_proj_fused, vface_gn_silu_conv3x3_small, vface_linear_small; vface_attention's v_sets carries the live-set count in bits 8..15, vface_pack_unet_input / vface_ddim_step take the two-branch batch; nothing else of 4 changed (4: + vface_ffn_fused, the flow-producer glue, the paste-back entry points) */
 
 #define VFACE_OK 0
 #define VFACE_ERR_ARG (-1)
@@ -57,6 +57,8 @@ extern "C" {
 #define VFACE_TUNE_F32_TRANSPOSE 0x1000000 /* A/B: the epilogue's LDS transpose in fp32 even where nothing reads the fp32 sum (default there: 16 bits) */
 #define VFACE_TUNE_BIG_TILE 0x10000000     /* vface_gemm: the 256 x 320 tile (csrc/gemm_big.hip) whenever the launch qualifies (N % 320 == 0, K % 64 == 0, 16-bit output, bias / GEGLU / fp32 residual only), however few tiles; default: from 192 tiles on.  Same bits as the 128-row kernel */
 #define VFACE_TUNE_NO_BIG_TILE 0x20000000  /* A/B: never the 256 x 320 tile */
+#define VFACE_TUNE_BIG_W256 0x200000       /* vface_gemm, big tile: 256 channels per tile wherever N % 256 == 0 (default: the width whose one-workgroup-per-CU grid takes fewer tile-times).  Same bits */
+#define VFACE_TUNE_BIG_W320 0x400000       /* A/B: always 320 channels per tile */
 /* (VFACE_TUNE_PATCH on vface_gemm: run a plain GEMM with M % 256 == 0, K % 64 == 0, N % 128|160 == 0, no GEGLU / fp32-only output
  *  through the patch-staged kernel's 256-row tile -- same bits as the default kernel, measured 3-18 % SLOWER on the UNet's shapes
  *  (tools/bench_kernels.py "patch256"): an A/B switch, never chosen automatically) */

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol():
     for name in decls:
         assert hasattr(lib, name), f"{name} declared in include/vface_hip.h but not exported"
     lib.vface_abi_version.restype = ctypes.c_int
-    assert lib.vface_abi_version() == 6
+    assert lib.vface_abi_version() == 7
 
 
 def test_ctypes_table_matches_header():

@@ -1335,12 +1335,15 @@ def test_ffn_fused_rejects_what_it_cannot_run():
 
 # ------------------------------------------------------------------------------------------ the 256 x 320 tile (csrc/gemm_big.hip)
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(512, 640, 640), (1000, 320, 128), (768, 1920, 1280), (256, 1280, 2560)])
+@pytest.mark.parametrize("M,N,K", [(512, 640, 640), (1000, 320, 128), (768, 1920, 1280), (256, 1280, 2560), (1000, 2560, 384), (512, 1280, 128),
+                                   (300, 3840, 256)])
 def test_gemm_big_tile_equals_128_row_kernel_bit_for_bit(dt, M, N, K):
     """The 256 x 320 tile accumulates every output in the 128-row kernel's order (K tile by K tile, k32 half 0 then half 1, the
     same MFMA and operand roles): same bits -- plain, + bias, GEGLU, + bias + fp32 residual rows, dual-source K, strided views and
     a row count that is not a multiple of the tile (1000) -- and both within the fp16 bound of an fp64 computation."""
     h = hip()
+    # the 128-row kernel; the big tile 320 channels wide; the big tile 256 channels wide (round 6; where N % 256 != 0 the flag falls back to 320)
+    FORMS = (h.TUNE_NO_BIG_TILE, h.TUNE_BIG_TILE | h.TUNE_BIG_W320, h.TUNE_BIG_TILE | h.TUNE_BIG_W256)
     a, w = rnd((M, K), 1, dt).to(DEV), rnd((N, K), 2, dt, 1 / math.sqrt(K)).to(DEV)
     bias = rnd((N,), 3, torch.float32).to(DEV)
     res32 = rnd((M, N), 6, torch.float32).to(DEV)
@@ -1355,34 +1358,34 @@ def test_gemm_big_tile_equals_128_row_kernel_bit_for_bit(dt, M, N, K):
              ("bias+res16", dict(bias=bias, residual=res16, ldr=N), a.double() @ w.double().t() + bias.double() + res16.double())]
     for name, kw, ref in cases:
         outs = []
-        for fl in (h.TUNE_NO_BIG_TILE, h.TUNE_BIG_TILE):
+        for fl in FORMS:
             o = torch.full((M, N + 16), 7.0, dtype=dt, device=DEV)
             h.gemm(wide[:, 32:], w, o[:, 8:], M=M, N=N, K=K, lda=K + 64, ldc=N + 16, flags=fl, split_k=False, **kw)
             outs.append(o)
         assert rel_l2(outs[1][:, 8:8 + N].double().cpu(), ref.cpu()) < (1e-3 if dt == torch.float16 else 8e-3), name
-        assert torch.equal(outs[0], outs[1]), f"{name}: the two tiles' outputs differ"      # (and nothing outside the view was written)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), f"{name}: the tiles' outputs differ"      # (and nothing outside the view was written)
     # dual-source K (the hook's linear fusions: [x_c | x_0] against the folded [2d, 2d] weight)
     outs = []
-    for fl in (h.TUNE_NO_BIG_TILE, h.TUNE_BIG_TILE):
+    for fl in FORMS:
         o = torch.empty(M, N, dtype=dt, device=DEV)
         h.gemm(a[:, :K // 2], w, o, M=M, N=N, K=K, lda=K, ldc=N, a2=a0, lda2=K // 2, k1=K // 2, flags=fl, split_k=False)
         outs.append(o)
     ref = torch.cat([a[:, :K // 2], a0], 1).double() @ w.double().t()
     assert rel_l2(outs[1].double().cpu(), ref.cpu()) < (1e-3 if dt == torch.float16 else 8e-3)
-    assert torch.equal(outs[0], outs[1]), "dual-source K: the two tiles' outputs differ"
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "dual-source K: the tiles' outputs differ"
     # GEGLU (weight rows interleaved in 16-row value / gate blocks)
     from vface_amd import packing
     wp, bp = packing.pack_geglu(w.float().cpu(), bias.cpu())
     wp, bp = wp.to(device=DEV, dtype=dt), bp.to(DEV)
     outs = []
-    for fl in (h.TUNE_NO_BIG_TILE, h.TUNE_BIG_TILE):
+    for fl in FORMS:
         o = torch.empty(M, N // 2, dtype=dt, device=DEV)
         h.gemm(a, wp, o, M=M, N=N, K=K, lda=K, ldc=N // 2, bias=bp, flags=fl | h.EPI_GEGLU, split_k=False)
         outs.append(o)
     y = a.double() @ w.double().t() + bias.double()
     ref = y[:, :N // 2] * F.gelu(y[:, N // 2:])
     assert rel_l2(outs[1].double().cpu(), ref.cpu()) < (1e-3 if dt == torch.float16 else 8e-3)
-    assert torch.equal(outs[0], outs[1]), "GEGLU: the two tiles' outputs differ"
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "GEGLU: the tiles' outputs differ"
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])

@@ -36,8 +36,16 @@ namespace {
 constexpr int BM2 = 256, BN2 = 320;
 constexpr int A_BYTES = BM2 * 128, B_BYTES = BN2 * 128, STAGE_BYTES = A_BYTES + B_BYTES;   // 32 KB + 40 KB
 
-template <class TT, int EPI>
+// NJ: 16-channel tiles per wave -- 10 = the 256 x 320 tile; 8 = a 256 x 256 tile (round 6): the same kernel with eight weight pieces and
+// sixteen steps per K tile, for the launches whose 320-wide tile count leaves the last round of the one-workgroup-per-CU grid mostly
+// empty (N = 1280: 4 n-tiles x 96 m-tiles = 1.5 rounds; five 256-wide n-tiles make 1.875 rounds of tiles 0.8 as long).  Every output
+// element's MFMA order over K is unchanged, so the bits are too and the launcher may pick the width by the batch.
+template <class TT, int EPI, int NJ = 10>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
+    static_assert(NJ == 10 || (NJ == 8 && EPI != 3), "channel tiles per wave");
+    constexpr int BN2 = 32 * NJ, WN = 16 * NJ;                       // tile width; channels per wave
+    constexpr int B_BYTES = BN2 * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int NPC = 4 + NJ / 2, NS = 2 * NJ;                      // LDS-DMA pieces per wave and K tile; steps per K tile
     using E = typename TT::elem;
     using V8 = typename TT::v8;
     using V4 = typename TT::v4;
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // ---- staging map.  Piece q = rows 8q .. 8q+7 of a tile (1 KiB, lane-linear in LDS): lane l -> row 8q + (l >> 3), 16-B slot
     // l & 7 holds logical k-chunk (l & 7) ^ ((row >> 1) & 7).  Wave w issues activation pieces w, w+8, w+16, w+24 and weight
     // pieces w, w+8, .., w+32.
-    unsigned a_off[4], a2_off[4], b_off[5];
+    unsigned a_off[4], a2_off[4], b_off[NJ / 2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = (wave + 8 * i) * 8 + (lane >> 3);
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         a2_off[i] = (p.A2 && m < p.M) ? (unsigned)((m * p.lda2 + ch * 8) * 2) : OOB;
     }
 #pragma unroll
-    for (int i = 0; i < 5; ++i) {
+    for (int i = 0; i < NJ / 2; ++i) {
         const int row = (wave + 8 * i) * 8 + (lane >> 3);
         const unsigned ch = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
         b_off[i] = (unsigned)((((long)(n0 + row)) * p.ldw + ch * 8) * 2);
@@ -111,15 +119,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         }
     };
 
-    f4_t acc[10][4];   // [channel tile j][row tile i]
+    f4_t acc[NJ][4];   // [channel tile j][row tile i]
 #pragma unroll
-    for (int j = 0; j < 10; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[j][i] = f4_t{0.f, 0.f, 0.f, 0.f};
 
     // fragment addresses inside a stage (k32 half 0; half 1 = the same address with byte bit 6 flipped; row tiles and channel
     // tiles are 16 rows = 2 KiB apart and keep the swizzle term)
-    const int arow = wm * 64 + fr, wrow = wn * 160 + fr;
+    const int arow = wm * 64 + fr, wrow = wn * WN + fr;
     const unsigned aadr = (unsigned)(arow * 128 + ((fq ^ ((arow >> 1) & 7)) << 4));
     const unsigned wadr = (unsigned)(A_BYTES + wrow * 128 + ((fq ^ ((wrow >> 1) & 7)) << 4));
 
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     // of tile kt+2 go out at steps 18, 19 of tile kt and 0..6 of tile kt+1, a full tile ahead of their use.
     const int nt = p.K >> 6;
 #pragma unroll
-    for (int s = 0; s < 9; ++s) issue_piece(s, 0, 0);
+    for (int s = 0; s < NPC; ++s) issue_piece(s, 0, 0);
     if (nt > 1) { issue_piece(0, 1, 1); issue_piece(1, 1, 1); }      // (what steps 18, 19 of a tile "-1" would have issued)
     V8 af[2][4], wf[4];
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");          // tile 0 has landed (the two pieces of tile 1 may still fly)
@@ -149,33 +157,33 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         const unsigned char* st = smem_raw + cur * STAGE_BYTES;
         const unsigned char* sn = smem_raw + (cur ^ 1) * STAGE_BYTES;
 #pragma unroll
-        for (int s = 0; s < 20; ++s) {
-            const int kk = s / 10, j = s - kk * 10;
-            if (s == 18 && more) {
+        for (int s = 0; s < NS; ++s) {
+            const int kk = s / NJ, j = s - kk * NJ;
+            if (s == NS - 2 && more) {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
             }
             {
                 const int s2 = s + 2;
-                if (s2 < 20) {
-                    const int kk2 = s2 / 10, j2 = s2 - kk2 * 10;
+                if (s2 < NS) {
+                    const int kk2 = s2 / NJ, j2 = s2 - kk2 * NJ;
                     wf[s2 & 3] = *reinterpret_cast<const V8*>(st + ((wadr + j2 * 2048) ^ (kk2 ? 64u : 0u)));
                 } else if (more) {
-                    wf[s2 & 3] = *reinterpret_cast<const V8*>(sn + wadr + (s2 - 20) * 2048);
+                    wf[s2 & 3] = *reinterpret_cast<const V8*>(sn + wadr + (s2 - NS) * 2048);
                 }
             }
             if (s == 4) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) af[1][i] = *reinterpret_cast<const V8*>(st + ((aadr + i * 2048) ^ 64u));
             }
-            if (s == 18 && more) {
+            if (s == NS - 2 && more) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) af[0][i] = *reinterpret_cast<const V8*>(sn + aadr + i * 2048);
             }
             // pieces of the tile after next: 0, 1 at steps 18, 19 (into the stage this tile just left), 2..8 at steps 0..6 of the next
-            if (s >= 18) { if (more2) issue_piece(s - 18, kt + 2, cur); }
-            else if (s < 7) { if (more) issue_piece(s + 2, kt + 1, cur ^ 1); }
+            if (s >= NS - 2) { if (more2) issue_piece(s - (NS - 2), kt + 2, cur); }
+            else if (s < NPC - 2) { if (more) issue_piece(s + 2, kt + 1, cur ^ 1); }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -203,16 +211,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(vec ? (const void*)vec : p.Wt), 0, vec ? p.N * 4 : 0, 0x00020000);
 #pragma unroll
             for (int jh = 0; jh < 2; ++jh) {
-                f4_t bj[5];
+                constexpr int HJ = NJ / 2;
+                f4_t bj[HJ];
 #pragma unroll
-                for (int j = 0; j < 5; ++j)
-                    bj[j] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rV, (n0 + wn * 160 + (jh * 5 + j) * 16 + fq * 4) * 4, 0, 0));
+                for (int j = 0; j < HJ; ++j)
+                    bj[j] = __builtin_bit_cast(f4_t, __builtin_amdgcn_raw_buffer_load_b128(rV, (n0 + wn * WN + (jh * HJ + j) * 16 + fq * 4) * 4, 0, 0));
 #pragma unroll
-                for (int j = 0; j < 5; ++j)
+                for (int j = 0; j < HJ; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        acc[jh * 5 + j][i] += bj[j];
-                        asm volatile("" : "+v"(acc[jh * 5 + j][i]));      // (pinned HERE: hipcc otherwise sinks the sums to their first use and spills the vector meanwhile)
+                        acc[jh * HJ + j][i] += bj[j];
+                        asm volatile("" : "+v"(acc[jh * HJ + j][i]));      // (pinned HERE: hipcc otherwise sinks the sums to their first use and spills the vector meanwhile)
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -227,12 +236,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     __builtin_amdgcn_sched_barrier(0);      // (nothing of the passes below is hoisted above the bias sums: its registers are those the bias held)
     E* Cout = reinterpret_cast<E*>(p.C);
     if constexpr (EPI == 0 || EPI == 1) {
-        constexpr int OW = EPI == 1 ? 80 : 160;          // output channels of this wave
+        constexpr int OW = EPI == 1 ? WN / 2 : WN;        // output channels of this wave
         constexpr int CH = OW / 8;                       // 16-byte chunks per output row
         constexpr int SPH = OW * 2 + 16;                 // scratch row pitch (bytes)
         constexpr int NIT = (16 * CH + 63) / 64;
         unsigned char* scr = smem_raw + wave * (16 * SPH);
-        const int ncol0 = EPI == 1 ? ((n0 + wn * 160) >> 1) : (n0 + wn * 160);
+        const int ncol0 = EPI == 1 ? ((n0 + wn * WN) >> 1) : (n0 + wn * WN);
         int rr[NIT], cc[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -245,11 +254,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
             unsigned char* hrow = scr + fr * SPH + fq * 8;
             if constexpr (EPI == 0) {
 #pragma unroll
-                for (int j = 0; j < 10; ++j)
+                for (int j = 0; j < NJ; ++j)
                     *reinterpret_cast<V4*>(hrow + j * 32) = V4{from_f32<E>(acc[j][i][0]), from_f32<E>(acc[j][i][1]), from_f32<E>(acc[j][i][2]), from_f32<E>(acc[j][i][3])};
             } else {
 #pragma unroll
-                for (int jj = 0; jj < 5; ++jj) {
+                for (int jj = 0; jj < NJ / 2; ++jj) {
                     // value rows in the even channel tiles, gate rows 16 further in the odd ones (packing.pack_geglu)
                     const float a0 = acc[2 * jj][i][0], a1 = acc[2 * jj][i][1], a2 = acc[2 * jj][i][2], a3 = acc[2 * jj][i][3];
                     const float g0 = acc[2 * jj + 1][i][0], g1 = acc[2 * jj + 1][i][1], g2 = acc[2 * jj + 1][i][2], g3 = acc[2 * jj + 1][i][3];
@@ -365,23 +374,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     } else {
         // fp32 transposes; the residual rows and the output go through buffer descriptors (32-bit offsets, rows past M are
         // out-of-range offsets: loads return zeros, stores are dropped) -- one offset register per chunk instead of a pointer pair
-        constexpr int SP = 164;                          // fp32 scratch row pitch (floats)
+        constexpr int SP = WN + 4;                       // fp32 scratch row pitch (floats)
+        constexpr int CPR = WN / 8, NPASS = 16 * CPR / 64;       // 8-channel chunks per row; passes of 64 lanes per row tile (5 | 4)
         float* scr = reinterpret_cast<float*>(smem_raw) + wave * (16 * SP);
-        const int ncol0 = n0 + wn * 160;
+        const int ncol0 = n0 + wn * WN;
         const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.residual), 0, (int)p.res_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(p.C, 0, (int)p.c_bytes, 0x00020000);
-        unsigned lofs[5];                                // LDS byte offset of this lane's chunk (row rr, chunk cc) per pass
-        int rr[5], cc[5];
+        unsigned lofs[NPASS];                            // LDS byte offset of this lane's chunk (row rr, chunk cc) per pass
+        int rr[NPASS], cc[NPASS];
 #pragma unroll
-        for (int it = 0; it < 5; ++it) {
+        for (int it = 0; it < NPASS; ++it) {
             const int idx = lane + 64 * it;
-            rr[it] = idx / 20;
-            cc[it] = idx - rr[it] * 20;
+            rr[it] = idx / CPR;
+            cc[it] = idx - rr[it] * CPR;
             lofs[it] = (unsigned)((rr[it] * SP + cc[it] * 8) * 4);
         }
         // residual rows as a RING of one row tile (40 registers): pass `it` of row tile i + 1 is requested the moment pass `it` of row
         // tile i has been summed -- five passes ahead of its use; two full row tiles in flight do not fit beside the accumulators
-        f4_t r32[5][2];
+        f4_t r32[NPASS][2];
         const bool res16 = !p.res_f32;      // 16-bit residual rows (a block's interior running sum kept in 16 bits): one 16-byte load per chunk
         auto load_res = [&](int i, int it) {
             const long m = wrow0 + i * 16 + rr[it];
@@ -400,15 +410,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
         for (int i = 0; i < 4; ++i) {
             float* srow = scr + fr * SP + fq * 4;
 #pragma unroll
-            for (int j = 0; j < 10; ++j)
+            for (int j = 0; j < NJ; ++j)
                 *reinterpret_cast<float4*>(srow + j * 16) = make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
             __builtin_amdgcn_sched_barrier(0);
             if (i == 0) {      // (the first row tile's residual rows: requested once its accumulators have left their registers)
 #pragma unroll
-                for (int it = 0; it < 5; ++it) load_res(0, it);
+                for (int it = 0; it < NPASS; ++it) load_res(0, it);
             }
 #pragma unroll
-            for (int it = 0; it < 5; ++it) {
+            for (int it = 0; it < NPASS; ++it) {
                 const unsigned char* lrd = reinterpret_cast<const unsigned char*>(scr) + lofs[it];
                 const f4_t x0 = *reinterpret_cast<const f4_t*>(lrd), x1 = *reinterpret_cast<const f4_t*>(lrd + 16);
                 const f4_t a = r32[it][0], b = r32[it][1];
@@ -426,18 +436,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(GemmParams p) {
     }
 }
 
-template <class TT, int EPI>
+template <class TT, int EPI, int NJ>
 int launch_big(const GemmParams& p, hipStream_t stream) {
-    auto kern = gemm256_kernel<TT, EPI>;
+    auto kern = gemm256_kernel<TT, EPI, NJ>;
     static VfOncePerDevice attr_set;
-    constexpr int lds = 2 * STAGE_BYTES;
+    constexpr int BN = 32 * NJ;
+    constexpr int lds = 2 * (A_BYTES + BN * 128);
     if (!attr_set.set_lds(reinterpret_cast<const void*>(kern), lds)) return VF_ERR_LAUNCH;
-    const int ntn = p.N / BN2, ntm = (p.M + BM2 - 1) / BM2;
+    const int ntn = p.N / BN, ntm = (p.M + BM2 - 1) / BM2;
     GemmParams q = p;
     {
         // column-group width of the XCD-aware tile order: gemm.hip's rule (bytes through an XCD's L2 are least at
         // GN = sqrt(tiles_xcd * A_mt / W_nt); the GN weight panels stay within half of the 4 MiB L2)
-        const double a_mt = (double)BM2 * p.K * 2.0, w_nt = (double)BN2 * p.K * 2.0;
+        const double a_mt = (double)BM2 * p.K * 2.0, w_nt = (double)BN * p.K * 2.0;
         int gn = (int)(__builtin_sqrt((double)ntm * ntn / 8.0 * a_mt / w_nt) + 0.5);
         const int cap = (int)(2097152.0 / w_nt);
         if (gn > cap) gn = cap;
@@ -447,12 +458,33 @@ int launch_big(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? VF_OK : VF_ERR_LAUNCH;
 }
 
+// Tile width of a launch: 320 channels, or 256 where N allows both, K is short and the one-workgroup-per-CU grid then takes fewer
+// tile-times (rounds of 256 workgroups).  MEASURED (tools/bench_gemm_widths.py, profiles/r06_h): a 256-wide tile is NOT 0.8 of a 320-wide
+// one when K is deep -- ff2 at K = 5120: 240 tiles in one round take as long as 192 (175 vs 180 us at 48 samples; 361 vs 349 at 96),
+// the K loop waits for its activation pieces, which five n-tiles per m-tile request instead of four -- it pays where the prologue and
+// epilogue weigh: the 1280 x 1280 projections (55 -> 45 us at 48 samples, 90 -> 80 at 96) and the dual-source projection under one
+// round (80 -> 70).  Hence: K <= 1280 only, and only where the rounds say so at 0.85 of a tile-time.  The two widths give the same bits,
+// so the choice may follow the batch.  GEMM_BIG_W256 / _W320 (tuning bits of vface_gemm: tests and A/B runs) force one.
+template <class TT, int EPI>
+int launch_big_width(const GemmParams& p, hipStream_t stream) {
+    if constexpr (EPI != 3) {
+        bool w256 = false;
+        if (p.N % 256 == 0 && !(p.flags & GEMM_BIG_W320)) {
+            const long ntm = (p.M + BM2 - 1) / BM2;
+            const long r320 = (ntm * (p.N / 320) + 255) / 256, r256 = (ntm * (p.N / 256) + 255) / 256;
+            w256 = (p.flags & GEMM_BIG_W256) || (p.K <= 1280 && (double)r256 * 0.85 < (double)r320);
+        }
+        if (w256) return launch_big<TT, EPI, 8>(p, stream);
+    }
+    return launch_big<TT, EPI, 10>(p, stream);
+}
+
 template <class TT>
 int launch_big_dtype(const GemmParams& p, hipStream_t stream) {
-    if (p.C32) return launch_big<TT, 3>(p, stream);
-    if (p.flags & GEMM_GEGLU) return launch_big<TT, 1>(p, stream);
-    if (p.residual) return launch_big<TT, 2>(p, stream);
-    return launch_big<TT, 0>(p, stream);
+    if (p.C32) return launch_big_width<TT, 3>(p, stream);
+    if (p.flags & GEMM_GEGLU) return launch_big_width<TT, 1>(p, stream);
+    if (p.residual) return launch_big_width<TT, 2>(p, stream);
+    return launch_big_width<TT, 0>(p, stream);
 }
 
 }  // namespace

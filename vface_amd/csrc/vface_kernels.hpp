@@ -23,7 +23,8 @@ struct VfOncePerDevice {
 
 enum { GEMM_GEGLU = 1, GEMM_OUT_F32 = 2, GEMM_NO_XCD_REMAP = 0x1000, GEMM_NO_SETPRIO = 0x2000, GEMM_NARROW_EPILOGUE = 0x8000, GEMM_NO_PERSIST = 0x10000, GEMM_PERSIST = 0x20000,
        GEMM_NO_PATCH = 0x80000, GEMM_PATCH = 0x100000, GEMM_GN8 = 0x8000000 /* A/B: fixed column groups of 8 n-tiles in the plain GEMM's tile order */, GEMM_NO_Q8 = 0x4000000 /* A/B: the 8x8 level stays on the im2col kernel */, GEMM_PATCH_BN160 = 0x2000000 /* A/B: the patch kernel's 160-wide tile wherever it divides N */, GEMM_F32_TRANSPOSE = 0x1000000 /* A/B: epilogue transposes in fp32 even where 16 bits would do */,
-       GEMM_BIG = 0x10000000 /* take gemm_big.hip's 256 x 320 tile whenever the launch qualifies */, GEMM_NO_BIG = 0x20000000 /* A/B: never */ };  // (0x40000 = VFACE_CONV_PAD_TRAILING)  // bits 8..11 of flags: forced schedule variant (0 = automatic)
+       GEMM_BIG = 0x10000000 /* take gemm_big.hip's 256 x 320 tile whenever the launch qualifies */, GEMM_NO_BIG = 0x20000000 /* A/B: never */,
+       GEMM_BIG_W256 = 0x200000 /* gemm_big.hip: the 256-channel tile width wherever N allows it */, GEMM_BIG_W320 = 0x400000 /* ... never */ };  // (0x40000 = VFACE_CONV_PAD_TRAILING)  // bits 8..11 of flags: forced schedule variant (0 = automatic)
 
 struct GemmParams {
     int mode;  // 0: plain A[M][K]; 1: implicit 3x3 conv over NHWC

@@ -26,6 +26,7 @@ TUNE_NO_Q8 = 0x4000000  # A/B: the 8x8 level stays on the im2col kernel
 TUNE_PATCH_BN160 = 0x2000000  # A/B: patch kernel's 160-wide tile wherever it divides Cout
 TUNE_F32_TRANSPOSE = 0x1000000  # A/B: epilogue transposes through LDS in fp32 even where 16 bits would do
 TUNE_NO_PERSISTENT, TUNE_PERSISTENT = 0x10000, 0x20000  # flags of gemm / conv3x3: force one workgroup per tile / the persistent form
+TUNE_BIG_W256, TUNE_BIG_W320 = 0x200000, 0x400000  # gemm, big tile: force the 256- / the 320-channel width (default: by grid rounds; same bits)
 TUNE_BIG_TILE, TUNE_NO_BIG_TILE = 0x10000000, 0x20000000  # gemm: always (where the launch qualifies) / never the 256 x 320 tile (csrc/gemm_big.hip)
 FUSION_NONE, FUSION_REPLACE, FUSION_LINEAR = 0, 1, 2
 
@@ -134,7 +135,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.vface_abi_version() != 6:
+    if lib.vface_abi_version() != 7:
         raise VFaceHipError("libvface_hip.so ABI version mismatch")
     _lib = lib
     return lib
