@@ -699,9 +699,12 @@ int launch_q8(const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 // The 8 x 8 level through the patch-staged kernel (Q8 form): 0 = not such a launch, else the K split (number of fp32 partial
-// tiles per output tile).  Four images per workgroup and N / 128 channel tiles give (nimg / 4) * (N / 128) workgroups -- 60 at
-// the nominal 24-sample batch of the UNet's 1280-channel level -- so K is split over channel chunks until the one-per-CU grid
+// tiles per output tile).  Four images per workgroup and N / 128 channel tiles give (nimg / 4) * (N / 128) workgroups -- 120 at
+// the nominal 48-sample batch of the UNet's 1280-channel level -- so K is split over channel chunks until the one-per-CU grid
 // is about one round; the split follows the NOMINAL batch (the fp32 summation order must not depend on the launch's batch).
+// Nominal = 48 samples since round 6, like the tile-width rule below (one launch stream's half of the 32-frame headline, a rank's
+// 16-frame share at N > 1): K in two shares instead of four -- half the prologues, epilogues and fp32 partials.  Same-box A/B
+// (profiles/r06_i): 32 frames 76.22 -> 75.83 ms/step (conv family 31.65 -> 30.96); the 8-frame clip pays for it, 20.0 -> 20.6.
 int vf_conv_q8_split(const GemmParams& p) {
     if (p.mode != 1 || p.stride != 1 || p.upsample || p.out_phase || (p.Cin & 63) || p.gn_ab) return 0;
     if (p.H != 8 || p.W != 8 || p.OH != 8 || p.OW != 8 || p.KH != 3 || p.KW != 3 || p.ntaps != 9 || p.pad != 1 || p.pad_x != 1) return 0;
@@ -709,7 +712,7 @@ int vf_conv_q8_split(const GemmParams& p) {
     if (p.A2 && ((p.K - p.K1) & 63)) return 0;
     if (p.rows_per_sample != 64 && p.rowbias) return 0;
     const int nchunks = p.Cin >> 6;
-    const long tiles24 = 6L * (p.N / 128);
+    const long tiles24 = 12L * (p.N / 128);      // (the name is history: the nominal batch is 48 samples = 12 image quads)
     int s = (int)(256 / tiles24);
     if (s > 8) s = 8;
     if (s > nchunks / 2) s = nchunks / 2;       // at least two chunks (18 K tiles) per share
