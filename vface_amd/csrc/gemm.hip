@@ -1020,7 +1020,7 @@ long vf_splitk_workspace_bytes(int M, int N, int K, int flags, int rows_per_samp
     if (rows_per_sample == 64 && (N % 128) == 0 && !(flags & (GEMM_GEGLU | GEMM_OUT_F32))) {
         // a 3x3 convolution on 8x8 images may take the Q8 form (conv.hip: vf_conv_q8_split), which always ends in fp32 partials:
         // room for the largest split that rule can choose for this N
-        int s8 = (int)(256 / (6L * (N / 128)));
+        int s8 = (int)(256 / (12L * (N / 128)));      // (vf_conv_q8_split's nominal 48-sample grid)
         if (s8 > 8) s8 = 8;
         if (s8 < 1) s8 = 1;
         if (s8 > s) s = s8;

@@ -264,13 +264,17 @@ def attn_module_forward(mod, x: torch.Tensor, context: Optional[torch.Tensor], c
 
 
 def _phase_form_pays(hw_in: int, cout: int) -> bool:
-    """The four parity-phase launches of an upsampling conv each cover hw_in rows per sample: below ~400 tiles per
-    launch (at the nominal 24-sample batch, so the choice -- and the bits -- do not depend on the batch) the 9-tap form
-    on the upsampled grid fills the chip better (measured: 8x8 -> 16x16 at 1280 channels 230 vs 284 us; 16x16 -> 32x32
-    741 vs 375 us)."""
+    """The four parity-phase launches of an upsampling conv each cover hw_in rows per sample: below ~200 tiles per launch the
+    9-tap form on the upsampled grid fills the chip better.  The tile count is taken at a NOMINAL batch, so the choice -- and the
+    bits -- do not depend on the batch: 48 samples since round 6 (one launch stream's half of the 32-frame headline, a rank's 16-frame
+    share at N > 1), like the convolution kernels' own rules.  At 48 the 8x8 -> 16x16 upsampling at 1280 channels takes the phase form
+    too (measured, profiles/r05_m / r06_j: 369 vs 434 us at 48 samples, 399 vs 829 at 96 -- and 369 vs 224 at 24, which the 8-frame
+    clip pays); same-box A/B on the headline: 76.00 -> 75.42 ms/step.  VFACE_PHASE_NOMINAL24=1: the rule of rounds 2-5 (A/B)."""
     if os.environ.get("VFACE_NO_PHASE_UPSAMPLE") == "1":   # A/B switch for measurements
         return False
-    return (24 * hw_in // 128) * (cout // 128) >= 400
+    if os.environ.get("VFACE_PHASE_NOMINAL24") == "1":
+        return (24 * hw_in // 128) * (cout // 128) >= 400
+    return (48 * hw_in // 128) * (cout // 128) >= 200
 
 
 class _GraphSegments:
