@@ -205,7 +205,10 @@ __global__ __launch_bounds__(64) void gn_coeffs_cols_kernel(const float* __restr
     }
 }
 
-template <class TT, bool IN32>
+// DEEP: four pixels per trip with their loads issued together (the small maps); !DEEP: one pixel per trip (the large maps: enough
+// workgroups in flight to hide a single load per trip) -- its own instantiation since round 6: 40 instead of 96 registers per lane, so
+// that a wave of it fits beside the matrix kernels of another launch stream (gemm256 leaves 48 free, eight-wave attention 80)
+template <class TT, bool IN32, bool DEEP>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ x, long ldx,
                                                        const float* __restrict__ stats,
                                                        const float* __restrict__ gamma,
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const void* __restrict__ 
         }
         // four pixels per trip, their loads issued together: on the small maps (8x8, 16x16 images) a thread's pixel loop was a
         // chain of dependent load -> store round trips (17-22 us per launch for ~10 MB)
-        if (pix_per_block > 32) {      // large maps: enough workgroups in flight to hide a single load per trip
+        if constexpr (!DEEP) {
             for (int p = p0 + lanep; p < p1; p += PP) {
                 float v[8];
                 load8<TT, IN32>(x, xb + (long)p * ldx + ch * 8, v);
@@ -811,8 +814,13 @@ int vf_launch_gn_apply(const void* x, long ldx, const float* stats, const float*
     dim3 grid((hw + ppb - 1) / ppb, nimg);
     DISPATCH_DTYPE(dtype, {
         using E = typename TT::elem;
-        if (in_f32) hipLaunchKernelGGL((gn_apply_kernel<TT, true>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
-        else hipLaunchKernelGGL((gn_apply_kernel<TT, false>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
+        if (ppb > 32) {
+            if (in_f32) hipLaunchKernelGGL((gn_apply_kernel<TT, true, false>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
+            else hipLaunchKernelGGL((gn_apply_kernel<TT, false, false>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
+        } else {
+            if (in_f32) hipLaunchKernelGGL((gn_apply_kernel<TT, true, true>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
+            else hipLaunchKernelGGL((gn_apply_kernel<TT, false, true>), grid, dim3(256), 0, stream, x, ldx, stats, gamma, beta, (E*)y, ldy, hw, C, groups, silu, ppb);
+        }
     });
     return ok();
 }
