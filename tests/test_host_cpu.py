@@ -401,3 +401,26 @@ def test_every_built_kernel_keeps_its_values_in_registers():
                     spilled.append((sym, int(k[".private_segment_fixed_size"])))
     assert n > 200, n
     assert not spilled, spilled
+
+
+def test_shipped_flow_warp_has_no_select_behind_a_packed_product():
+    """Round 5 / 6: the one instruction schedule that ever mis-executed beside another queue's attention waves had a
+    ``v_cndmask_b32`` reading, within three issue slots, the result of a packed-fp32 instruction (``v_pk_mul_f32 v[40:41]`` ->
+    ``v_cndmask_b32_e32 v40, 0, v40, vcc``).  The shipped warp forms its weights without selects; this reads its listing from the build
+    (tools/codeobj_audit.py, no GPU) and fails if hipcc ever brings that pair back."""
+    import sys
+    import tempfile
+    obj = os.path.join(ROOT, "vface_amd", "csrc", "build", "pointwise.hip.o")
+    if not os.path.exists(obj) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("no build objects / no llvm-objdump here")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import codeobj_audit as audit
+    sites = []
+    with tempfile.TemporaryDirectory() as td:
+        co = audit.extract(obj, td)
+        assert co is not None
+        stats = audit.scan(co, sites)
+    warp = [k for k in stats if "flow_warp_kernel" in k]
+    assert warp, "flow_warp_kernel not found in pointwise.hip.o"
+    bad = [(k, d, p, c) for k, d, p, c in sites if "flow_warp_kernel" in k and c.startswith("v_cndmask")]
+    assert not bad, bad

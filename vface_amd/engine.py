@@ -640,7 +640,9 @@ class UNetEngine:
             elif kind in ("share_qk", "share_v"):
                 # _st_front_shared with a warp: slot 0 = chunk 1's warped q|k, slot 1 = chunk 0's q|k and the v of chunks 0, 1
                 idx = torch.arange(B, dtype=torch.int32)
-                m = torch.where(idx < c, idx + c, torch.where((idx < 2 * c) & torch.tensor(kind == "share_qk"), idx - c, idx))
+                m = torch.where(idx < c, idx + c, idx)            # chunk 0 reads slot 1 (q|k and v)
+                if kind == "share_qk":
+                    m = torch.where((idx >= c) & (idx < 2 * c), idx - c, m)      # chunk 1's q|k: slot 0 (its v stays in slot 1 = itself)
             else:  # v_fixed: chunk 0 identity, chunk k >= 1 -> its first frame
                 idx = torch.arange(B, dtype=torch.int32)
                 m = torch.where(idx < c, idx, (idx // c) * c)
