@@ -513,7 +513,14 @@ def main():
                 eng.exchange_events.clear()
             timer.on = instrument
             t0 = time.perf_counter()
+            done_clips = []
             for i in range(n_steps):
+                if i and i % len(steps) == 0:
+                    # K beyond one schedule: a new clip's start latents -- the synthetic UNet iterated through the schedule again and
+                    # again on its own output leaves fp32 range.  A tensor hand-over, nothing enqueued; the finished clip's latents are
+                    # kept so that the bit comparison between the timed region and the kernel-by-kernel pass covers every step
+                    done_clips.append(img)
+                    img = x_T
                 img = one_step(img, i)
             t_enq = time.perf_counter() - t0      # host time to enqueue the steps (the GPU runs behind)
             fence()
@@ -567,7 +574,7 @@ def main():
                    "between them (engine._GraphSegments)"))
         eng.exchange_events = None
         sampler.drop_dead_branches = False
-        return {"final_latents": img.detach().clone(),
+        return {"final_latents": torch.cat([t.detach() for t in done_clips] + [img.detach()]).clone(),
                 "ms_step": el / n_steps * 1e3, "enqueue_ms": t_enq / n_steps * 1e3, "inv_ms": inv_ms, "elapsed": el,
                 "launch": launch, "exchange": exch, "h": h}
 
