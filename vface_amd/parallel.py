@@ -4,7 +4,7 @@ The hot path shards by frame: every rank runs the full 3-way batch for a contigu
 structure injection have no cross-frame dependency; flow-guided smoothing reads exactly one
 neighbour (F9): rank r needs rank r-1's LAST frame's fused q|k of chunk 1 at the level-0 hooked layers.  That is
 the only exchange step on the path, and the only collective this module issues: per hooked level-0 layer and
-DDIM step, a ``[n, 2d]`` 16-bit slab (2.6 MB at 512x512) moves one hop down the chain -- point-to-point
+DDIM step, a ``[n, 2d]`` 16-bit slab (5.2 MB at 512x512: 2.6 MB each of q and k) moves one hop down the chain -- point-to-point
 ``isend/irecv`` (xGMI is point-to-point, so a one-hop shift costs one link transfer), or an all-gather of the
 slabs when ``mode="allgather"``.  The transfer is started right after chunk 1's fused projection and waited for
 just before the warp, so it overlaps chunk 2's projection (see ``UNetEngine._attn1_sharded``).
