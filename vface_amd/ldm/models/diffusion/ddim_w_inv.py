@@ -391,9 +391,12 @@ class DDIMSampler(object):
         st_s, g_s = self._sampling_plan(sk.pop("conditioning"), (batch_size, C, H, W), **sk)
         st_i, g_i = self._invert_plan(ik.pop("x"), ik.pop("cond"), None, interleaved=True, **ik)
         cur = torch.cuda.current_stream()
-        if getattr(self, "_pipe_streams", None) is None:
-            self._pipe_streams = (torch.cuda.Stream(), torch.cuda.Stream())
         eng = self.model.model.diffusion_model.engine
+        if getattr(self, "_pipe_streams", None) is None:
+            # a pair whose launches really overlap (HIP maps streams onto a few hardware queues; two streams on one queue run their
+            # launches one after the other -- seen in round 6: 1.41 s instead of 1.07 s for a pipelined batch): the engine's probe,
+            # a spin kernel on each stream timed together and alone, up to three pairs
+            self._pipe_streams = tuple(eng._concurrent_stream_pair())
         saved_split = eng.split_streams
         eng.split_streams = 1          # the two loops ARE the two launch sequences
         for s in self._pipe_streams:
