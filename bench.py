@@ -562,7 +562,8 @@ def main():
             el = float(tt.item())
         split2 = graphed and any(k[0] != "plan" and "streams" in v for k, v in eng._split_state.items() if isinstance(v, dict))
         # (a coupled configuration whose single sequence measured faster than its two coupled halves stays on one: UNetEngine.split_timing)
-        chose_one = ("coupled", (2 if drop else 3) * F_) in eng._split_off
+        tkey = ("coupled", (2 if drop else 3) * F_, h, h)
+        chose_one = tkey in eng._split_off
         if chose_one:
             split2, nseg = False, 1          # (the halves' segmented graphs are still cached; the steps replay the whole batch's single graph)
         two = split2 and (nseg <= 1 or dist is None)
@@ -572,7 +573,7 @@ def main():
             two_text += (f"; the halves are coupled through one frame (flow_fix: half 0 hands its last frame's fused q|k to half 1 through a "
                          f"slot + event, parallel.StreamShard), each half a chain of {nseg} graph segments cut at the hand-overs")
         if chose_one:
-            t2, t1 = eng.split_timing[("coupled", (2 if drop else 3) * F_)]
+            t2, t1 = eng.split_timing[tkey]
             two_text = (f": ONE launch sequence -- the engine timed this configuration both ways on its second step ({t2:.2f} ms as two coupled "
                         f"frame halves on two streams, {t1:.2f} ms as one sequence) and kept the faster")
         launch = ("kernel by kernel" if not graphed else
@@ -645,7 +646,7 @@ def main():
                            "launch_streams": 2 if "two halves" in e["launch"] else 1, "two_streams_bits_equal_one_sequence": same2,
                            # flow_fix: ms of one step as two coupled launch sequences / as one, timed once by the engine on the second step
                            # of this configuration; it keeps the faster form (one sequence only if it wins by more than 1 %)
-                           "engine_two_vs_one_sequence_ms": eng.split_timing.get(("coupled", 3 * f2)),
+                           "engine_two_vs_one_sequence_ms": eng.split_timing.get(("coupled", 3 * f2, e["h"], e["h"])),
                            "steps": a.extra_steps if res2 == 512 else max(3, a.extra_steps // 2), "warmup": 2,
                            "launch": "hipGraph replay" if e["launch"] != "kernel by kernel" else "kernel by kernel",
                            "ms_per_step": e["ms_step"], "host_enqueue_ms_per_step": e["enqueue_ms"],

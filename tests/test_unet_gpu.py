@@ -605,8 +605,8 @@ def test_two_launch_streams_equal_one(small, fusion):
             if streams == 2 and fusion == "flow_fix":
                 assert any("shard_objs" in v for k, v in eng._split_state.items() if k[0] != "plan"), "the coupled halves ran as stream shards"
                 # ... and the engine timed the configuration both ways on its second step (it keeps the faster form: either is exact)
-                t2, t1 = eng.split_timing[("coupled", 3 * F_)]
-                assert t2 > 0 and t1 > 0 and ((("coupled", 3 * F_) in eng._split_off) == (t1 < 0.99 * t2))
+                t2, t1 = eng.split_timing[("coupled", 3 * F_, h, w)]
+                assert t2 > 0 and t1 > 0 and ((("coupled", 3 * F_, h, w) in eng._split_off) == (t1 < 0.99 * t2))
         for what, a_, b_ in zip(("sampling 3F", "sampling 2F (dead branches dropped)", "inversion"), res[1], res[2]):
             assert torch.equal(a_, b_), f"{fusion}, {what}: two streams != one -- {_diff_pattern(b_, a_)}"
         if fusion == "replace":

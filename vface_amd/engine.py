@@ -485,7 +485,7 @@ class UNetEngine:
         # return the single sequence's result and stay on one launch sequence for good.  VFACE_SPLIT_SELFCHECK=0 skips it.
         self.split_selfcheck = os.environ.get("VFACE_SPLIT_SELFCHECK", "1") != "0"
         self.split_checked: Dict[str, bool] = {}       # kind -> the halves' eps equalled the single sequence's
-        self.split_timing: Dict[tuple, tuple] = {}     # ("coupled", samples) -> (ms of a two-sequence step, ms of a one-sequence step)
+        self.split_timing: Dict[tuple, tuple] = {}     # ("coupled", samples, H, W) -> (ms of a two-sequence step, ms of a one-sequence step)
         self._split_off: set = set()                   # ... the configurations that stay on one launch sequence because it measured faster
         hip.load()
 
@@ -1579,7 +1579,7 @@ class UNetEngine:
         # (batch size) configuration both forms are timed once -- one replay each, the whole batch's graph captured for it -- and the
         # configuration keeps the faster one (the single sequence only if it wins by more than 1 %).  Skipped where the extra graph
         # would crowd the graph cache (the whole batch's pool ~ the two halves' together).
-        if coupled and self.split_selfcheck and st["calls"] == 2 and ("coupled", N) not in self.split_timing and \
+        if coupled and self.split_selfcheck and st["calls"] == 2 and ("coupled", N, x.H, x.W) not in self.split_timing and \
                 4 * sum(v["bytes"] for v in self._graphs.values()) <= self.graph_budget_bytes:
             def timed(fn):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1590,11 +1590,12 @@ class UNetEngine:
                 return e0.elapsed_time(e1), out
             self._step_forward_one(x, timesteps, context)                    # (captures the whole batch's graph if the bit check above did not)
             t_whole, _ = timed(lambda: self._step_forward_one(x, timesteps, context))
-            self.split_timing[("coupled", N)] = (None, t_whole)              # (set first: the nested split call below must not recurse here)
+            tkey = ("coupled", N, x.H, x.W)
+            self.split_timing[tkey] = (None, t_whole)                        # (set first: the nested split call below must not recurse here)
             t_split, eps = timed(lambda: self._step_forward_split(x, timesteps, context, plan))
-            self.split_timing[("coupled", N)] = (t_split, t_whole)
+            self.split_timing[tkey] = (t_split, t_whole)
             if t_whole < 0.99 * t_split:
-                self._split_off.add(("coupled", N))
+                self._split_off.add(tkey)
             return eps
         return st["eps"]
 
@@ -1603,7 +1604,7 @@ class UNetEngine:
         coupled, the two frame halves through ``_step_forward_one`` at once."""
         if self.use_graph and x.t32 is None and x.t.is_contiguous():
             plan = self._split_plan(x.N)
-            if plan is not None and not (self._split_coupled and ("coupled", x.N) in self._split_off):
+            if plan is not None and not (self._split_coupled and ("coupled", x.N, x.H, x.W) in self._split_off):
                 return self._step_forward_split(x, timesteps, context, plan)
         return self._step_forward_one(x, timesteps, context)
 
