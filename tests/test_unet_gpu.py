@@ -598,6 +598,7 @@ def test_two_launch_streams_equal_one(small, fusion):
         res = {}
         for streams in (1, 2):
             eng.use_graph, eng._graphs, eng._split_state, eng.split_streams = True, {}, {}, streams
+            eng._split_off.clear(); eng.split_timing.clear()       # (a configuration an earlier case timed faster as ONE sequence would not split at all)
             res[streams] = (run(False), run(True), invert())
             assert not eng._graph_failed
             split = [k for k in eng._split_state if k[0] != "plan"]
@@ -606,7 +607,7 @@ def test_two_launch_streams_equal_one(small, fusion):
                 assert any("shard_objs" in v for k, v in eng._split_state.items() if k[0] != "plan"), "the coupled halves ran as stream shards"
                 # ... and the engine timed the configuration both ways on its second step (it keeps the faster form: either is exact)
                 t2, t1 = eng.split_timing[("coupled", 3 * F_, h, w)]
-                assert t2 > 0 and t1 > 0 and ((("coupled", 3 * F_, h, w) in eng._split_off) == (t1 < 0.99 * t2))
+                assert t2 > 0 and t1 > 0 and ((("coupled", 3 * F_, h, w) in eng._split_off) == (t1 < 0.995 * t2))
         for what, a_, b_ in zip(("sampling 3F", "sampling 2F (dead branches dropped)", "inversion"), res[1], res[2]):
             assert torch.equal(a_, b_), f"{fusion}, {what}: two streams != one -- {_diff_pattern(b_, a_)}"
         if fusion == "replace":
@@ -614,6 +615,7 @@ def test_two_launch_streams_equal_one(small, fusion):
             # detected on the second split step and the engine returns to one launch sequence -- with the right bits throughout
             one = torch.cuda.Stream()
             eng.use_graph, eng._graphs, eng._split_state, eng.split_streams = True, {}, {}, 2
+            eng._split_off.clear(); eng.split_timing.clear()
             eng._split_pair, eng._split_verified, eng.split_overlap = [one, one], False, None
             with pytest.warns(UserWarning, match="do not overlap"):
                 r = run(False)

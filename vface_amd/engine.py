@@ -465,7 +465,7 @@ class UNetEngine:
         self.use_graph = os.environ.get("VFACE_GRAPH", "1") != "0"
         self._graphs: "Dict[tuple, dict]" = {}
         self._graph_failed: set = set()       # keys whose capture failed: they run kernel by kernel, other keys still capture
-        self.graph_capacity = 8
+        self.graph_capacity = 12        # (a split configuration holds three graphs: two halves and, for its self-check and timing, the whole batch)
         self.graph_budget_bytes = int(float(os.environ.get("VFACE_GRAPH_GB", "64")) * (1 << 30))
         # Two launch streams (VFACE_STREAMS=2, the default; 1 = one stream): a graph-replayed forward whose frames are not coupled
         # across the split (no hook, or replace / fft / mix: every edit stays inside a frame's own chunks) runs as two half-batches
@@ -485,7 +485,7 @@ class UNetEngine:
         # return the single sequence's result and stay on one launch sequence for good.  VFACE_SPLIT_SELFCHECK=0 skips it.
         self.split_selfcheck = os.environ.get("VFACE_SPLIT_SELFCHECK", "1") != "0"
         self.split_checked: Dict[str, bool] = {}       # kind -> the halves' eps equalled the single sequence's
-        self.split_timing: Dict[tuple, tuple] = {}     # ("coupled", samples, H, W) -> (ms of a two-sequence step, ms of a one-sequence step)
+        self.split_timing: Dict[tuple, tuple] = {}     # (kind, samples, H, W) -> (ms of a two-sequence step, ms of a one-sequence step)
         self._split_off: set = set()                   # ... the configurations that stay on one launch sequence because it measured faster
         hip.load()
 
@@ -1574,12 +1574,15 @@ class UNetEngine:
                               "device: back to one launch sequence")
                 self.split_streams = 1
                 return whole
-        # Coupled halves (flow_fix) wait for each other at every hooked flow layer: whether two launch sequences beat one depends on
-        # the batch (round 6, one box: 16 frames 38.0 vs 38.5 ms, 32 frames 75.7 vs 74.6).  On the second split step of every coupled
-        # (batch size) configuration both forms are timed once -- one replay each, the whole batch's graph captured for it -- and the
-        # configuration keeps the faster one (the single sequence only if it wins by more than 1 %).  Skipped where the extra graph
-        # would crowd the graph cache (the whole batch's pool ~ the two halves' together).
-        if coupled and self.split_selfcheck and st["calls"] == 2 and ("coupled", N, x.H, x.W) not in self.split_timing and \
+        # Whether two launch sequences beat one depends on the batch, the hook mode and the box: coupled (flow_fix) halves wait for each other
+        # at every hooked flow layer (round 6: 16 frames 38.0 vs 38.5 ms, 32 frames 78.0 vs 74.2), and since the launch rules follow the
+        # 48-sample half batch and the shared block issues its tail twice, free halves no longer win everywhere either (32 frames fft, same
+        # box: 75.3 vs 74.4-75.0 as one sequence; round 4-5: two sequences won by 1-4 %).  So on the second split step of every (kind,
+        # batch, resolution) BOTH forms are timed -- two replays each, the whole batch's graph captured for it -- and the configuration
+        # keeps the faster one (the single sequence only if it wins by more than 0.5 %).  Skipped where the extra graph would crowd the
+        # graph cache (the whole batch's pool ~ the two halves' together).
+        tkey = (kind, N, x.H, x.W)
+        if self.split_selfcheck and st["calls"] == 2 and tkey not in self.split_timing and \
                 4 * sum(v["bytes"] for v in self._graphs.values()) <= self.graph_budget_bytes:
             def timed(fn):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1589,12 +1592,12 @@ class UNetEngine:
                 e1.synchronize()
                 return e0.elapsed_time(e1), out
             self._step_forward_one(x, timesteps, context)                    # (captures the whole batch's graph if the bit check above did not)
-            t_whole, _ = timed(lambda: self._step_forward_one(x, timesteps, context))
-            tkey = ("coupled", N, x.H, x.W)
-            self.split_timing[tkey] = (None, t_whole)                        # (set first: the nested split call below must not recurse here)
+            self.split_timing[tkey] = (None, None)                           # (set first: the nested split calls below must not recurse here)
+            t_whole = min(timed(lambda: self._step_forward_one(x, timesteps, context))[0] for _ in range(2))
             t_split, eps = timed(lambda: self._step_forward_split(x, timesteps, context, plan))
+            t_split = min(t_split, timed(lambda: self._step_forward_split(x, timesteps, context, plan))[0])
             self.split_timing[tkey] = (t_split, t_whole)
-            if t_whole < 0.99 * t_split:
+            if t_whole < 0.995 * t_split:
                 self._split_off.add(tkey)
             return eps
         return st["eps"]
@@ -1604,7 +1607,7 @@ class UNetEngine:
         coupled, the two frame halves through ``_step_forward_one`` at once."""
         if self.use_graph and x.t32 is None and x.t.is_contiguous():
             plan = self._split_plan(x.N)
-            if plan is not None and not (self._split_coupled and ("coupled", x.N, x.H, x.W) in self._split_off):
+            if plan is not None and ("coupled" if self._split_coupled else "free", x.N, x.H, x.W) not in self._split_off:
                 return self._step_forward_split(x, timesteps, context, plan)
         return self._step_forward_one(x, timesteps, context)
 
