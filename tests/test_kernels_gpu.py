@@ -1423,6 +1423,31 @@ def test_gemm_big_tile_residual_stream_form(dt, M, N, K, rps):
             assert torch.allclose(outs[1][2].double(), want, rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("M,N,K,kind", [(24576, 1280, 512, "res16"), (24576, 3840, 256, "plain"), (24576 + 300, 1280, 256, "geglu")])
+def test_gemm_default_dispatch_at_full_batch_keeps_the_bits(M, N, K, kind):
+    """The library's own choice among its plain-GEMM forms at the headline's row counts (the 128-row kernel, the big tile 320 or 256 channels
+    wide -- N = 1280 / 3840 allow both widths) gives the bits of either kernel forced, with a residual operand, through GEGLU, and with a
+    ragged row count.  (Round 6 also tried cutting a 1.5-round grid by rows between the two kernels: same bits, no gain -- the big tile's
+    full round is itself activation-bound on these shapes -- and not kept.)"""
+    h = hip()
+    dt = torch.float16
+    a, w = rnd((M, K), 1, dt).to(DEV), rnd((N, K), 2, dt, 1 / math.sqrt(K)).to(DEV)
+    bias = rnd((N,), 3, torch.float32).to(DEV)
+    kw, base, ncol = dict(), 0, N
+    if kind == "res16":
+        kw = dict(bias=bias, residual=rnd((M, N), 4, dt).to(DEV), ldr=N)
+    elif kind == "geglu":
+        from vface_amd import packing
+        wp, bp = packing.pack_geglu(w.float().cpu(), bias.cpu())
+        w, kw, base, ncol = wp.to(device=DEV, dtype=dt), dict(bias=bp.to(DEV)), h.EPI_GEGLU, N // 2
+    outs = []
+    for fl in (0, h.TUNE_NO_BIG_TILE, h.TUNE_BIG_TILE):
+        o = torch.full((M, ncol + 8), 7.0, dtype=dt, device=DEV)
+        h.gemm(a, w, o[:, :ncol], M=M, N=N, K=K, lda=K, ldc=ncol + 8, flags=base | fl, split_k=False, **kw)
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_gemm_big_tile_refuses_what_it_cannot_do():
     """VFACE_TUNE_BIG_TILE is a preference, not a different result: a launch the 256 x 320 tile does not take (N % 320 != 0; a row
     bias whose samples are shorter than the tile; an fp32-only output) runs the 128-row kernel and gives that kernel's bits."""
